@@ -1,0 +1,127 @@
+/*
+ * pwg_kernels.h -- C ABI of libpwgkernels.so, the MI355X (gfx950) kernel library
+ * behind the ParallelWaveGAN-compatible Python surface in parallelwavegan_amd/.
+ *
+ * The reference (kan-bayashi/ParallelWaveGAN) has no native code: every FLOP of
+ * its hot path is an ATen op called from Python.  Each entry
+ * point below therefore replaces an ATen *call site* in the reference; the
+ * file:line of that call site (relative to /root/reference/) is cited on every
+ * declaration.  A maintainer binds these with ctypes.
+ *
+ * Conventions
+ *   - plain C: raw device pointers (fp32, contiguous NCW), ints, floats; no
+ *     torch types.  `stream` is a hipStream_t passed as void*.
+ *   - the library allocates nothing; every buffer incl. packed weights and
+ *     workspaces is owned by the caller.
+ *   - every launch goes to `stream`; no implicit device synchronisation.
+ *   - return value: PWG_OK (0) or a negative pwg_status; pwg_last_error()
+ *     returns a thread-local human-readable message for the last failure.
+ */
+#ifndef PWG_KERNELS_H_
+#define PWG_KERNELS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum pwg_status {
+  PWG_OK = 0,
+  PWG_ERR_BAD_SHAPE = -1,   /* inconsistent sizes in a descriptor            */
+  PWG_ERR_UNSUPPORTED = -2, /* valid request this build has no kernel for     */
+  PWG_ERR_LAUNCH = -3,      /* hipLaunchKernel / hipGetLastError failed        */
+  PWG_ERR_NULL = -4,        /* required pointer is NULL                        */
+  PWG_ERR_WORKSPACE = -5    /* workspace too small                             */
+} pwg_status;
+
+const char* pwg_last_error(void);
+/* ABI version: bumped on any signature change. */
+int pwg_abi_version(void);
+/* Returns 950 (the only ISA this library is built for). */
+int pwg_target_arch(void);
+
+/* ------------------------------------------------------------------------- */
+/* Activations / padding selectors                                            */
+/* ------------------------------------------------------------------------- */
+enum { PWG_ACT_NONE = 0, PWG_ACT_LEAKY_RELU = 1, PWG_ACT_TANH = 2, PWG_ACT_RELU = 3 };
+enum { PWG_PAD_ZERO = 0, PWG_PAD_REFLECT = 1, PWG_PAD_REPLICATE = 2 };
+
+/* ------------------------------------------------------------------------- */
+/* 1-D convolution family                                                     */
+/*                                                                            */
+/* One descriptor covers every convolution on the hot path:                   */
+/*   - torch.nn.Conv1d (dilated / strided / grouped), e.g.                    */
+/*       layers/residual_block.py:190-196,213-220  (HiFi-GAN MRF)             */
+/*       layers/residual_block.py:78-86             (PWG dilated gate conv)   */
+/*       models/hifigan.py:75-81,143-149            (input / output conv)     */
+/*       models/hifigan.py:516-568                  (MSD grouped strided)     */
+/*       layers/residual_stack.py:47-55             (MelGAN stack, reflect)   */
+/*   - torch.nn.ConvTranspose1d, computed polyphase (transposed = 1):         */
+/*       models/hifigan.py:99-107, models/melgan.py:93-101                    */
+/*   - torch.nn.Conv2d with (k,1) kernels on the period-folded view           */
+/*       (width = period): models/hifigan.py:314-341                          */
+/*                                                                            */
+/* Fused around the contraction (all optional):                               */
+/*   y = post_act( (conv(pre_act(pad(x)), w) + bias + add1 + add2) * out_mul  */
+/*                  / out_div )                                               */
+/* which is how `x = xt + x` (residual_block.py:257), the MRF `cs += ...;     */
+/* c = cs / num_blocks` (hifigan.py:186-190) and the final Tanh               */
+/* (hifigan.py:150) disappear into the producing kernel.                      */
+/* ------------------------------------------------------------------------- */
+typedef struct pwg_conv1d_desc {
+  int32_t batch;
+  int32_t c_in;       /* total input channels                                 */
+  int32_t c_out;      /* total output channels                                */
+  int32_t t_in;       /* input length  (rows H for the (k,1) Conv2d case)     */
+  int32_t t_out;      /* output length (rows H_out)                           */
+  int32_t width;      /* 1 for Conv1d; the period p for (k,1) Conv2d          */
+  int32_t kernel;     /* taps                                                 */
+  int32_t stride;
+  int32_t dilation;
+  int32_t pad_left;   /* implicit padding on the left (zeros/reflect/...)     */
+  int32_t groups;
+  int32_t transposed; /* 0: Conv1d semantics, 1: ConvTranspose1d semantics    */
+                      /*    (stride = upsampling factor, pad_left = `padding`)*/
+  int32_t pad_mode;   /* PWG_PAD_*  (reflect/replicate only for width==1)     */
+  int32_t pre_act;    /* PWG_ACT_NONE | LEAKY_RELU | RELU applied to x        */
+  float pre_slope;
+  int32_t post_act;   /* PWG_ACT_* applied to the result                      */
+  float post_slope;
+  float out_mul;      /* 1.0f = off                                           */
+  float out_div;      /* 1.0f = off  (true IEEE division, matches `cs / 3`)   */
+} pwg_conv1d_desc;
+
+/* Number of floats of the packed weight image for `d` (forward direction). */
+size_t pwg_conv1d_packed_weight_floats(const pwg_conv1d_desc* d);
+
+/* Re-layout a torch-format weight into the kernel's [group][tap][ci][M] image.
+ *   transposed == 0: w is (c_out, c_in/groups, kernel)   [torch Conv1d]
+ *   transposed == 1: w is (c_in, c_out/groups, kernel)   [torch ConvTranspose1d]
+ * `scale` (optional, may be NULL) holds one multiplier per dim-0 slice of w,
+ * i.e. g/||v|| of old-style weight_norm (see pwg_weight_norm_scale), so that
+ * weight_norm + pack is one pass.                                             */
+int pwg_conv1d_pack_weight(const pwg_conv1d_desc* d, const float* w, const float* scale,
+                           float* w_packed, void* stream);
+
+/* y = fused conv forward (see above).  bias/add1/add2 may be NULL.
+ * x: (batch, c_in, t_in*width)  y/add1/add2: (batch, c_out, t_out*width)     */
+int pwg_conv1d_forward(const pwg_conv1d_desc* d, const float* x, const float* w_packed,
+                       const float* bias, const float* add1, const float* add2, float* y,
+                       void* stream);
+
+/* Old-style torch.nn.utils.weight_norm (dim=0) scale: scale[i] = g[i]/||v[i,...]||_2
+ * replaces torch._weight_norm at every conv call site.
+ * v: (n0, inner) flattened, g: (n0).                                          */
+int pwg_weight_norm_scale(const float* v, const float* g, float* scale, int32_t n0,
+                          int32_t inner, void* stream);
+/* w = v * scale[dim0]  (materialises the torch-format weight, e.g. for
+ * remove_weight_norm(): models/hifigan.py:209-219)                            */
+int pwg_scale_rows(const float* v, const float* scale, float* w, int32_t n0, int32_t inner,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PWG_KERNELS_H_ */

@@ -1,0 +1,61 @@
+"""Slaney-style mel filterbank, numpy restatement of ``librosa.filters.mel``.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  The product's own copy of this
+formula lives in parallelwavegan_amd/losses/mel_basis.py; the two are written
+independently of each other's code path and compared in tests.
+
+Third-party algorithm: librosa (``librosa>=0.8.0``, reference setup.py:29) is
+not vendored under /root/reference and not installed here, so the *values* of
+the basis are PARITY-UNPINNED.  Call sites in the reference:
+``parallel_wavegan/losses/mel_loss.py:52-59`` and
+``parallel_wavegan/bin/preprocess.py:72-78``.
+
+Published algorithm (librosa docs, ``htk=False, norm="slaney"``):
+  * mel(f) = f / (200/3)                      for f <  1000 Hz
+             15 + ln(f/1000) / (ln(6.4)/27)   for f >= 1000 Hz
+  * n_mels+2 edges equally spaced in mel in [fmin, fmax], mapped back to Hz
+  * triangle i: max(0, min((f-e_i)/(e_{i+1}-e_i), (e_{i+2}-f)/(e_{i+2}-e_{i+1})))
+    evaluated at the rfft bin centres f_k = k*sr/n_fft
+  * area normalisation: row i *= 2/(e_{i+2}-e_i)
+  * float32 result of shape (n_mels, 1+n_fft//2)
+"""
+import numpy as np
+
+_F_SP = 200.0 / 3.0
+_MIN_LOG_HZ = 1000.0
+_MIN_LOG_MEL = _MIN_LOG_HZ / _F_SP
+_LOGSTEP = np.log(6.4) / 27.0
+
+
+def hz_to_mel(f):
+    f = np.asarray(f, dtype=np.float64)
+    lin = f / _F_SP
+    with np.errstate(divide="ignore", invalid="ignore"):
+        log = _MIN_LOG_MEL + np.log(np.maximum(f, 1e-300) / _MIN_LOG_HZ) / _LOGSTEP
+    return np.where(f >= _MIN_LOG_HZ, log, lin)
+
+
+def mel_to_hz(m):
+    m = np.asarray(m, dtype=np.float64)
+    lin = m * _F_SP
+    log = _MIN_LOG_HZ * np.exp(_LOGSTEP * (m - _MIN_LOG_MEL))
+    return np.where(m >= _MIN_LOG_MEL, log, lin)
+
+
+def mel(sr, n_fft, n_mels=128, fmin=0.0, fmax=None):
+    """Return the (n_mels, 1 + n_fft//2) float32 Slaney mel basis."""
+    if fmax is None:
+        fmax = sr / 2.0
+    n_bins = 1 + n_fft // 2
+    fftfreqs = np.arange(n_bins, dtype=np.float64) * (float(sr) / n_fft)
+    edges = mel_to_hz(np.linspace(hz_to_mel(fmin), hz_to_mel(fmax), n_mels + 2))
+    fdiff = np.diff(edges)
+    ramps = edges[:, None] - fftfreqs[None, :]
+    weights = np.zeros((n_mels, n_bins), dtype=np.float64)
+    for i in range(n_mels):
+        lower = -ramps[i] / fdiff[i]
+        upper = ramps[i + 2] / fdiff[i + 1]
+        weights[i] = np.maximum(0.0, np.minimum(lower, upper))
+    enorm = 2.0 / (edges[2 : n_mels + 2] - edges[:n_mels])
+    weights *= enorm[:, None]
+    return weights.astype(np.float32)

@@ -1,0 +1,85 @@
+"""ctypes binding of libpwgkernels.so (the C ABI declared in include/pwg_kernels.h).
+
+The library is the ONLY compute path of this package: there is no CPU or
+PyTorch-op fallback.  If it cannot be loaded, every op raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpwgkernels.so")
+
+PWG_ACT_NONE, PWG_ACT_LEAKY_RELU, PWG_ACT_TANH, PWG_ACT_RELU = 0, 1, 2, 3
+PWG_PAD_ZERO, PWG_PAD_REFLECT, PWG_PAD_REPLICATE = 0, 1, 2
+ABI_VERSION = 1
+
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of ``pwg_conv1d_desc`` (include/pwg_kernels.h)."""
+
+    _fields_ = [
+        ("batch", ctypes.c_int32),
+        ("c_in", ctypes.c_int32),
+        ("c_out", ctypes.c_int32),
+        ("t_in", ctypes.c_int32),
+        ("t_out", ctypes.c_int32),
+        ("width", ctypes.c_int32),
+        ("kernel", ctypes.c_int32),
+        ("stride", ctypes.c_int32),
+        ("dilation", ctypes.c_int32),
+        ("pad_left", ctypes.c_int32),
+        ("groups", ctypes.c_int32),
+        ("transposed", ctypes.c_int32),
+        ("pad_mode", ctypes.c_int32),
+        ("pre_act", ctypes.c_int32),
+        ("pre_slope", ctypes.c_float),
+        ("post_act", ctypes.c_int32),
+        ("post_slope", ctypes.c_float),
+        ("out_mul", ctypes.c_float),
+        ("out_div", ctypes.c_float),
+    ]
+
+
+_lib = None
+_vp = ctypes.c_void_p
+_i32 = ctypes.c_int32
+
+# name -> (restype, argtypes); every symbol include/pwg_kernels.h declares
+SIGNATURES = {
+    "pwg_last_error": (ctypes.c_char_p, []),
+    "pwg_abi_version": (ctypes.c_int, []),
+    "pwg_target_arch": (ctypes.c_int, []),
+    "pwg_conv1d_packed_weight_floats": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
+    "pwg_conv1d_pack_weight": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
+    "pwg_conv1d_forward": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pwg_weight_norm_scale": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
+    "pwg_scale_rows": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
+}
+
+
+def lib():
+    """Load (once) and return the kernel library; raise loudly if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -m parallelwavegan_amd.csrc.build` "
+                "(hipcc --offload-arch=gfx950). This package has no fallback compute path."
+            )
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if l.pwg_abi_version() != ABI_VERSION:
+            raise RuntimeError(
+                f"libpwgkernels.so ABI {l.pwg_abi_version()} != expected {ABI_VERSION}; rebuild it"
+            )
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().pwg_last_error().decode(errors="replace")
+        raise RuntimeError(f"pwg kernel call failed ({what}, status {rc}): {msg}")

@@ -1,0 +1,513 @@
+// conv1d.hip -- fp32 implicit-GEMM 1-D convolution family on gfx950 MFMA.
+//
+// One kernel template covers Conv1d (dilated/strided/grouped), ConvTranspose1d
+// (polyphase: every output phase is a stride-1 conv with K/s taps; the phases
+// are extra GEMM rows) and the (k,1) Conv2d of the period discriminator
+// (rows of `width` samples are the time axis, the flat view is contiguous).
+//
+// GEMM view per (batch item, group):   D[m][n] = sum_{tap,ci} A[m][tap,ci] * B[tap,ci][n]
+//   m = phase*Cout_g + co   (rows,   weights,   A operand)
+//   n = output column       (cols,   time axis, B operand)
+// The contraction runs on v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD,
+// the fp32 matrix peak of 157 TFLOP/s); k-order = (ci-chunk, tap, ci), so the
+// result equals an fmaf chain in that order (cdna_hip_programming.md s3).
+//
+// Data movement per workgroup (BM rows x BN columns, 4 waves):
+//   x : (CK channels) x (BN*stride + halo) samples are read ONCE from HBM per
+//       ci-chunk, coalesced along time, pre-activation (LeakyReLU) and padding
+//       (zero/reflect/replicate) applied on the way into LDS, so each tap is a
+//       shifted LDS read and not a re-read of HBM.
+//   w : packed image [group][tap][ci][Mpad] (m fastest) -> LDS with 16-B loads;
+//       lanes 0-31 read 32 consecutive rows m, lanes 32-63 the next ci:
+//       conflict-free ds_read_b32 for both operands.
+//   y : MFMA D layout has col = lane&31, i.e. 32 consecutive time samples per
+//       half-wave -> coalesced 128-B stores; bias/residual/scale/tanh fused.
+#include "common.h"
+
+namespace pwg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+  const float* x;
+  const float* wp;
+  const float* bias;
+  const float* add1;
+  const float* add2;
+  float* y;
+  int cin_g;      // input channels per group
+  int cin_pad;    // packed-weight ci extent (multiple of 16)
+  int cout_g;     // real output channels per group
+  int m_g;        // GEMM rows per group = phases * cout_g
+  int m_pad;      // packed-weight m extent (multiple of 32)
+  int t_in;       // input rows
+  int t_out;      // output rows (real)
+  int width;      // samples per row (1 for Conv1d)
+  int k;          // taps of the (phase) convolution
+  int stride;     // input rows advanced per output column-row
+  int dil;
+  int pad;        // left padding in rows
+  int n_cols;     // GEMM columns per batch item = q_rows * width
+  int out_stride; // output row u = q*out_stride + phase - out_off
+  int out_off;
+  int x_cstride;  // t_in * width
+  int y_cstride;  // t_out * width
+  long x_bstride;
+  long y_bstride;
+  int xs_stride;  // LDS row stride of the x tile (floats)
+  int pad_mode, pre_act, post_act;
+  float pre_slope, post_slope, out_mul, out_div;
+};
+
+template <int WM, int WN, int WAVES_M, int WAVES_N, int CK>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv1d_mfma_kernel(ConvArgs a) {
+  constexpr int BM = 32 * WM * WAVES_M;
+  constexpr int BN = 32 * WN * WAVES_N;
+  constexpr int NWAVES = WAVES_M * WAVES_N;
+  constexpr int NT = 64 * NWAVES;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int XS = a.xs_stride;
+  float* xs = smem;            // [CK][XS]
+  float* ws = smem + CK * XS;  // [k][CK][BM]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave / WAVES_N;
+  const int wave_n = wave % WAVES_N;
+  const int l31 = lane & 31;
+  const int lhi = lane >> 5;
+
+  const int n0 = blockIdx.x * BN;
+  const int mtiles = (a.m_g + BM - 1) / BM;
+  const int g = blockIdx.y / mtiles;
+  const int m0 = (blockIdx.y % mtiles) * BM;
+  const int b = blockIdx.z;
+
+  const int W = a.width;
+  // rows of the input covered by this column tile
+  const int h0 = n0 / W;
+  int n_last = n0 + BN - 1;
+  if (n_last > a.n_cols - 1) n_last = a.n_cols - 1;
+  const int h1 = n_last / W;
+  const int f0 = (h0 * a.stride - a.pad) * W;                                   // first flat input index
+  const int L = ((h1 - h0) * a.stride + (a.k - 1) * a.dil + 1) * W;             // staged samples per channel
+  const int tap_step = a.dil * W;
+  const int in_len = a.t_in * W;
+
+  // per-lane LDS column offsets of this wave's WN column sub-tiles
+  int coff[WN];
+#pragma unroll
+  for (int ni = 0; ni < WN; ++ni) {
+    int n = n0 + (wave_n * WN + ni) * 32 + l31;
+    if (n > a.n_cols - 1) n = a.n_cols - 1;
+    const int h = n / W;
+    coff[ni] = (h - h0) * a.stride * W + (n - h * W);
+  }
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const float* xb = a.x + (long)b * a.x_bstride + (long)g * a.cin_g * a.x_cstride;
+  const float* wg = a.wp + (long)g * a.k * a.cin_pad * a.m_pad;
+
+  for (int ci0 = 0; ci0 < a.cin_g; ci0 += CK) {
+    // ---- stage x chunk: CK channels x L samples (activation + padding fused)
+    for (int r = wave; r < CK; r += NWAVES) {
+      const int ci = ci0 + r;
+      const float* xrow = xb + (long)ci * a.x_cstride;
+      float* dst = xs + r * XS;
+      const bool ch_ok = ci < a.cin_g;
+      for (int i = lane; i < L; i += 64) {
+        int f = f0 + i;
+        float v = 0.f;
+        if (ch_ok) {
+          bool ok = (f >= 0) && (f < in_len);
+          if (!ok && a.pad_mode != PWG_PAD_ZERO) {
+            if (a.pad_mode == PWG_PAD_REFLECT) {
+              f = f < 0 ? -f : 2 * (in_len - 1) - f;
+            } else {
+              f = f < 0 ? 0 : in_len - 1;
+            }
+            ok = (f >= 0) && (f < in_len);
+          }
+          if (ok) {
+            v = xrow[f];
+            if (a.pre_act == PWG_ACT_LEAKY_RELU)
+              v = v > 0.f ? v : v * a.pre_slope;
+            else if (a.pre_act == PWG_ACT_RELU)
+              v = v > 0.f ? v : 0.f;
+          }
+        }
+        dst[i] = v;
+      }
+    }
+    // ---- stage w chunk: k x CK x BM floats, 16-B loads
+    {
+      constexpr int BM4 = BM / 4;
+      const int total4 = a.k * CK * BM4;
+      for (int idx = tid; idx < total4; idx += NT) {
+        const int j4 = idx % BM4;
+        const int rr = idx / BM4;  // tap*CK + r
+        const int r = rr % CK;
+        const int tap = rr / CK;
+        const int m = m0 + j4 * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < a.m_pad)
+          v = *reinterpret_cast<const float4*>(wg + ((long)tap * a.cin_pad + ci0 + r) * a.m_pad + m);
+        *reinterpret_cast<float4*>(ws + rr * BM + j4 * 4) = v;
+      }
+    }
+    __syncthreads();
+
+    // ---- contraction over (tap, ci in chunk)
+    for (int tap = 0; tap < a.k; ++tap) {
+      const float* wt = ws + tap * CK * BM + wave_m * (WM * 32) + l31;
+      const float* xt = xs + tap * tap_step;
+#pragma unroll
+      for (int kk = 0; kk < CK / 2; ++kk) {
+        const int kr = 2 * kk + lhi;
+        float av[WM], bv[WN];
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi) av[mi] = wt[kr * BM + mi * 32];
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) bv[ni] = xt[kr * XS + coff[ni]];
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < WN; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const long ybase = (long)b * a.y_bstride;
+#pragma unroll
+  for (int ni = 0; ni < WN; ++ni) {
+    const int n = n0 + (wave_n * WN + ni) * 32 + l31;
+    if (n >= a.n_cols) continue;
+    const int q = n / W;
+    const int wcol = n - q * W;
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wave_m * WM + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (m >= a.m_g) continue;
+        const int phase = m / a.cout_g;
+        const int co = m - phase * a.cout_g;
+        const int u = q * a.out_stride + phase - a.out_off;
+        if (u < 0 || u >= a.t_out) continue;
+        const int cglob = g * a.cout_g + co;
+        const long o = ybase + (long)cglob * a.y_cstride + (long)u * W + wcol;
+        float v = acc[mi][ni][r];
+        if (a.bias) v += a.bias[cglob];
+        if (a.add1) v += a.add1[o];
+        if (a.add2) v += a.add2[o];
+        if (a.out_mul != 1.0f) v *= a.out_mul;
+        if (a.out_div != 1.0f) v = v / a.out_div;
+        v = apply_act(v, a.post_act, a.post_slope);
+        a.y[o] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// weight packing:  torch layout -> [group][tap][ci (pad 16)][m (pad 32)]
+// ---------------------------------------------------------------------------
+struct PackArgs {
+  const float* w;
+  const float* scale;
+  float* wp;
+  int groups, k_phase, cin_g, cin_pad, cout_g, m_g, m_pad;
+  int kernel, stride, transposed;
+};
+
+__global__ void pack_weight_kernel(PackArgs a) {
+  const long total = (long)a.groups * a.k_phase * a.cin_pad * a.m_pad;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int m = i % a.m_pad;
+    long r = i / a.m_pad;
+    const int ci = r % a.cin_pad;
+    r /= a.cin_pad;
+    const int tap = r % a.k_phase;
+    const int g = r / a.k_phase;
+    float v = 0.f;
+    if (m < a.m_g && ci < a.cin_g) {
+      if (!a.transposed) {
+        // w: (c_out, cin_g, kernel); dim0 = global out channel
+        const int co = g * a.cout_g + m;
+        v = a.w[((long)co * a.cin_g + ci) * a.kernel + tap];
+        if (a.scale) v *= a.scale[co];
+      } else {
+        // w: (c_in, cout_g, kernel); phase conv tap' reads x[q + tap' - (J-1)]
+        // and multiplies the original tap k = phase + (J-1-tap')*stride
+        const int phase = m / a.cout_g;
+        const int co = m - phase * a.cout_g;
+        const int kk = phase + (a.k_phase - 1 - tap) * a.stride;
+        if (kk < a.kernel) {
+          const int cig = g * a.cin_g + ci;
+          v = a.w[((long)cig * a.cout_g + co) * a.kernel + kk];
+          if (a.scale) v *= a.scale[cig];
+        }
+      }
+    }
+    a.wp[i] = v;
+  }
+}
+
+// one block per dim-0 slice: scale = g / ||v||
+__global__ void weight_norm_scale_kernel(const float* v, const float* g, float* scale, int inner) {
+  __shared__ float red[4];
+  const int row = blockIdx.x;
+  const float* p = v + (long)row * inner;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < inner; i += blockDim.x) {
+    const float t = p[i];
+    s += t * t;
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+    scale[row] = g[row] / sqrtf(t);
+  }
+}
+
+__global__ void scale_rows_kernel(const float* v, const float* scale, float* w, long total, int inner) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x)
+    w[i] = v[i] * scale[i / inner];
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+struct Geometry {
+  int cin_g, cin_pad, cout_g, phases, k_phase, m_g, m_pad;
+  int stride, dil, pad, n_cols, out_stride, out_off;
+};
+
+static int make_geometry(const pwg_conv1d_desc* d, Geometry* g) {
+  PWG_REQUIRE(d != nullptr, PWG_ERR_NULL, "conv1d: NULL descriptor");
+  PWG_REQUIRE(d->batch > 0 && d->c_in > 0 && d->c_out > 0 && d->t_in > 0 && d->t_out > 0,
+              PWG_ERR_BAD_SHAPE, "conv1d: non-positive size (B=%d Cin=%d Cout=%d Tin=%d Tout=%d)",
+              d->batch, d->c_in, d->c_out, d->t_in, d->t_out);
+  PWG_REQUIRE(d->kernel > 0 && d->stride > 0 && d->dilation > 0 && d->groups > 0 && d->width > 0,
+              PWG_ERR_BAD_SHAPE, "conv1d: kernel/stride/dilation/groups/width must be positive");
+  PWG_REQUIRE(d->c_in % d->groups == 0 && d->c_out % d->groups == 0, PWG_ERR_BAD_SHAPE,
+              "conv1d: channels (%d,%d) not divisible by groups %d", d->c_in, d->c_out, d->groups);
+  PWG_REQUIRE(d->pad_left >= 0, PWG_ERR_BAD_SHAPE, "conv1d: negative padding");
+  g->cin_g = d->c_in / d->groups;
+  g->cout_g = d->c_out / d->groups;
+  g->cin_pad = round_up(g->cin_g, 16);
+  if (!d->transposed) {
+    const int need = (d->t_out - 1) * d->stride + (d->kernel - 1) * d->dilation + 1;
+    PWG_REQUIRE((d->t_out - 1) * d->stride - d->pad_left < d->t_in, PWG_ERR_BAD_SHAPE,
+                "conv1d: t_out=%d starts past the end of t_in=%d", d->t_out, d->t_in);
+    if (d->pad_mode == PWG_PAD_REFLECT) {
+      const int right = need - d->pad_left - d->t_in;
+      PWG_REQUIRE(d->width == 1 && d->pad_left < d->t_in && right < d->t_in, PWG_ERR_BAD_SHAPE,
+                  "conv1d: reflect padding (%d,%d) must be smaller than t_in=%d and width==1",
+                  d->pad_left, right, d->t_in);
+    }
+    if (d->pad_mode == PWG_PAD_REPLICATE)
+      PWG_REQUIRE(d->width == 1, PWG_ERR_BAD_SHAPE, "conv1d: replicate padding needs width==1");
+    g->phases = 1;
+    g->k_phase = d->kernel;
+    g->stride = d->stride;
+    g->dil = d->dilation;
+    g->pad = d->pad_left;
+    g->n_cols = d->t_out * d->width;
+    g->out_stride = 1;
+    g->out_off = 0;
+  } else {
+    PWG_REQUIRE(d->width == 1 && d->dilation == 1 && d->pad_mode == PWG_PAD_ZERO, PWG_ERR_UNSUPPORTED,
+                "conv_transpose1d: width/dilation must be 1 and padding zero");
+    const int full = (d->t_in - 1) * d->stride - 2 * d->pad_left + d->kernel;
+    PWG_REQUIRE(d->t_out >= full && d->t_out < full + d->stride, PWG_ERR_BAD_SHAPE,
+                "conv_transpose1d: t_out=%d not in [%d,%d)", d->t_out, full, full + d->stride);
+    g->phases = d->stride;
+    g->k_phase = ceil_div(d->kernel, d->stride);
+    g->stride = 1;
+    g->dil = 1;
+    g->pad = g->k_phase - 1;
+    g->n_cols = d->t_in + g->k_phase - 1;
+    g->out_stride = d->stride;
+    g->out_off = d->pad_left;
+  }
+  g->m_g = g->phases * g->cout_g;
+  g->m_pad = round_up(g->m_g, 32);
+  return PWG_OK;
+}
+
+template <int WM, int WN, int WAVES_M, int WAVES_N, int CK>
+static int launch_conv(const ConvArgs& a0, const Geometry& g, int batch, int groups, hipStream_t stream) {
+  constexpr int BM = 32 * WM * WAVES_M;
+  constexpr int BN = 32 * WN * WAVES_N;
+  ConvArgs a = a0;
+  const int W = a.width;
+  const int rows = (W == 1) ? BN : ((BN - 1) / W + 2);
+  int xs_len = ((rows - 1) * g.stride + (g.k_phase - 1) * g.dil + 1) * W;
+  // odd multiple of 32-bank row + keep 16-B alignment of the weight tile that follows
+  a.xs_stride = round_up(xs_len, 4);
+  const size_t lds = ((size_t)CK * a.xs_stride + (size_t)g.k_phase * CK * BM) * sizeof(float);
+  PWG_REQUIRE(lds <= 160 * 1024, PWG_ERR_UNSUPPORTED,
+              "conv1d: tile needs %zu B of LDS (k=%d stride=%d dil=%d)", lds, g.k_phase, g.stride, g.dil);
+  auto kern = conv1d_mfma_kernel<WM, WN, WAVES_M, WAVES_N, CK>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    PWG_REQUIRE(e == hipSuccess, PWG_ERR_LAUNCH, "conv1d: cannot raise LDS limit to %zu: %s", lds,
+                hipGetErrorString(e));
+  }
+  dim3 grid(ceil_div(g.n_cols, BN), ceil_div(g.m_g, BM) * groups, batch);
+  dim3 block(64 * WAVES_M * WAVES_N);
+  hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
+  PWG_CHECK_LAUNCH("conv1d_forward");
+  return PWG_OK;
+}
+
+}  // namespace pwg
+
+using namespace pwg;
+
+extern "C" size_t pwg_conv1d_packed_weight_floats(const pwg_conv1d_desc* d) {
+  Geometry g;
+  if (make_geometry(d, &g) != PWG_OK) return 0;
+  return (size_t)d->groups * g.k_phase * g.cin_pad * g.m_pad;
+}
+
+extern "C" int pwg_conv1d_pack_weight(const pwg_conv1d_desc* d, const float* w, const float* scale,
+                                      float* w_packed, void* stream) {
+  Geometry g;
+  int rc = make_geometry(d, &g);
+  if (rc != PWG_OK) return rc;
+  PWG_REQUIRE(w && w_packed, PWG_ERR_NULL, "pack_weight: NULL pointer");
+  PackArgs a;
+  a.w = w;
+  a.scale = scale;
+  a.wp = w_packed;
+  a.groups = d->groups;
+  a.k_phase = g.k_phase;
+  a.cin_g = g.cin_g;
+  a.cin_pad = g.cin_pad;
+  a.cout_g = g.cout_g;
+  a.m_g = g.m_g;
+  a.m_pad = g.m_pad;
+  a.kernel = d->kernel;
+  a.stride = d->stride;
+  a.transposed = d->transposed;
+  const long total = (long)a.groups * a.k_phase * a.cin_pad * a.m_pad;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  PWG_CHECK_LAUNCH("pack_weight");
+  return PWG_OK;
+}
+
+extern "C" int pwg_conv1d_forward(const pwg_conv1d_desc* d, const float* x, const float* w_packed,
+                                  const float* bias, const float* add1, const float* add2, float* y,
+                                  void* stream_) {
+  Geometry g;
+  int rc = make_geometry(d, &g);
+  if (rc != PWG_OK) return rc;
+  PWG_REQUIRE(x && w_packed && y, PWG_ERR_NULL, "conv1d_forward: NULL pointer");
+  hipStream_t stream = (hipStream_t)stream_;
+  ConvArgs a;
+  a.x = x;
+  a.wp = w_packed;
+  a.bias = bias;
+  a.add1 = add1;
+  a.add2 = add2;
+  a.y = y;
+  a.cin_g = g.cin_g;
+  a.cin_pad = g.cin_pad;
+  a.cout_g = g.cout_g;
+  a.m_g = g.m_g;
+  a.m_pad = g.m_pad;
+  a.t_in = d->t_in;
+  a.t_out = d->t_out;
+  a.width = d->width;
+  a.k = g.k_phase;
+  a.stride = g.stride;
+  a.dil = g.dil;
+  a.pad = g.pad;
+  a.n_cols = g.n_cols;
+  a.out_stride = g.out_stride;
+  a.out_off = g.out_off;
+  a.x_cstride = d->t_in * d->width;
+  a.y_cstride = d->t_out * d->width;
+  a.x_bstride = (long)d->c_in * a.x_cstride;
+  a.y_bstride = (long)d->c_out * a.y_cstride;
+  a.xs_stride = 0;
+  a.pad_mode = d->pad_mode;
+  a.pre_act = d->pre_act;
+  a.post_act = d->post_act;
+  a.pre_slope = d->pre_slope;
+  a.post_slope = d->post_slope;
+  a.out_mul = d->out_mul;
+  a.out_div = d->out_div;
+  PWG_REQUIRE(d->pre_act == PWG_ACT_NONE || d->pre_act == PWG_ACT_LEAKY_RELU || d->pre_act == PWG_ACT_RELU,
+              PWG_ERR_UNSUPPORTED, "conv1d: pre_act %d unsupported", d->pre_act);
+
+  // tile selection: rows first (BM = 128 / 64 / 32), then enough column tiles to
+  // cover 256 CUs, then the ci-chunk that keeps the LDS image <= ~56 KB
+  const int m = g.m_g;
+  const long lds_w_per_ck128 = (long)g.k_phase * 128 * 4;  // bytes per ci of a BM=128 tile
+  if (m > 64) {
+    const long blocks128 = (long)ceil_div(g.n_cols, 128) * ceil_div(m, 128) * d->groups * d->batch;
+    if (blocks128 >= 256 || g.n_cols > 64) {
+      if (lds_w_per_ck128 * 16 <= 40 * 1024 && g.cin_g >= 16)
+        return launch_conv<2, 2, 2, 2, 16>(a, g, d->batch, d->groups, stream);
+      if (lds_w_per_ck128 * 8 <= 56 * 1024)
+        return launch_conv<2, 2, 2, 2, 8>(a, g, d->batch, d->groups, stream);
+      return launch_conv<2, 2, 2, 2, 4>(a, g, d->batch, d->groups, stream);
+    }
+    if (lds_w_per_ck128 * 8 <= 56 * 1024) return launch_conv<2, 1, 2, 2, 8>(a, g, d->batch, d->groups, stream);
+    return launch_conv<2, 1, 2, 2, 4>(a, g, d->batch, d->groups, stream);
+  } else if (m > 32) {
+    if (lds_w_per_ck128 * 8 <= 56 * 1024 && g.cin_g >= 16)
+      return launch_conv<2, 2, 1, 4, 16>(a, g, d->batch, d->groups, stream);
+    if (lds_w_per_ck128 * 4 <= 56 * 1024) return launch_conv<2, 2, 1, 4, 8>(a, g, d->batch, d->groups, stream);
+    return launch_conv<2, 2, 1, 4, 4>(a, g, d->batch, d->groups, stream);
+  } else {
+    if (lds_w_per_ck128 * 4 <= 56 * 1024 && g.cin_g >= 16)
+      return launch_conv<1, 2, 1, 4, 16>(a, g, d->batch, d->groups, stream);
+    if (lds_w_per_ck128 * 2 <= 56 * 1024 && g.cin_g >= 8)
+      return launch_conv<1, 2, 1, 4, 8>(a, g, d->batch, d->groups, stream);
+    return launch_conv<1, 2, 1, 4, 4>(a, g, d->batch, d->groups, stream);
+  }
+}
+
+extern "C" int pwg_weight_norm_scale(const float* v, const float* g, float* scale, int32_t n0,
+                                     int32_t inner, void* stream) {
+  PWG_REQUIRE(v && g && scale, PWG_ERR_NULL, "weight_norm_scale: NULL pointer");
+  PWG_REQUIRE(n0 > 0 && inner > 0, PWG_ERR_BAD_SHAPE, "weight_norm_scale: bad shape (%d,%d)", n0, inner);
+  hipLaunchKernelGGL(weight_norm_scale_kernel, dim3(n0), dim3(256), 0, (hipStream_t)stream, v, g, scale, inner);
+  PWG_CHECK_LAUNCH("weight_norm_scale");
+  return PWG_OK;
+}
+
+extern "C" int pwg_scale_rows(const float* v, const float* scale, float* w, int32_t n0, int32_t inner,
+                              void* stream) {
+  PWG_REQUIRE(v && scale && w, PWG_ERR_NULL, "scale_rows: NULL pointer");
+  PWG_REQUIRE(n0 > 0 && inner > 0, PWG_ERR_BAD_SHAPE, "scale_rows: bad shape (%d,%d)", n0, inner);
+  const long total = (long)n0 * inner;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, v, scale, w, total, inner);
+  PWG_CHECK_LAUNCH("scale_rows");
+  return PWG_OK;
+}

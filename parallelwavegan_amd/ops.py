@@ -1,0 +1,99 @@
+"""Tensor-level wrappers over the C ABI (device pointers in, device pointers out).
+
+PyTorch is used here only as the owner of device memory and streams.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc
+
+ACT = {None: _lib.PWG_ACT_NONE, "none": _lib.PWG_ACT_NONE, "leaky_relu": _lib.PWG_ACT_LEAKY_RELU,
+       "tanh": _lib.PWG_ACT_TANH, "relu": _lib.PWG_ACT_RELU}
+PAD = {"zero": _lib.PWG_PAD_ZERO, "reflect": _lib.PWG_PAD_REFLECT, "replicate": _lib.PWG_PAD_REPLICATE}
+
+
+def _require_device(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "parallelwavegan_amd ops run only on an MI355X device tensor (got a CPU tensor); "
+                "there is no CPU fallback path"
+            )
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"expected float32 tensor, got {t.dtype}")
+        if not t.is_contiguous():
+            raise RuntimeError("expected contiguous tensor")
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def make_conv_desc(batch, c_in, c_out, t_in, t_out, kernel, stride=1, dilation=1, pad_left=0, groups=1,
+                   transposed=False, width=1, pad_mode="zero", pre_act=None, pre_slope=0.0, post_act=None,
+                   post_slope=0.0, out_mul=1.0, out_div=1.0):
+    return ConvDesc(batch, c_in, c_out, t_in, t_out, width, kernel, stride, dilation, pad_left, groups,
+                    int(bool(transposed)), PAD[pad_mode], ACT[pre_act], float(pre_slope), ACT[post_act],
+                    float(post_slope), float(out_mul), float(out_div))
+
+
+def conv_out_length(t_in, kernel, stride=1, dilation=1, pad_left=0, pad_right=0):
+    return (t_in + pad_left + pad_right - dilation * (kernel - 1) - 1) // stride + 1
+
+
+def conv_transpose_out_length(t_in, kernel, stride, padding, output_padding):
+    return (t_in - 1) * stride - 2 * padding + kernel + output_padding
+
+
+def packed_weight_floats(desc):
+    n = _lib.lib().pwg_conv1d_packed_weight_floats(ctypes.byref(desc))
+    if n == 0:
+        _lib.check(-1, "packed_weight_floats")
+    return n
+
+
+def pack_weight(desc, w, scale=None):
+    """torch-layout weight (+ optional weight_norm row scale) -> packed image."""
+    _require_device(w, scale)
+    out = torch.empty(packed_weight_floats(desc), device=w.device, dtype=torch.float32)
+    _lib.check(_lib.lib().pwg_conv1d_pack_weight(ctypes.byref(desc), _ptr(w), _ptr(scale), _ptr(out), _stream()),
+               "conv1d_pack_weight")
+    return out
+
+
+def conv1d_forward(desc, x, w_packed, bias=None, add1=None, add2=None, out=None):
+    _require_device(x, w_packed, bias, add1, add2, out)
+    if out is None:
+        out = torch.empty((desc.batch, desc.c_out, desc.t_out * desc.width), device=x.device, dtype=torch.float32)
+    assert x.numel() == desc.batch * desc.c_in * desc.t_in * desc.width, (tuple(x.shape), desc.batch, desc.c_in, desc.t_in)
+    assert out.numel() == desc.batch * desc.c_out * desc.t_out * desc.width
+    _lib.check(_lib.lib().pwg_conv1d_forward(ctypes.byref(desc), _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(add1),
+                                             _ptr(add2), _ptr(out), _stream()), "conv1d_forward")
+    return out
+
+
+def weight_norm_scale(v, g):
+    """scale[i] = g[i] / ||v[i]||  (old-style weight_norm, dim=0)."""
+    _require_device(v, g)
+    n0 = v.shape[0]
+    inner = v.numel() // n0
+    scale = torch.empty(n0, device=v.device, dtype=torch.float32)
+    _lib.check(_lib.lib().pwg_weight_norm_scale(_ptr(v), _ptr(g), _ptr(scale), n0, inner, _stream()), "weight_norm_scale")
+    return scale
+
+
+def scale_rows(v, scale):
+    _require_device(v, scale)
+    n0 = v.shape[0]
+    inner = v.numel() // n0
+    w = torch.empty_like(v)
+    _lib.check(_lib.lib().pwg_scale_rows(_ptr(v), _ptr(scale), _ptr(w), n0, inner, _stream()), "scale_rows")
+    return w

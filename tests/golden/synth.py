@@ -1,0 +1,90 @@
+"""Deterministic synthetic state_dicts and inputs shared by the golden-vector
+generator (run in the build container against the reference) and the parity
+tests (run anywhere, including the GPU box where /root/reference is absent).
+
+numpy's PCG64 streams are stable across platforms, so regenerating from
+(name, shape, seed) gives bit-identical float32 tensors on both sides; only the
+reference's OUTPUTS need to be committed as fixtures.
+"""
+import zlib
+
+import numpy as np
+import torch
+
+
+def _rng(seed, name):
+    return np.random.default_rng([int(seed), zlib.crc32(name.encode())])
+
+
+def synth_tensor(name, shape, seed=0, g_scale=1.0):
+    """Value for one reference state_dict entry, chosen by its key suffix."""
+    r = _rng(seed, name)
+    shape = tuple(shape)
+    leaf = name.rsplit(".", 1)[-1]
+    if leaf == "weight_g":
+        a = g_scale * (1.0 + 0.1 * r.standard_normal(shape))
+    elif leaf in ("weight_v", "weight_orig"):
+        a = r.standard_normal(shape)
+    elif leaf == "weight":
+        fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else 1
+        a = g_scale * r.standard_normal(shape) / np.sqrt(max(fan_in, 1))
+    elif leaf == "bias":
+        a = 0.05 * r.standard_normal(shape)
+    elif leaf == "weight_u":
+        a = r.standard_normal(shape)
+        a = a / np.linalg.norm(a)
+    elif leaf == "mean":
+        a = 0.1 * r.standard_normal(shape)
+    elif leaf == "scale":
+        a = 1.0 + 0.1 * r.random(shape)
+    else:
+        raise KeyError(f"no synthetic rule for state_dict key {name!r}")
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+
+
+def synth_state_dict(shapes, seed=0, g_scale=1.0, skip=()):
+    """shapes: mapping name -> shape (e.g. from ``module.state_dict()``)."""
+    out = {}
+    for name, shp in shapes.items():
+        if any(name.endswith(s) for s in skip):
+            continue
+        shp = tuple(shp.shape) if hasattr(shp, "shape") else tuple(shp)
+        out[name] = synth_tensor(name, shp, seed, g_scale)
+    return out
+
+
+def synth_input(name, shape, seed=0):
+    r = _rng(seed, "input:" + name)
+    return torch.from_numpy(r.standard_normal(tuple(shape)).astype(np.float32))
+
+
+# ---------------------------------------------------------------------------
+# Configurations exercised by the golden fixtures (subset of the reference's
+# YAML generator_params; full-size ones equal egs/ljspeech/voc1/conf/*.yaml).
+# ---------------------------------------------------------------------------
+HIFIGAN_V1 = dict(
+    in_channels=80,
+    out_channels=1,
+    channels=512,
+    kernel_size=7,
+    upsample_scales=[8, 8, 2, 2],
+    upsample_kernel_sizes=[16, 16, 4, 4],
+    resblock_kernel_sizes=[3, 7, 11],
+    resblock_dilations=[[1, 3, 5], [1, 3, 5], [1, 3, 5]],
+    use_additional_convs=True,
+    bias=True,
+    nonlinear_activation="LeakyReLU",
+    nonlinear_activation_params={"negative_slope": 0.1},
+    use_weight_norm=True,
+)
+# LibriTTS 24 kHz variant (egs/libritts/voc1/conf/hifigan.v1.yaml): odd scales
+HIFIGAN_V1_LIBRITTS = dict(HIFIGAN_V1, upsample_scales=[5, 5, 4, 3], upsample_kernel_sizes=[10, 10, 8, 6])
+# small config in the spirit of the reference's own unit tests (test/test_hifigan.py)
+HIFIGAN_TINY = dict(
+    HIFIGAN_V1,
+    channels=64,
+    upsample_scales=[4, 3, 2],
+    upsample_kernel_sizes=[8, 6, 4],
+    resblock_kernel_sizes=[3, 5],
+    resblock_dilations=[[1, 3], [1, 2]],
+)
