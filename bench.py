@@ -58,26 +58,39 @@ def cpu_baseline(budget_s=12.0):
     from parallelwavegan_amd.models import HiFiGANGenerator
 
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     g = HiFiGANGenerator(**HIFIGAN_V1)
     g.remove_weight_norm()
     sd = {k: v.detach() for k, v in g.state_dict().items()}
     frames = 100
     c = torch.randn(1, 80, frames)
+
+    def once():
+        t0 = time.time()
+        y = torch_cpu.hifigan_generator(sd, c, **HIFIGAN_V1)
+        return time.time() - t0, y
+
     with torch.no_grad():
-        torch_cpu.hifigan_generator(sd, c, **HIFIGAN_V1)  # warm-up
+        # torch's default (= all cores) oversubscribes these small convs on a many-core host, so
+        # probe a few intra-op thread counts briefly and keep the fastest for the timed sample
+        probe = {}
+        for nt in sorted({min(cores, n) for n in (8, 16, 32, 64)}):
+            torch.set_num_threads(nt)
+            once()
+            probe[nt] = min(once()[0], once()[0])
+        nthreads = min(probe, key=probe.get)
+        torch.set_num_threads(nthreads)
         best, n, t_start = float("inf"), 0, time.time()
         while n < 3 or (time.time() - t_start < budget_s and n < 200):
-            t0 = time.time()
-            y = torch_cpu.hifigan_generator(sd, c, **HIFIGAN_V1)
-            best = min(best, time.time() - t0)
+            dt, y = once()
+            best = min(best, dt)
             n += 1
     return {
         "value": y.numel() / best,
         "unit": "samples/s",
         "cores": torch.get_num_threads(),
         "kind": "port",
-        "sample": f"oracle.torch_cpu.hifigan_generator, B=1 x {frames} frames, best of {n} calls",
+        "sample": f"oracle.torch_cpu.hifigan_generator, B=1 x {frames} frames, best of {n} calls, "
+                  f"{nthreads} of {cores} host threads (fastest of {sorted(probe)})",
     }
 
 

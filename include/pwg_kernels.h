@@ -111,6 +111,16 @@ int pwg_conv1d_forward(const pwg_conv1d_desc* d, const float* x, const float* w_
                        const float* bias, const float* add1, const float* add2, float* y,
                        void* stream);
 
+/* Tuning / diagnostics: the same operation with an explicit tile configuration
+ * (0 <= tile_config < pwg_conv1d_num_tile_configs()) and staging path (use_dma:
+ * 1 = LDS-DMA double-buffered, 0 = register-staged).  tools/bench_conv.py sweeps
+ * these to derive the heuristic inside pwg_conv1d_forward; results are identical
+ * for every configuration up to fp32 summation order.                          */
+int pwg_conv1d_num_tile_configs(void);
+int pwg_conv1d_forward_cfg(const pwg_conv1d_desc* d, const float* x, const float* w_packed,
+                           const float* bias, const float* add1, const float* add2, float* y,
+                           int32_t tile_config, int32_t use_dma, void* stream);
+
 /* Old-style torch.nn.utils.weight_norm (dim=0) scale: scale[i] = g[i]/||v[i,...]||_2
  * replaces torch._weight_norm at every conv call site.
  * v: (n0, inner) flattened, g: (n0).                                          */

@@ -52,6 +52,8 @@ SIGNATURES = {
     "pwg_conv1d_packed_weight_floats": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
     "pwg_conv1d_pack_weight": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     "pwg_conv1d_forward": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pwg_conv1d_num_tile_configs": (ctypes.c_int, []),
+    "pwg_conv1d_forward_cfg": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "pwg_weight_norm_scale": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "pwg_scale_rows": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
 }
@@ -66,6 +68,11 @@ def lib():
                 f"{LIB_PATH} not found: build it with `python -m parallelwavegan_amd.csrc.build` "
                 "(hipcc --offload-arch=gfx950). This package has no fallback compute path."
             )
+        # torch bundles its own HIP runtime; it must be the one already loaded when our
+        # library's libamdhip64 dependency is resolved, or the process ends up with two
+        # runtimes and ours sees "no ROCm-capable device".
+        import torch  # noqa: F401
+
         l = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the symbol is missing

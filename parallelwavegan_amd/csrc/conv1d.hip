@@ -17,7 +17,7 @@
 //       ci-chunk, coalesced along time, pre-activation (LeakyReLU) and padding
 //       (zero/reflect/replicate) applied on the way into LDS, so each tap is a
 //       shifted LDS read and not a re-read of HBM.
-//   w : packed image [group][tap][ci][Mpad] (m fastest) -> LDS with 16-B loads;
+//   w : packed image [group][tap][ci][Mpad] (m fastest, Mpad % 128 == 0) -> LDS with 16-B loads;
 //       lanes 0-31 read 32 consecutive rows m, lanes 32-63 the next ci:
 //       conflict-free ds_read_b32 for both operands.
 //   y : MFMA D layout has col = lane&31, i.e. 32 consecutive time samples per
@@ -39,7 +39,7 @@ struct ConvArgs {
   int cin_pad;    // packed-weight ci extent (multiple of 16)
   int cout_g;     // real output channels per group
   int m_g;        // GEMM rows per group = phases * cout_g
-  int m_pad;      // packed-weight m extent (multiple of 32)
+  int m_pad;      // packed-weight m extent (multiple of 128)
   int t_in;       // input rows
   int t_out;      // output rows (real)
   int width;      // samples per row (1 for Conv1d)
@@ -221,6 +221,186 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv1d_mfma_kernel(Con
 }
 
 // ---------------------------------------------------------------------------
+// v2: LDS-DMA staged, double-buffered variant (zero padding only).
+//
+//   * w chunk: global_load_lds_dwordx4 (1 KiB per wave-instruction, lane-linear LDS image
+//     == the [tap][ci][BM] tile, no VGPR round trip)
+//   * x chunk: buffer_load_dword ... lds through a per-channel-row raw buffer descriptor
+//     whose num_records is the row length: samples left/right of the row (the implicit
+//     zero padding) and channels past c_in are out of range and land as 0.0 in LDS
+//     (probed on hardware: tools/probes/glds_oob.hip).  The pre-activation is applied
+//     when the B operand is read from LDS (2-3 VALU ops per 64-cycle MFMA).
+//   * chunk c+1 is in flight while chunk c is contracted: one vmcnt(0)+barrier per chunk.
+// ---------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int WM, int WN, int WAVES_M, int WAVES_N, int CK>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv1d_mfma_dma_kernel(ConvArgs a) {
+  constexpr int BM = 32 * WM * WAVES_M;
+  constexpr int BN = 32 * WN * WAVES_N;
+  constexpr int NWAVES = WAVES_M * WAVES_N;
+  constexpr int ROWS_PER_PIECE = 256 / BM;  // w rows per 1 KiB DMA piece
+  constexpr int L4 = BM / 4;                // lanes per w row
+  constexpr int KS = CK / 2;                // MFMA k-steps per tap
+  static_assert((CK % ROWS_PER_PIECE) == 0, "CK must cover whole DMA pieces");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int XS = a.xs_stride;
+  const int buf_floats = CK * XS + a.k * CK * BM;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave / WAVES_N;
+  const int wave_n = wave % WAVES_N;
+  const int l31 = lane & 31;
+  const int lhi = lane >> 5;
+
+  const int n0 = blockIdx.x * BN;
+  const int mtiles = (a.m_g + BM - 1) / BM;
+  const int g = blockIdx.y / mtiles;
+  const int m0 = (blockIdx.y % mtiles) * BM;
+  const int b = blockIdx.z;
+
+  const int W = a.width;
+  const int h0 = n0 / W;
+  int n_last = n0 + BN - 1;
+  if (n_last > a.n_cols - 1) n_last = a.n_cols - 1;
+  const int h1 = n_last / W;
+  const int f0 = (h0 * a.stride - a.pad) * W;
+  const int L = ((h1 - h0) * a.stride + (a.k - 1) * a.dil + 1) * W;
+  const int tap_step = a.dil * W;
+  const int in_bytes = a.t_in * W * 4;
+
+  int coff[WN];
+#pragma unroll
+  for (int ni = 0; ni < WN; ++ni) {
+    int n = n0 + (wave_n * WN + ni) * 32 + l31;
+    if (n > a.n_cols - 1) n = a.n_cols - 1;
+    const int h = n / W;
+    coff[ni] = (h - h0) * a.stride * W + (n - h * W);
+  }
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const float* xb = a.x + (long)b * a.x_bstride + (long)g * a.cin_g * a.x_cstride;
+  const float* wg = a.wp + (long)g * a.k * a.cin_pad * a.m_pad + m0;
+  const int npieces = a.k * CK / ROWS_PER_PIECE;
+  const int w_row_in_piece = lane / L4;
+  const int w_col = (lane % L4) * 4;
+
+  auto issue = [&](int ci0, float* buf) {
+    float* xs = buf;
+    float* ws = buf + CK * XS;
+    for (int r = wave; r < CK; r += NWAVES) {
+      const int ci = ci0 + r;
+      const float* xrow = xb + (long)ci * a.x_cstride;
+      const int nrec = ci < a.cin_g ? in_bytes : 0;
+      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xrow, 0, nrec, 0x00020000);
+      for (int i0 = 0; i0 < L; i0 += 64)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(xs + r * XS + i0), 4, (f0 + i0 + lane) * 4, 0, 0, 0);
+    }
+    for (int p = wave; p < npieces; p += NWAVES) {
+      const int rr = p * ROWS_PER_PIECE + w_row_in_piece;
+      const int tap = rr / CK;
+      const int r = rr - tap * CK;
+      const float* src = wg + ((long)tap * a.cin_pad + ci0 + r) * a.m_pad + w_col;
+      __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(ws + p * 256), 16, 0, 0);
+    }
+  };
+
+  const float slope_eff = a.pre_act == PWG_ACT_LEAKY_RELU ? a.pre_slope : (a.pre_act == PWG_ACT_RELU ? 0.f : 1.f);
+  const int nchunks = (a.cin_g + CK - 1) / CK;
+  issue(0, smem);
+  for (int c = 0; c < nchunks; ++c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float* buf = smem + (c & 1) * buf_floats;
+    if (c + 1 < nchunks) issue((c + 1) * CK, smem + ((c + 1) & 1) * buf_floats);
+    const float* xs = buf;
+    const float* wl = buf + CK * XS + wave_m * (WM * 32) + l31 + lhi * BM;  // + tap*CK*BM + 2*kk*BM + mi*32
+    const float* xl = xs + lhi * XS;                                          // + tap*tap_step + 2*kk*XS + coff
+    // operands of one tap live in registers; the next tap's LDS reads are issued before this
+    // tap's MFMAs so that LDS latency hides under the 64-cycle matrix instructions
+    auto load_ops = [&](int tap, float(&av)[KS][WM], float(&bv)[KS][WN]) {
+      const float* wt = wl + tap * (CK * BM);
+      const float* xt = xl + tap * tap_step;
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi) av[kk][mi] = wt[2 * kk * BM + mi * 32];
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) bv[kk][ni] = xt[2 * kk * XS + coff[ni]];
+      }
+    };
+    auto mma = [&](float(&av)[KS][WM], float(&bv)[KS][WN]) {
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+        float bact[WN];
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) {
+          // branch-free pre-activation: v>0 ? v : v*slope  ==  max(v,0) + slope*min(v,0)  (exact:
+          // one of the two terms is always 0); slope_eff = 1 (none) / slope (LeakyReLU) / 0 (ReLU)
+          const float v = bv[kk][ni];
+          bact[ni] = __builtin_fmaf(slope_eff, __builtin_fminf(v, 0.f), __builtin_fmaxf(v, 0.f));
+        }
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < WN; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk][mi], bact[ni], acc[mi][ni], 0, 0, 0);
+      }
+    };
+    float a0[KS][WM], b0[KS][WN], a1[KS][WM], b1[KS][WN];
+    load_ops(0, a0, b0);
+    int tap = 0;
+    for (; tap + 2 <= a.k; tap += 2) {
+      load_ops(tap + 1, a1, b1);
+      mma(a0, b0);
+      if (tap + 2 < a.k) load_ops(tap + 2, a0, b0);
+      mma(a1, b1);
+    }
+    if (tap < a.k) mma(a0, b0);
+  }
+
+  const long ybase = (long)b * a.y_bstride;
+#pragma unroll
+  for (int ni = 0; ni < WN; ++ni) {
+    const int n = n0 + (wave_n * WN + ni) * 32 + l31;
+    if (n >= a.n_cols) continue;
+    const int q = n / W;
+    const int wcol = n - q * W;
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wave_m * WM + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (m >= a.m_g) continue;
+        const int phase = m / a.cout_g;
+        const int co = m - phase * a.cout_g;
+        const int u = q * a.out_stride + phase - a.out_off;
+        if (u < 0 || u >= a.t_out) continue;
+        const int cglob = g * a.cout_g + co;
+        const long o = ybase + (long)cglob * a.y_cstride + (long)u * W + wcol;
+        float v = acc[mi][ni][r];
+        if (a.bias) v += a.bias[cglob];
+        if (a.add1) v += a.add1[o];
+        if (a.add2) v += a.add2[o];
+        if (a.out_mul != 1.0f) v *= a.out_mul;
+        if (a.out_div != 1.0f) v = v / a.out_div;
+        v = apply_act(v, a.post_act, a.post_slope);
+        a.y[o] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // weight packing:  torch layout -> [group][tap][ci (pad 16)][m (pad 32)]
 // ---------------------------------------------------------------------------
 struct PackArgs {
@@ -348,24 +528,29 @@ static int make_geometry(const pwg_conv1d_desc* d, Geometry* g) {
     g->out_off = d->pad_left;
   }
   g->m_g = g->phases * g->cout_g;
-  g->m_pad = round_up(g->m_g, 32);
+  g->m_pad = round_up(g->m_g, 128);
   return PWG_OK;
 }
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, int CK>
+template <int WM, int WN, int WAVES_M, int WAVES_N, int CK, bool DMA>
 static int launch_conv(const ConvArgs& a0, const Geometry& g, int batch, int groups, hipStream_t stream) {
   constexpr int BM = 32 * WM * WAVES_M;
   constexpr int BN = 32 * WN * WAVES_N;
   ConvArgs a = a0;
   const int W = a.width;
   const int rows = (W == 1) ? BN : ((BN - 1) / W + 2);
-  int xs_len = ((rows - 1) * g.stride + (g.k_phase - 1) * g.dil + 1) * W;
-  // odd multiple of 32-bank row + keep 16-B alignment of the weight tile that follows
-  a.xs_stride = round_up(xs_len, 4);
-  const size_t lds = ((size_t)CK * a.xs_stride + (size_t)g.k_phase * CK * BM) * sizeof(float);
+  const int xs_len = ((rows - 1) * g.stride + (g.k_phase - 1) * g.dil + 1) * W;
+  // DMA variant: whole 64-lane pieces per row; register variant: 16-B aligned weight tile
+  a.xs_stride = DMA ? round_up(xs_len, 64) : round_up(xs_len, 4);
+  const size_t buf = ((size_t)CK * a.xs_stride + (size_t)g.k_phase * CK * BM) * sizeof(float);
+  const size_t lds = DMA ? 2 * buf : buf;
   PWG_REQUIRE(lds <= 160 * 1024, PWG_ERR_UNSUPPORTED,
               "conv1d: tile needs %zu B of LDS (k=%d stride=%d dil=%d)", lds, g.k_phase, g.stride, g.dil);
-  auto kern = conv1d_mfma_kernel<WM, WN, WAVES_M, WAVES_N, CK>;
+  void (*kern)(ConvArgs);
+  if (DMA)
+    kern = conv1d_mfma_dma_kernel<WM, WN, WAVES_M, WAVES_N, CK>;
+  else
+    kern = conv1d_mfma_kernel<WM, WN, WAVES_M, WAVES_N, CK>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -376,6 +561,149 @@ static int launch_conv(const ConvArgs& a0, const Geometry& g, int batch, int gro
   dim3 block(64 * WAVES_M * WAVES_N);
   hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
   PWG_CHECK_LAUNCH("conv1d_forward");
+  return PWG_OK;
+}
+
+// Tile configurations (id -> instantiation).  ids are stable: tools/bench_conv.py sweeps them.
+struct TileCfg {
+  int bm, bn, ck;
+};
+#define PWG_CONV_CFGS(X)  \
+  X(0, 2, 2, 2, 2, 8)     \
+  X(1, 2, 2, 2, 2, 16)    \
+  X(2, 2, 2, 2, 2, 4)     \
+  X(3, 2, 4, 2, 2, 8)     \
+  X(4, 2, 4, 2, 2, 4)     \
+  X(5, 2, 2, 1, 4, 8)     \
+  X(6, 2, 2, 1, 4, 16)    \
+  X(7, 2, 4, 1, 4, 8)     \
+  X(8, 1, 2, 1, 4, 8)     \
+  X(9, 1, 2, 1, 4, 16)    \
+  X(10, 1, 4, 1, 4, 8)    \
+  X(11, 1, 4, 1, 4, 16)   \
+  X(12, 2, 1, 2, 2, 8)    \
+  X(13, 1, 1, 1, 4, 8)    \
+  X(14, 2, 4, 1, 4, 4)    \
+  X(15, 2, 2, 1, 4, 4)
+static const int kNumCfgs = 16;
+
+static TileCfg cfg_info(int id) {
+  switch (id) {
+#define X(ID, WM, WN, WVM, WVN, CK) \
+  case ID:                          \
+    return TileCfg{32 * WM * WVM, 32 * WN * WVN, CK};
+    PWG_CONV_CFGS(X)
+#undef X
+  }
+  return TileCfg{0, 0, 0};
+}
+
+static size_t cfg_lds(int id, const Geometry& g, int W, bool dma) {
+  TileCfg c = cfg_info(id);
+  const int rows = (W == 1) ? c.bn : ((c.bn - 1) / W + 2);
+  const int xs_len = ((rows - 1) * g.stride + (g.k_phase - 1) * g.dil + 1) * W;
+  const int xs = dma ? round_up(xs_len, 64) : round_up(xs_len, 4);
+  const size_t buf = ((size_t)c.ck * xs + (size_t)g.k_phase * c.ck * c.bm) * sizeof(float);
+  return dma ? 2 * buf : buf;
+}
+
+static int launch_cfg(int id, bool dma, const ConvArgs& a, const Geometry& g, int batch, int groups,
+                      hipStream_t stream) {
+  switch (id) {
+#define X(ID, WM, WN, WVM, WVN, CK)                                                        \
+  case ID:                                                                                 \
+    return dma ? launch_conv<WM, WN, WVM, WVN, CK, true>(a, g, batch, groups, stream)      \
+               : launch_conv<WM, WN, WVM, WVN, CK, false>(a, g, batch, groups, stream);
+    PWG_CONV_CFGS(X)
+#undef X
+  }
+  set_error("conv1d: unknown tile config %d", id);
+  return PWG_ERR_UNSUPPORTED;
+}
+
+// Heuristic from the tools/bench_conv.py sweep on MI355X (HiFi-GAN V1 problem set, B=16 x 800
+// frames): the kernel is latency- rather than reuse-bound, so few taps want SMALL tiles (more
+// resident workgroups per CU), many taps want a short ci-chunk (CK=4) under a 128x128 / 64x256
+// tile.  Every candidate list ends in a configuration that fits the 160 KB LDS for any k.
+static int choose_cfg(const Geometry& g, int W, int batch, int groups, bool dma) {
+  const int m = g.m_g;
+  const int k = g.k_phase;
+  static const int big_fewtaps[] = {12, 0, 2};   // 128x64x8, 128x128x8, 128x128x4
+  static const int big_manytaps[] = {2, 12};     // 128x128x4, 128x64x8
+  static const int mid_fewtaps[] = {13, 15};     // 32x128x8, 64x256x4
+  static const int mid_manytaps[] = {15, 13};    // 64x256x4, 32x128x8
+  static const int small_any[] = {13};           // 32x128x8
+  const int* cand;
+  int ncand;
+  if (m > 64) {
+    if (k <= 4) {
+      cand = big_fewtaps;
+      ncand = 3;
+    } else {
+      cand = big_manytaps;
+      ncand = 2;
+    }
+  } else if (m > 32) {
+    if (k <= 8) {
+      cand = mid_fewtaps;
+      ncand = 2;
+    } else {
+      cand = mid_manytaps;
+      ncand = 2;
+    }
+  } else {
+    cand = small_any;
+    ncand = 1;
+  }
+  (void)batch;
+  (void)groups;
+  for (int i = 0; i < ncand; ++i)
+    if (cfg_lds(cand[i], g, W, dma) <= 80 * 1024) return cand[i];
+  for (int i = 0; i < ncand; ++i)
+    if (cfg_lds(cand[i], g, W, dma) <= 160 * 1024) return cand[i];
+  return 13;
+}
+
+static int fill_args(const pwg_conv1d_desc* d, const Geometry& g, const float* x, const float* w_packed,
+                     const float* bias, const float* add1, const float* add2, float* y, ConvArgs* out) {
+  PWG_REQUIRE(x && w_packed && y, PWG_ERR_NULL, "conv1d_forward: NULL pointer");
+  PWG_REQUIRE(d->pre_act == PWG_ACT_NONE || d->pre_act == PWG_ACT_LEAKY_RELU || d->pre_act == PWG_ACT_RELU,
+              PWG_ERR_UNSUPPORTED, "conv1d: pre_act %d unsupported", d->pre_act);
+  ConvArgs a;
+  a.x = x;
+  a.wp = w_packed;
+  a.bias = bias;
+  a.add1 = add1;
+  a.add2 = add2;
+  a.y = y;
+  a.cin_g = g.cin_g;
+  a.cin_pad = g.cin_pad;
+  a.cout_g = g.cout_g;
+  a.m_g = g.m_g;
+  a.m_pad = g.m_pad;
+  a.t_in = d->t_in;
+  a.t_out = d->t_out;
+  a.width = d->width;
+  a.k = g.k_phase;
+  a.stride = g.stride;
+  a.dil = g.dil;
+  a.pad = g.pad;
+  a.n_cols = g.n_cols;
+  a.out_stride = g.out_stride;
+  a.out_off = g.out_off;
+  a.x_cstride = d->t_in * d->width;
+  a.y_cstride = d->t_out * d->width;
+  a.x_bstride = (long)d->c_in * a.x_cstride;
+  a.y_bstride = (long)d->c_out * a.y_cstride;
+  a.xs_stride = 0;
+  a.pad_mode = d->pad_mode;
+  a.pre_act = d->pre_act;
+  a.post_act = d->post_act;
+  a.pre_slope = d->pre_slope;
+  a.post_slope = d->post_slope;
+  a.out_mul = d->out_mul;
+  a.out_div = d->out_div;
+  *out = a;
   return PWG_OK;
 }
 
@@ -419,76 +747,34 @@ extern "C" int pwg_conv1d_pack_weight(const pwg_conv1d_desc* d, const float* w, 
 
 extern "C" int pwg_conv1d_forward(const pwg_conv1d_desc* d, const float* x, const float* w_packed,
                                   const float* bias, const float* add1, const float* add2, float* y,
-                                  void* stream_) {
+                                  void* stream) {
   Geometry g;
   int rc = make_geometry(d, &g);
   if (rc != PWG_OK) return rc;
-  PWG_REQUIRE(x && w_packed && y, PWG_ERR_NULL, "conv1d_forward: NULL pointer");
-  hipStream_t stream = (hipStream_t)stream_;
   ConvArgs a;
-  a.x = x;
-  a.wp = w_packed;
-  a.bias = bias;
-  a.add1 = add1;
-  a.add2 = add2;
-  a.y = y;
-  a.cin_g = g.cin_g;
-  a.cin_pad = g.cin_pad;
-  a.cout_g = g.cout_g;
-  a.m_g = g.m_g;
-  a.m_pad = g.m_pad;
-  a.t_in = d->t_in;
-  a.t_out = d->t_out;
-  a.width = d->width;
-  a.k = g.k_phase;
-  a.stride = g.stride;
-  a.dil = g.dil;
-  a.pad = g.pad;
-  a.n_cols = g.n_cols;
-  a.out_stride = g.out_stride;
-  a.out_off = g.out_off;
-  a.x_cstride = d->t_in * d->width;
-  a.y_cstride = d->t_out * d->width;
-  a.x_bstride = (long)d->c_in * a.x_cstride;
-  a.y_bstride = (long)d->c_out * a.y_cstride;
-  a.xs_stride = 0;
-  a.pad_mode = d->pad_mode;
-  a.pre_act = d->pre_act;
-  a.post_act = d->post_act;
-  a.pre_slope = d->pre_slope;
-  a.post_slope = d->post_slope;
-  a.out_mul = d->out_mul;
-  a.out_div = d->out_div;
-  PWG_REQUIRE(d->pre_act == PWG_ACT_NONE || d->pre_act == PWG_ACT_LEAKY_RELU || d->pre_act == PWG_ACT_RELU,
-              PWG_ERR_UNSUPPORTED, "conv1d: pre_act %d unsupported", d->pre_act);
+  rc = fill_args(d, g, x, w_packed, bias, add1, add2, y, &a);
+  if (rc != PWG_OK) return rc;
+  const bool dma = d->pad_mode == PWG_PAD_ZERO;  // reflect/replicate need index remapping: register path
+  const int id = choose_cfg(g, d->width, d->batch, d->groups, dma);
+  return launch_cfg(id, dma, a, g, d->batch, d->groups, (hipStream_t)stream);
+}
 
-  // tile selection: rows first (BM = 128 / 64 / 32), then enough column tiles to
-  // cover 256 CUs, then the ci-chunk that keeps the LDS image <= ~56 KB
-  const int m = g.m_g;
-  const long lds_w_per_ck128 = (long)g.k_phase * 128 * 4;  // bytes per ci of a BM=128 tile
-  if (m > 64) {
-    const long blocks128 = (long)ceil_div(g.n_cols, 128) * ceil_div(m, 128) * d->groups * d->batch;
-    if (blocks128 >= 256 || g.n_cols > 64) {
-      if (lds_w_per_ck128 * 16 <= 40 * 1024 && g.cin_g >= 16)
-        return launch_conv<2, 2, 2, 2, 16>(a, g, d->batch, d->groups, stream);
-      if (lds_w_per_ck128 * 8 <= 56 * 1024)
-        return launch_conv<2, 2, 2, 2, 8>(a, g, d->batch, d->groups, stream);
-      return launch_conv<2, 2, 2, 2, 4>(a, g, d->batch, d->groups, stream);
-    }
-    if (lds_w_per_ck128 * 8 <= 56 * 1024) return launch_conv<2, 1, 2, 2, 8>(a, g, d->batch, d->groups, stream);
-    return launch_conv<2, 1, 2, 2, 4>(a, g, d->batch, d->groups, stream);
-  } else if (m > 32) {
-    if (lds_w_per_ck128 * 8 <= 56 * 1024 && g.cin_g >= 16)
-      return launch_conv<2, 2, 1, 4, 16>(a, g, d->batch, d->groups, stream);
-    if (lds_w_per_ck128 * 4 <= 56 * 1024) return launch_conv<2, 2, 1, 4, 8>(a, g, d->batch, d->groups, stream);
-    return launch_conv<2, 2, 1, 4, 4>(a, g, d->batch, d->groups, stream);
-  } else {
-    if (lds_w_per_ck128 * 4 <= 56 * 1024 && g.cin_g >= 16)
-      return launch_conv<1, 2, 1, 4, 16>(a, g, d->batch, d->groups, stream);
-    if (lds_w_per_ck128 * 2 <= 56 * 1024 && g.cin_g >= 8)
-      return launch_conv<1, 2, 1, 4, 8>(a, g, d->batch, d->groups, stream);
-    return launch_conv<1, 2, 1, 4, 4>(a, g, d->batch, d->groups, stream);
-  }
+extern "C" int pwg_conv1d_num_tile_configs(void) { return kNumCfgs; }
+
+extern "C" int pwg_conv1d_forward_cfg(const pwg_conv1d_desc* d, const float* x, const float* w_packed,
+                                      const float* bias, const float* add1, const float* add2, float* y,
+                                      int32_t tile_config, int32_t use_dma, void* stream) {
+  Geometry g;
+  int rc = make_geometry(d, &g);
+  if (rc != PWG_OK) return rc;
+  ConvArgs a;
+  rc = fill_args(d, g, x, w_packed, bias, add1, add2, y, &a);
+  if (rc != PWG_OK) return rc;
+  PWG_REQUIRE(tile_config >= 0 && tile_config < kNumCfgs, PWG_ERR_UNSUPPORTED, "conv1d: tile config %d out of range",
+              tile_config);
+  PWG_REQUIRE(!(use_dma && d->pad_mode != PWG_PAD_ZERO), PWG_ERR_UNSUPPORTED,
+              "conv1d: the DMA path implements zero padding only");
+  return launch_cfg(tile_config, use_dma != 0, a, g, d->batch, d->groups, (hipStream_t)stream);
 }
 
 extern "C" int pwg_weight_norm_scale(const float* v, const float* g, float* scale, int32_t n0,

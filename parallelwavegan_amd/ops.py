@@ -97,3 +97,18 @@ def scale_rows(v, scale):
     w = torch.empty_like(v)
     _lib.check(_lib.lib().pwg_scale_rows(_ptr(v), _ptr(scale), _ptr(w), n0, inner, _stream()), "scale_rows")
     return w
+
+
+def conv1d_forward_cfg(desc, x, w_packed, bias=None, add1=None, add2=None, out=None, tile_config=0, use_dma=True):
+    """Tuning entry: explicit tile configuration / staging path (see include/pwg_kernels.h)."""
+    _require_device(x, w_packed, bias, add1, add2, out)
+    if out is None:
+        out = torch.empty((desc.batch, desc.c_out, desc.t_out * desc.width), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().pwg_conv1d_forward_cfg(ctypes.byref(desc), _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(add1),
+                                                 _ptr(add2), _ptr(out), int(tile_config), int(bool(use_dma)),
+                                                 _stream()), "conv1d_forward_cfg")
+    return out
+
+
+def num_tile_configs():
+    return _lib.lib().pwg_conv1d_num_tile_configs()
