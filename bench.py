@@ -147,41 +147,31 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
-    # ---- dominant-kernel roofline: event-bracket every conv1d_mfma launch of one more step
+    # ---- dominant-kernel roofline: HIP events recorded inside the library on the launch stream
+    # around every kernel of `prof_steps` further steps (pwg_prof_*, include/pwg_kernels.h)
     roofline = None
     if rank == 0:
-        spans = []
-        orig = ops.conv1d_forward
-
-        def timed(desc, *a, **k):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = orig(desc, *a, **k)
-            e1.record()
-            spans.append((e0, e1))
-            return out
-
-        import parallelwavegan_amd.layers.conv as conv_mod
-
-        conv_mod.ops.conv1d_forward = timed
-        with torch.no_grad():
-            g(c)
-        torch.cuda.synchronize()
-        conv_mod.ops.conv1d_forward = orig
-        kernel_ms = sum(a.elapsed_time(b) for a, b in spans)
-        flops = 2.0 * hifigan_macs_per_sample(HIFIGAN_V1) * samples_per_step
-        achieved = flops / (kernel_ms * 1e-3) / 1e12
+        prof_steps = min(args.steps, 3)
+        with ops.profile() as prof, torch.no_grad():
+            for _ in range(prof_steps):
+                g(c)
+        name, r = max(prof.results.items(), key=lambda kv: kv[1]["ms"])
+        achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
         roofline = {
-            "kernel": "conv1d_mfma_kernel (all instantiations)",
+            "kernel": name,
             "bound": "mfma",
             "achieved": achieved,
             "peak": FP32_MATRIX_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / FP32_MATRIX_PEAK_TFLOPS,
             "traffic": None,
-            "launches_per_step": len(spans),
-            "kernel_ms_per_step": kernel_ms,
-            "flops_per_step": flops,
+            "launches_per_step": r["launches"] / prof_steps,
+            "avg_launch_us": r["ms"] * 1e3 / r["launches"],
+            "flops_per_launch": r["flops"] / r["launches"],
+            "algorithmic_bytes_per_launch": r["bytes"] / r["launches"],
+            "algorithmic_GBps": r["bytes"] / (r["ms"] * 1e-3) / 1e9,
+            "kernel_ms_per_step": r["ms"] / prof_steps,
+            "share_of_step_kernel_time": r["ms"] / sum(v["ms"] for v in prof.results.values()),
         }
 
     if rank == 0:

@@ -43,6 +43,19 @@ int pwg_abi_version(void);
 int pwg_target_arch(void);
 
 /* ------------------------------------------------------------------------- */
+/* Per-launch timing (measurement support).  While enabled, every */
+/* kernel launched through this ABI is bracketed by hipEvents recorded on the   */
+/* stream it is launched on; totals are kept per kernel family together with     */
+/* the ALGORITHMIC flops/bytes of the launches (not hardware counters).          */
+/* pwg_prof_get/_num_kernels synchronise the recorded events.                     */
+/* ------------------------------------------------------------------------- */
+int pwg_prof_enable(int on);
+int pwg_prof_reset(void);
+int pwg_prof_num_kernels(void);
+int pwg_prof_get(int32_t idx, char* name, size_t name_cap, double* total_ms, int64_t* launches,
+                 double* flops, double* bytes);
+
+/* ------------------------------------------------------------------------- */
 /* Activations / padding selectors                                            */
 /* ------------------------------------------------------------------------- */
 enum { PWG_ACT_NONE = 0, PWG_ACT_LEAKY_RELU = 1, PWG_ACT_TANH = 2, PWG_ACT_RELU = 3 };

@@ -49,6 +49,12 @@ SIGNATURES = {
     "pwg_last_error": (ctypes.c_char_p, []),
     "pwg_abi_version": (ctypes.c_int, []),
     "pwg_target_arch": (ctypes.c_int, []),
+    "pwg_prof_enable": (ctypes.c_int, [ctypes.c_int]),
+    "pwg_prof_reset": (ctypes.c_int, []),
+    "pwg_prof_num_kernels": (ctypes.c_int, []),
+    "pwg_prof_get": (ctypes.c_int, [_i32, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_double),
+                                    ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double),
+                                    ctypes.POINTER(ctypes.c_double)]),
     "pwg_conv1d_packed_weight_floats": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
     "pwg_conv1d_pack_weight": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     "pwg_conv1d_forward": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -1,6 +1,10 @@
 // capi.hip -- error reporting and version queries of the C ABI.
 #include "common.h"
 
+#include <mutex>
+#include <string>
+#include <vector>
+
 namespace pwg {
 static thread_local char g_err[512] = "";
 
@@ -10,7 +14,95 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+// ---- per-launch event timing ------------------------------------------------------------
+struct ProfRec {
+  const char* kernel;
+  double flops, bytes;
+  hipEvent_t e0, e1;
+};
+static bool g_prof_on = false;
+static std::mutex g_prof_mu;
+static std::vector<ProfRec> g_prof_open;  // launches not yet folded into the totals
+struct ProfTotal {
+  std::string kernel;
+  double ms = 0, flops = 0, bytes = 0;
+  long launches = 0;
+};
+static std::vector<ProfTotal> g_prof_totals;
+
+bool prof_enabled() { return g_prof_on; }
+
+void prof_record(hipStream_t stream, const char* kernel, double flops, double bytes, bool begin) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (begin) {
+    ProfRec r{kernel, flops, bytes, nullptr, nullptr};
+    (void)hipEventCreate(&r.e0);
+    (void)hipEventCreate(&r.e1);
+    (void)hipEventRecord(r.e0, stream);
+    g_prof_open.push_back(r);
+  } else {
+    for (size_t i = g_prof_open.size(); i-- > 0;)
+      if (g_prof_open[i].kernel == kernel) {  // innermost open scope of this kernel family
+        (void)hipEventRecord(g_prof_open[i].e1, stream);
+        break;
+      }
+  }
+}
+
+static void prof_fold() {
+  for (auto& r : g_prof_open) {
+    float ms = 0.f;
+    (void)hipEventSynchronize(r.e1);
+    (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+    ProfTotal* t = nullptr;
+    for (auto& c : g_prof_totals)
+      if (c.kernel == r.kernel) t = &c;
+    if (!t) {
+      g_prof_totals.emplace_back();
+      t = &g_prof_totals.back();
+      t->kernel = r.kernel;
+    }
+    t->ms += ms;
+    t->flops += r.flops;
+    t->bytes += r.bytes;
+    t->launches += 1;
+  }
+  g_prof_open.clear();
+}
 }  // namespace pwg
+
+extern "C" int pwg_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(pwg::g_prof_mu);
+  pwg::g_prof_on = on != 0;
+  return PWG_OK;
+}
+extern "C" int pwg_prof_reset(void) {
+  std::lock_guard<std::mutex> lk(pwg::g_prof_mu);
+  pwg::prof_fold();
+  pwg::g_prof_totals.clear();
+  return PWG_OK;
+}
+extern "C" int pwg_prof_num_kernels(void) {
+  std::lock_guard<std::mutex> lk(pwg::g_prof_mu);
+  pwg::prof_fold();
+  return (int)pwg::g_prof_totals.size();
+}
+extern "C" int pwg_prof_get(int32_t idx, char* name, size_t name_cap, double* total_ms, int64_t* launches,
+                            double* flops, double* bytes) {
+  std::lock_guard<std::mutex> lk(pwg::g_prof_mu);
+  pwg::prof_fold();
+  PWG_REQUIRE(idx >= 0 && idx < (int)pwg::g_prof_totals.size(), PWG_ERR_BAD_SHAPE, "prof_get: index %d out of range", idx);
+  const auto& t = pwg::g_prof_totals[idx];
+  if (name && name_cap) snprintf(name, name_cap, "%s", t.kernel.c_str());
+  if (total_ms) *total_ms = t.ms;
+  if (launches) *launches = t.launches;
+  if (flops) *flops = t.flops;
+  if (bytes) *bytes = t.bytes;
+  return PWG_OK;
+}
 
 extern "C" const char* pwg_last_error(void) { return pwg::g_err; }
 extern "C" int pwg_abi_version(void) { return 1; }

@@ -27,6 +27,24 @@ void set_error(const char* fmt, ...);
     }                                                                        \
   } while (0)
 
+// Optional per-launch timing with HIP events recorded on the launch stream (pwg_prof_* in the
+// public header).  Zero cost when disabled.
+bool prof_enabled();
+void prof_record(hipStream_t stream, const char* kernel, double flops, double bytes, bool begin);
+struct ProfScope {
+  hipStream_t s;
+  const char* k;
+  double f, b;
+  bool on;
+  ProfScope(hipStream_t stream, const char* kernel, double flops, double bytes)
+      : s(stream), k(kernel), f(flops), b(bytes), on(prof_enabled()) {
+    if (on) prof_record(s, k, f, b, true);
+  }
+  ~ProfScope() {
+    if (on) prof_record(s, k, f, b, false);
+  }
+};
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 

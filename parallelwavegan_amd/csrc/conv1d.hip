@@ -559,6 +559,15 @@ static int launch_conv(const ConvArgs& a0, const Geometry& g, int batch, int gro
   }
   dim3 grid(ceil_div(g.n_cols, BN), ceil_div(g.m_g, BM) * groups, batch);
   dim3 block(64 * WAVES_M * WAVES_N);
+  // algorithmic work of this launch: 2*taps*Cin_g MACs per real output element, and one read of
+  // x / one write of y / one read of each fused addend / one read of the packed weights
+  const double out_elems = (double)batch * groups * g.cout_g * a.t_out * a.width;
+  const double taps_eff = (double)g.k_phase * g.phases / g.out_stride;  // transposed: k/stride taps hit each output
+  const double flops = 2.0 * out_elems * g.cin_g * taps_eff;
+  const double bytes = 4.0 * ((double)batch * groups * g.cin_g * a.t_in * a.width +
+                              out_elems * (1 + (a.add1 != nullptr) + (a.add2 != nullptr)) +
+                              (double)groups * g.k_phase * g.cin_g * g.m_g);
+  ProfScope prof(stream, DMA ? "conv1d_mfma_dma_kernel" : "conv1d_mfma_kernel", flops, bytes);
   hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
   PWG_CHECK_LAUNCH("conv1d_forward");
   return PWG_OK;

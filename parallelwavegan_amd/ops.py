@@ -112,3 +112,29 @@ def conv1d_forward_cfg(desc, x, w_packed, bias=None, add1=None, add2=None, out=N
 
 def num_tile_configs():
     return _lib.lib().pwg_conv1d_num_tile_configs()
+
+
+class profile:
+    """Context manager: per-kernel-family HIP-event timing of every launch made through the
+    C ABI (``pwg_prof_*``).  ``.results`` -> {kernel: dict(ms, launches, flops, bytes)}."""
+
+    def __enter__(self):
+        l = _lib.lib()
+        l.pwg_prof_reset()
+        l.pwg_prof_enable(1)
+        self.results = {}
+        return self
+
+    def __exit__(self, *exc):
+        l = _lib.lib()
+        l.pwg_prof_enable(0)
+        n = l.pwg_prof_num_kernels()
+        for i in range(n):
+            name = ctypes.create_string_buffer(128)
+            ms, fl, by = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+            cnt = ctypes.c_int64()
+            _lib.check(l.pwg_prof_get(i, name, 128, ctypes.byref(ms), ctypes.byref(cnt), ctypes.byref(fl),
+                                      ctypes.byref(by)), "prof_get")
+            self.results[name.value.decode()] = dict(ms=ms.value, launches=cnt.value, flops=fl.value, bytes=by.value)
+        l.pwg_prof_reset()
+        return False
