@@ -124,6 +124,24 @@ int pwg_conv1d_forward(const pwg_conv1d_desc* d, const float* x, const float* w_
                        const float* bias, const float* add1, const float* add2, float* y,
                        void* stream);
 
+/* ---- backward (training; replaces ATen convolution_backward at the same call sites) ---- */
+/* Weight image for the data-gradient direction (the dual convolution).          */
+size_t pwg_conv1d_packed_weight_bwd_floats(const pwg_conv1d_desc* d);
+int pwg_conv1d_pack_weight_bwd(const pwg_conv1d_desc* d, const float* w, const float* scale,
+                               float* w_packed_bwd, void* stream);
+/* dx = d(pre_act)/dx(x) * conv_data_grad(dy) + accum.  `d` is the FORWARD descriptor
+ * (its post_act/out_mul/out_div are NOT differentiated here: the caller passes the gradient
+ * w.r.t. the pre-post_act, pre-scale result).  x: forward input (may be NULL when
+ * pre_act == NONE); accum: optional tensor added to the result (gradient accumulation),
+ * may alias dx.                                                                 */
+int pwg_conv1d_backward_data(const pwg_conv1d_desc* d, const float* dy, const float* w_packed_bwd,
+                             const float* x, const float* accum, float* dx, void* stream);
+/* dw (torch layout, same shape as the forward weight) += sum_{b,t} dy * pre_act(x) taps;
+ * db[c] = sum dy.  dw must be ZEROED by the caller (partial sums are combined with fp32
+ * atomics).  Either of dw/db may be NULL.                                       */
+int pwg_conv1d_backward_weight(const pwg_conv1d_desc* d, const float* x, const float* dy, float* dw,
+                               float* db, void* stream);
+
 /* Tuning / diagnostics: the same operation with an explicit tile configuration
  * (0 <= tile_config < pwg_conv1d_num_tile_configs()) and staging path (use_dma:
  * 1 = LDS-DMA double-buffered, 0 = register-staged).  tools/bench_conv.py sweeps

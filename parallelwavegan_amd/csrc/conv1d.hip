@@ -57,6 +57,9 @@ struct ConvArgs {
   int xs_stride;  // LDS row stride of the x tile (floats)
   int pad_mode, pre_act, post_act;
   float pre_slope, post_slope, out_mul, out_div;
+  // backward-data only: multiply by d(pre_act)/dx evaluated at the forward input
+  const float* mask_src;
+  float mask_slope;  // derivative for mask_src <= 0 (LeakyReLU slope, 0 for ReLU)
 };
 
 template <int WM, int WN, int WAVES_M, int WAVES_N, int CK>
@@ -209,6 +212,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv1d_mfma_kernel(Con
         const long o = ybase + (long)cglob * a.y_cstride + (long)u * W + wcol;
         float v = acc[mi][ni][r];
         if (a.bias) v += a.bias[cglob];
+        if (a.mask_src) v *= (a.mask_src[o] > 0.f ? 1.f : a.mask_slope);
         if (a.add1) v += a.add1[o];
         if (a.add2) v += a.add2[o];
         if (a.out_mul != 1.0f) v *= a.out_mul;
@@ -389,6 +393,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv1d_mfma_dma_kernel
         const long o = ybase + (long)cglob * a.y_cstride + (long)u * W + wcol;
         float v = acc[mi][ni][r];
         if (a.bias) v += a.bias[cglob];
+        if (a.mask_src) v *= (a.mask_src[o] > 0.f ? 1.f : a.mask_slope);
         if (a.add1) v += a.add1[o];
         if (a.add2) v += a.add2[o];
         if (a.out_mul != 1.0f) v *= a.out_mul;
@@ -513,17 +518,17 @@ static int make_geometry(const pwg_conv1d_desc* d, Geometry* g) {
     g->out_stride = 1;
     g->out_off = 0;
   } else {
-    PWG_REQUIRE(d->width == 1 && d->dilation == 1 && d->pad_mode == PWG_PAD_ZERO, PWG_ERR_UNSUPPORTED,
-                "conv_transpose1d: width/dilation must be 1 and padding zero");
-    const int full = (d->t_in - 1) * d->stride - 2 * d->pad_left + d->kernel;
-    PWG_REQUIRE(d->t_out >= full && d->t_out < full + d->stride, PWG_ERR_BAD_SHAPE,
-                "conv_transpose1d: t_out=%d not in [%d,%d)", d->t_out, full, full + d->stride);
+    PWG_REQUIRE(d->pad_mode == PWG_PAD_ZERO, PWG_ERR_UNSUPPORTED, "conv_transpose1d: zero padding only");
+    PWG_REQUIRE(d->dilation == 1 || d->stride == 1, PWG_ERR_UNSUPPORTED,
+                "conv_transpose1d: dilation > 1 is supported for stride 1 only");
+    // polyphase: output row u = q*s + r - pad; phase r is a stride-1 conv with J taps over x[q-m]
     g->phases = d->stride;
     g->k_phase = ceil_div(d->kernel, d->stride);
     g->stride = 1;
-    g->dil = 1;
-    g->pad = g->k_phase - 1;
-    g->n_cols = d->t_in + g->k_phase - 1;
+    g->dil = d->dilation;  // != 1 only when stride == 1
+    g->pad = (g->k_phase - 1) * g->dil;
+    const int q_rows = (d->t_out - 1 + d->pad_left) / d->stride + 1;  // covers every u < t_out
+    g->n_cols = q_rows * d->width;
     g->out_stride = d->stride;
     g->out_off = d->pad_left;
   }
@@ -712,6 +717,8 @@ static int fill_args(const pwg_conv1d_desc* d, const Geometry& g, const float* x
   a.post_slope = d->post_slope;
   a.out_mul = d->out_mul;
   a.out_div = d->out_div;
+  a.mask_src = nullptr;
+  a.mask_slope = 0.f;
   *out = a;
   return PWG_OK;
 }
@@ -763,9 +770,72 @@ extern "C" int pwg_conv1d_forward(const pwg_conv1d_desc* d, const float* x, cons
   ConvArgs a;
   rc = fill_args(d, g, x, w_packed, bias, add1, add2, y, &a);
   if (rc != PWG_OK) return rc;
-  const bool dma = d->pad_mode == PWG_PAD_ZERO;  // reflect/replicate need index remapping: register path
-  const int id = choose_cfg(g, d->width, d->batch, d->groups, dma);
+  bool dma = d->pad_mode == PWG_PAD_ZERO;  // reflect/replicate need index remapping: register path
+  int id = choose_cfg(g, d->width, d->batch, d->groups, dma);
+  if (dma && cfg_lds(id, g, d->width, true) > 160 * 1024) {  // very long filters (PQMF k=63): single buffer
+    dma = false;
+    id = choose_cfg(g, d->width, d->batch, d->groups, false);
+  }
   return launch_cfg(id, dma, a, g, d->batch, d->groups, (hipStream_t)stream);
+}
+
+// The data gradient of a convolution is the transposed convolution with the same torch-layout
+// weight (and vice versa), so both directions reuse the forward kernels through the dual descriptor.
+static void dual_desc(const pwg_conv1d_desc* d, pwg_conv1d_desc* o) {
+  *o = *d;
+  o->c_in = d->c_out;
+  o->c_out = d->c_in;
+  o->t_in = d->t_out;
+  o->t_out = d->t_in;
+  o->transposed = d->transposed ? 0 : 1;
+  o->pad_mode = PWG_PAD_ZERO;
+  o->pre_act = PWG_ACT_NONE;
+  o->post_act = PWG_ACT_NONE;
+  o->pre_slope = o->post_slope = 0.f;
+  o->out_mul = o->out_div = 1.f;
+}
+
+extern "C" size_t pwg_conv1d_packed_weight_bwd_floats(const pwg_conv1d_desc* d) {
+  if (!d) return 0;
+  pwg_conv1d_desc dd;
+  dual_desc(d, &dd);
+  return pwg_conv1d_packed_weight_floats(&dd);
+}
+
+extern "C" int pwg_conv1d_pack_weight_bwd(const pwg_conv1d_desc* d, const float* w, const float* scale,
+                                          float* w_packed_bwd, void* stream) {
+  PWG_REQUIRE(d, PWG_ERR_NULL, "pack_weight_bwd: NULL descriptor");
+  pwg_conv1d_desc dd;
+  dual_desc(d, &dd);
+  return pwg_conv1d_pack_weight(&dd, w, scale, w_packed_bwd, stream);
+}
+
+extern "C" int pwg_conv1d_backward_data(const pwg_conv1d_desc* d, const float* dy, const float* w_packed_bwd,
+                                        const float* x, const float* accum, float* dx, void* stream) {
+  PWG_REQUIRE(d, PWG_ERR_NULL, "conv1d_backward_data: NULL descriptor");
+  PWG_REQUIRE(d->pad_mode == PWG_PAD_ZERO, PWG_ERR_UNSUPPORTED,
+              "conv1d_backward_data: only zero padding (pad reflect/replicate inputs explicitly)");
+  PWG_REQUIRE(d->pre_act == PWG_ACT_NONE || x != nullptr, PWG_ERR_NULL,
+              "conv1d_backward_data: the forward input is needed for the pre-activation derivative");
+  pwg_conv1d_desc dd;
+  dual_desc(d, &dd);
+  Geometry g;
+  int rc = make_geometry(&dd, &g);
+  if (rc != PWG_OK) return rc;
+  ConvArgs a;
+  rc = fill_args(&dd, g, dy, w_packed_bwd, nullptr, accum, nullptr, dx, &a);
+  if (rc != PWG_OK) return rc;
+  if (d->pre_act != PWG_ACT_NONE) {
+    a.mask_src = x;
+    a.mask_slope = d->pre_act == PWG_ACT_LEAKY_RELU ? d->pre_slope : 0.f;
+  }
+  bool dma = true;
+  int id = choose_cfg(g, dd.width, dd.batch, dd.groups, true);
+  if (cfg_lds(id, g, dd.width, true) > 160 * 1024) {
+    dma = false;
+    id = choose_cfg(g, dd.width, dd.batch, dd.groups, false);
+  }
+  return launch_cfg(id, dma, a, g, dd.batch, dd.groups, (hipStream_t)stream);
 }
 
 extern "C" int pwg_conv1d_num_tile_configs(void) { return kNumCfgs; }

@@ -1,0 +1,276 @@
+// conv1d_wgrad.hip -- weight gradient of the conv1d family on gfx950 fp32 MFMA.
+//
+//   dW[o][i][k] = sum_{b,n}  G[b][o][n] * act(X[b][i][ xoff(n) + (k*dil - pad)*W ])
+//
+// with G the gradient w.r.t. the convolution output and X its input (roles are swapped by the
+// host for ConvTranspose1d, whose weight gradient is the same expression with x and dy
+// exchanged).  GEMM view per (group, tap): rows = o, cols = i, reduction = (b, n):
+//   A[o][n]  <- G tile   (LDS, rotation-swizzled so that 32 rows hit 32 banks)
+//   B[n][i]  <- X tile   (LDS, odd row stride; every tap is a shifted read of the same tile)
+// One workgroup = 2x2 waves = 64 o x 64 i x TG taps, looping over its slice of the (b,n) range in
+// chunks of 32 columns with LDS-DMA double buffering; partial sums are combined with fp32
+// atomics into the torch-layout gradient (the caller zeroes it).
+#include "common.h"
+
+namespace pwg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+struct WgArgs {
+  const float* g;   // "output gradient" role   (B, CO, n_cols)
+  const float* x;   // "input" role             (B, CI, x_len)
+  float* dw;        // (CO, CI/groups, K) torch layout, accumulated atomically
+  int co_g, ci_g, groups;
+  int k, k0_step;   // taps, taps per tap-group
+  int stride, dil, pad, width;
+  int n_cols;       // columns per batch item in G  (rows_out * width)
+  int x_len;        // samples per channel row in X (rows_in * width)
+  int batch;
+  int chunks_per_item, chunks_total, chunks_per_block;
+  int xs_stride;    // odd
+  float slope_g, slope_x;  // branch-free pre-activation slopes (1 = none)
+  unsigned g_bytes, x_bytes;
+};
+
+constexpr int WG_TT = 32;  // reduction columns per chunk
+
+template <int TG>
+__global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int XS = a.xs_stride;
+  const int buf_floats = 64 * WG_TT + 64 * XS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_o = wave >> 1, wave_i = wave & 1;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  const int otiles = (a.co_g + 63) / 64, itiles = (a.ci_g + 63) / 64;
+  int by = blockIdx.y;
+  const int it = by % itiles;
+  by /= itiles;
+  const int ot = by % otiles;
+  const int grp = by / otiles;
+  const int o0 = ot * 64, i0 = it * 64;
+  const int k0 = blockIdx.z * a.k0_step;
+  const int ntaps = min(TG, a.k - k0);
+  const int W = a.width;
+  const int co_tot = a.co_g * a.groups, ci_tot = a.ci_g * a.groups;
+
+  const int c_begin = blockIdx.x * a.chunks_per_block;
+  const int c_end = min(c_begin + a.chunks_per_block, a.chunks_total);
+  if (c_begin >= c_end) return;
+
+  __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.g, 0, a.g_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const unsigned OOB = 0xFFFFFFFCu;
+
+  f32x16 acc[TG];
+#pragma unroll
+  for (int t = 0; t < TG; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // samples of X per row needed by one chunk: columns span + tap span
+  auto issue = [&](int c, float* buf) {
+    float* gs = buf;
+    float* xs = buf + 64 * WG_TT;
+    const int b = c / a.chunks_per_item;
+    const int n0 = (c - b * a.chunks_per_item) * WG_TT;
+    // ---- G tile: 64 rows x 32 cols, element (o, n) stored at column (n + o) & 31
+    for (int j = wave; j < 32; j += 4) {
+      const int row = 2 * j + lhi;
+      const int n = n0 + ((l31 - row) & 31);
+      const int o = o0 + row;
+      unsigned off = OOB;
+      if (o < a.co_g && n < a.n_cols)
+        off = (unsigned)((((long)b * co_tot + grp * a.co_g + o) * a.n_cols + n) * 4);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(g_rs, (lds_ptr_t)(gs + j * 64), 4, off, 0, 0, 0);
+    }
+    // ---- X tile: 64 rows, flat range [f0, f0 + L)
+    const int h0 = n0 / W;
+    int n_last = n0 + WG_TT - 1;
+    if (n_last > a.n_cols - 1) n_last = a.n_cols - 1;
+    const int h1 = n_last / W;
+    const int f0 = (h0 * a.stride + k0 * a.dil - a.pad) * W;
+    const int L = ((h1 - h0) * a.stride + (ntaps - 1) * a.dil + 1) * W;
+    for (int r = wave; r < 64; r += 4) {
+      const int i = i0 + r;
+      const long rowbase = ((long)b * ci_tot + grp * a.ci_g + i) * a.x_len;
+      for (int e0 = 0; e0 < L; e0 += 64) {
+        const int f = f0 + e0 + lane;
+        unsigned off = OOB;
+        if (i < a.ci_g && f >= 0 && f < a.x_len && e0 + lane < L) off = (unsigned)((rowbase + f) * 4);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr_t)(xs + r * XS + e0), 4, off, 0, 0, 0);
+      }
+    }
+  };
+
+  issue(c_begin, smem);
+  for (int c = c_begin; c < c_end; ++c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float* buf = smem + ((c - c_begin) & 1) * buf_floats;
+    if (c + 1 < c_end) issue(c + 1, smem + ((c + 1 - c_begin) & 1) * buf_floats);
+    const float* gs = buf;
+    const float* xs = buf + 64 * WG_TT;
+    const int b = c / a.chunks_per_item;
+    const int n0 = (c - b * a.chunks_per_item) * WG_TT;
+    const int h0 = n0 / W;
+    const int orow = wave_o * 32 + l31;
+    const float* grow = gs + orow * WG_TT;
+    const float* xrow = xs + (wave_i * 32 + l31) * XS;
+#pragma unroll 4
+    for (int step = 0; step < WG_TT / 2; ++step) {
+      const int nl = 2 * step + lhi;
+      float av = grow[(nl + orow) & 31];
+      av = __builtin_fmaf(a.slope_g, __builtin_fminf(av, 0.f), __builtin_fmaxf(av, 0.f));
+      int xo;
+      if (W == 1) {
+        xo = nl * a.stride;
+      } else {
+        const int n = n0 + nl;
+        const int h = n / W;
+        xo = (h - h0) * a.stride * W + (n - h * W);
+      }
+#pragma unroll
+      for (int t = 0; t < TG; ++t) {
+        if (t < ntaps) {
+          float bv = xrow[xo + t * a.dil * W];
+          bv = __builtin_fmaf(a.slope_x, __builtin_fminf(bv, 0.f), __builtin_fmaxf(bv, 0.f));
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: D layout col = lane&31 (-> i), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (-> o)
+  const int i = i0 + wave_i * 32 + l31;
+  if (i < a.ci_g) {
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+      if (t < ntaps) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = o0 + wave_o * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          if (o < a.co_g)
+            atomicAdd(a.dw + (((long)(grp * a.co_g + o)) * a.ci_g + i) * a.k + k0 + t, acc[t][r]);
+        }
+      }
+    }
+  }
+}
+
+// db[c] = sum_{b,n} dy[b][c][n]   (one workgroup per channel)
+__global__ void bias_grad_kernel(const float* dy, float* db, int batch, int channels, int n) {
+  __shared__ float red[4];
+  const int c = blockIdx.x;
+  float s = 0.f;
+  for (int b = 0; b < batch; ++b) {
+    const float* p = dy + ((long)b * channels + c) * n;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += p[i];
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) db[c] = red[0] + red[1] + red[2] + red[3];
+}
+
+template <int TG>
+static int launch_wgrad(WgArgs a, int tap_groups, hipStream_t stream, double flops, double bytes) {
+  a.k0_step = TG;
+  const int rows = (a.width == 1) ? WG_TT : ((WG_TT - 1) / a.width + 2);
+  int xs_len = ((rows - 1) * a.stride + (TG - 1) * a.dil + 1) * a.width;
+  a.xs_stride = round_up(xs_len, 64) + 1;  // whole DMA pieces per row + odd stride (bank spread)
+  const size_t lds = 2 * (size_t)(64 * WG_TT + 64 * a.xs_stride) * sizeof(float);
+  PWG_REQUIRE(lds <= 160 * 1024, PWG_ERR_UNSUPPORTED, "conv1d_backward_weight: tile needs %zu B of LDS", lds);
+  auto kern = conv1d_wgrad_kernel<TG>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    PWG_REQUIRE(e == hipSuccess, PWG_ERR_LAUNCH, "conv1d_backward_weight: cannot raise LDS limit: %s",
+                hipGetErrorString(e));
+  }
+  const int tiles = ceil_div(a.co_g, 64) * ceil_div(a.ci_g, 64) * a.groups;
+  // enough reduction slices to fill the chip (~4 workgroups per CU), at least 4 chunks each
+  int splits = ceil_div(1024, tiles * tap_groups);
+  if (splits > ceil_div(a.chunks_total, 4)) splits = ceil_div(a.chunks_total, 4);
+  if (splits < 1) splits = 1;
+  a.chunks_per_block = ceil_div(a.chunks_total, splits);
+  splits = ceil_div(a.chunks_total, a.chunks_per_block);
+  dim3 grid(splits, tiles, tap_groups);
+  ProfScope prof(stream, "conv1d_wgrad_kernel", flops, bytes);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+  PWG_CHECK_LAUNCH("conv1d_backward_weight");
+  return PWG_OK;
+}
+
+}  // namespace pwg
+
+using namespace pwg;
+
+extern "C" int pwg_conv1d_backward_weight(const pwg_conv1d_desc* d, const float* x, const float* dy,
+                                          float* dw, float* db, void* stream_) {
+  PWG_REQUIRE(d && x && dy, PWG_ERR_NULL, "conv1d_backward_weight: NULL pointer");
+  PWG_REQUIRE(d->c_in % d->groups == 0 && d->c_out % d->groups == 0 && d->groups > 0, PWG_ERR_BAD_SHAPE,
+              "conv1d_backward_weight: bad groups");
+  PWG_REQUIRE(d->pad_mode == PWG_PAD_ZERO, PWG_ERR_UNSUPPORTED,
+              "conv1d_backward_weight: only zero padding (pad reflect/replicate inputs explicitly)");
+  hipStream_t stream = (hipStream_t)stream_;
+  const long y_elems = (long)d->batch * d->c_out * d->t_out * d->width;
+  const long x_elems = (long)d->batch * d->c_in * d->t_in * d->width;
+  PWG_REQUIRE(y_elems * 4 < 0xFFFFFFF0L && x_elems * 4 < 0xFFFFFFF0L, PWG_ERR_UNSUPPORTED,
+              "conv1d_backward_weight: tensors above 4 GiB need batch splitting");
+  if (db) {
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(d->c_out), dim3(256), 0, stream, dy, db, d->batch, d->c_out,
+                       d->t_out * d->width);
+    PWG_CHECK_LAUNCH("bias_grad");
+  }
+  if (!dw) return PWG_OK;
+  WgArgs a;
+  const float slope = d->pre_act == PWG_ACT_LEAKY_RELU ? d->pre_slope : (d->pre_act == PWG_ACT_RELU ? 0.f : 1.f);
+  if (!d->transposed) {
+    a.g = dy;
+    a.x = x;
+    a.co_g = d->c_out / d->groups;
+    a.ci_g = d->c_in / d->groups;
+    a.n_cols = d->t_out * d->width;
+    a.x_len = d->t_in * d->width;
+    a.slope_g = 1.f;
+    a.slope_x = slope;
+    a.g_bytes = (unsigned)(y_elems * 4);
+    a.x_bytes = (unsigned)(x_elems * 4);
+  } else {
+    // ConvTranspose1d: dW[ci][co][k] = sum x[ci][q] * dy[co][q*s - p + k]: same kernel, roles swapped
+    PWG_REQUIRE(d->dilation == 1 || d->stride == 1, PWG_ERR_UNSUPPORTED, "conv_transpose1d wgrad: dilation with stride");
+    a.g = x;
+    a.x = dy;
+    a.co_g = d->c_in / d->groups;
+    a.ci_g = d->c_out / d->groups;
+    a.n_cols = d->t_in * d->width;
+    a.x_len = d->t_out * d->width;
+    a.slope_g = slope;
+    a.slope_x = 1.f;
+    a.g_bytes = (unsigned)(x_elems * 4);
+    a.x_bytes = (unsigned)(y_elems * 4);
+  }
+  a.dw = dw;
+  a.groups = d->groups;
+  a.k = d->kernel;
+  a.stride = d->stride;
+  a.dil = d->dilation;
+  a.pad = d->pad_left;
+  a.width = d->width;
+  a.batch = d->batch;
+  a.chunks_per_item = ceil_div(a.n_cols, WG_TT);
+  a.chunks_total = a.chunks_per_item * d->batch;
+  const double flops = 2.0 * d->batch * (double)a.n_cols * a.co_g * a.ci_g * d->groups * d->kernel;
+  const double bytes = 4.0 * ((double)x_elems + (double)y_elems + (double)a.co_g * a.ci_g * d->groups * d->kernel);
+  const int k = d->kernel;
+  if (k <= 4) return launch_wgrad<4>(a, ceil_div(k, 4), stream, flops, bytes);
+  if (k <= 6 || k == 11 || k == 12) return launch_wgrad<6>(a, ceil_div(k, 6), stream, flops, bytes);
+  if (k == 7 || k == 41 || k == 42 || k == 14) return launch_wgrad<7>(a, ceil_div(k, 7), stream, flops, bytes);
+  return launch_wgrad<8>(a, ceil_div(k, 8), stream, flops, bytes);
+}

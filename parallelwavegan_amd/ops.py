@@ -80,6 +80,38 @@ def conv1d_forward(desc, x, w_packed, bias=None, add1=None, add2=None, out=None)
     return out
 
 
+def pack_weight_bwd(desc, w, scale=None):
+    """Weight image for the data-gradient direction of ``desc`` (forward descriptor)."""
+    _require_device(w, scale)
+    n = _lib.lib().pwg_conv1d_packed_weight_bwd_floats(ctypes.byref(desc))
+    if n == 0:
+        _lib.check(-1, "packed_weight_bwd_floats")
+    out = torch.empty(n, device=w.device, dtype=torch.float32)
+    _lib.check(_lib.lib().pwg_conv1d_pack_weight_bwd(ctypes.byref(desc), _ptr(w), _ptr(scale), _ptr(out), _stream()),
+               "conv1d_pack_weight_bwd")
+    return out
+
+
+def conv1d_backward_data(desc, dy, w_packed_bwd, x=None, accum=None, out=None):
+    """dx = pre_act'(x) * data_grad(dy) (+ accum); ``desc`` is the forward descriptor."""
+    _require_device(dy, w_packed_bwd, x, accum, out)
+    if out is None:
+        out = torch.empty((desc.batch, desc.c_in, desc.t_in * desc.width), device=dy.device, dtype=torch.float32)
+    _lib.check(_lib.lib().pwg_conv1d_backward_data(ctypes.byref(desc), _ptr(dy), _ptr(w_packed_bwd), _ptr(x),
+                                                   _ptr(accum), _ptr(out), _stream()), "conv1d_backward_data")
+    return out
+
+
+def conv1d_backward_weight(desc, x, dy, weight_shape, need_dw=True, need_db=True):
+    """(dw in torch layout, db); partial sums are combined with fp32 atomics."""
+    _require_device(x, dy)
+    dw = torch.zeros(weight_shape, device=x.device, dtype=torch.float32) if need_dw else None
+    db = torch.empty(desc.c_out, device=x.device, dtype=torch.float32) if need_db else None
+    _lib.check(_lib.lib().pwg_conv1d_backward_weight(ctypes.byref(desc), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db),
+                                                     _stream()), "conv1d_backward_weight")
+    return dw, db
+
+
 def weight_norm_scale(v, g):
     """scale[i] = g[i] / ||v[i]||  (old-style weight_norm, dim=0)."""
     _require_device(v, g)

@@ -1,0 +1,169 @@
+"""GPU parity of the conv1d family (forward / data gradient / weight gradient) against the
+same ATen ops on CPU (fp32), which is what the reference executes at these call sites."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from parallelwavegan_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+# fp32 tolerance relative to the largest reference magnitude (different summation order only)
+RTOL = 3e-5
+
+
+def _close(a, b, what):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = b.abs().max().item() + 1e-12
+    err = (a - b).abs().max().item() / scale
+    assert err <= RTOL, f"{what}: rel-to-max error {err:.3e}"
+
+
+def _lrelu(x, slope):
+    return F.leaky_relu(x, slope) if slope is not None else x
+
+
+CONV_CASES = [
+    # B, Cin, Cout, T, K, stride, dil, pad, groups, slope
+    (2, 80, 512, 32, 7, 1, 1, 3, 1, None),      # HiFi-GAN input conv
+    (2, 32, 32, 300, 3, 1, 5, 5, 1, 0.1),       # MRF k3 d5
+    (1, 64, 64, 257, 11, 1, 3, 15, 1, 0.1),     # MRF k11 d3, ragged T
+    (2, 128, 128, 130, 7, 1, 1, 3, 1, 0.1),
+    (2, 256, 256, 64, 3, 1, 1, 1, 1, 0.1),
+    (2, 32, 1, 200, 7, 1, 1, 3, 1, 0.01),       # output conv (Cout = 1)
+    (2, 1, 16, 400, 15, 1, 1, 7, 1, None),      # Cin = 1 first D layer
+    (2, 16, 64, 400, 41, 4, 1, 20, 4, 0.2),     # grouped strided (MelGAN D / MSD pattern)
+    (1, 128, 256, 256, 41, 4, 1, 20, 16, 0.1),  # MSD layer 2
+    (3, 64, 64, 97, 3, 1, 2, 2, 1, 0.2),        # PWG D dilation 2
+    (2, 8, 24, 50, 5, 3, 1, 2, 1, None),        # stride 3 (MPD pattern as plain 1-D)
+    (2, 4, 8, 63, 1, 1, 1, 0, 1, None),         # 1x1
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,K,stride,dil,pad,groups,slope", CONV_CASES)
+def test_conv1d_forward_backward(B, Cin, Cout, T, K, stride, dil, pad, groups, slope, device):
+    g = torch.Generator().manual_seed(B * 1000 + Cin + K)
+    x = torch.randn(B, Cin, T, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin // groups, K, generator=g) / (Cin // groups * K) ** 0.5).requires_grad_()
+    b = torch.randn(Cout, generator=g, requires_grad=True)
+    y_ref = F.conv1d(_lrelu(x, slope), w, b, stride=stride, padding=pad, dilation=dil, groups=groups)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    t_out = y_ref.shape[-1]
+    desc = ops.make_conv_desc(B, Cin, Cout, T, t_out, K, stride, dil, pad, groups,
+                              pre_act="leaky_relu" if slope is not None else None, pre_slope=slope or 0.0)
+    xd, wd, bd, dyd = (t.detach().to(device).contiguous() for t in (x, w, b, dy))
+    y = ops.conv1d_forward(desc, xd, ops.pack_weight(desc, wd), bd)
+    _close(y, y_ref, "forward")
+    dx = ops.conv1d_backward_data(desc, dyd, ops.pack_weight_bwd(desc, wd), xd)
+    _close(dx, x.grad, "backward_data")
+    dw, db = ops.conv1d_backward_weight(desc, xd, dyd, tuple(w.shape))
+    _close(dw, w.grad, "backward_weight")
+    _close(db, b.grad, "backward_bias")
+
+
+CONVT_CASES = [
+    # B, Cin, Cout, T, K, stride, pad, out_pad, slope
+    (2, 512, 256, 32, 16, 8, 4, 0, 0.1),
+    (2, 64, 32, 257, 4, 2, 1, 0, 0.1),
+    (1, 256, 128, 28, 10, 5, 3, 1, 0.1),   # LibriTTS odd scale
+    (2, 32, 16, 100, 6, 3, 2, 1, 0.2),
+    (2, 4, 1, 64, 63, 4, 31, 3, None),     # PQMF synthesis as one transposed conv
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,K,stride,pad,out_pad,slope", CONVT_CASES)
+def test_conv_transpose1d_forward_backward(B, Cin, Cout, T, K, stride, pad, out_pad, slope, device):
+    g = torch.Generator().manual_seed(B * 77 + Cin + K)
+    x = torch.randn(B, Cin, T, generator=g, requires_grad=True)
+    w = (torch.randn(Cin, Cout, K, generator=g) / (Cin * K / stride) ** 0.5).requires_grad_()
+    b = torch.randn(Cout, generator=g, requires_grad=True)
+    y_ref = F.conv_transpose1d(_lrelu(x, slope), w, b, stride=stride, padding=pad, output_padding=out_pad)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    desc = ops.make_conv_desc(B, Cin, Cout, T, y_ref.shape[-1], K, stride, 1, pad, 1, transposed=True,
+                              pre_act="leaky_relu" if slope is not None else None, pre_slope=slope or 0.0)
+    xd, wd, bd, dyd = (t.detach().to(device).contiguous() for t in (x, w, b, dy))
+    y = ops.conv1d_forward(desc, xd, ops.pack_weight(desc, wd), bd)
+    _close(y, y_ref, "forward")
+    dx = ops.conv1d_backward_data(desc, dyd, ops.pack_weight_bwd(desc, wd), xd)
+    _close(dx, x.grad, "backward_data")
+    dw, db = ops.conv1d_backward_weight(desc, xd, dyd, tuple(w.shape))
+    _close(dw, w.grad, "backward_weight")
+    _close(db, b.grad, "backward_bias")
+
+
+CONV2D_CASES = [
+    # B, Cin, Cout, H, period, K, stride, pad, slope     (MPD: Conv2d (K,1), stride (s,1), pad (p,0))
+    (2, 1, 32, 100, 3, 5, 3, 2, None),
+    (2, 32, 128, 67, 2, 5, 3, 2, 0.1),
+    (1, 128, 64, 23, 5, 5, 1, 2, 0.1),
+    (2, 64, 1, 11, 7, 2, 1, 1, 0.1),    # output conv, kernel (2,1) pad (1,0) -> H+1 rows
+    (2, 16, 16, 9, 11, 5, 3, 2, 0.1),
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,P,K,stride,pad,slope", CONV2D_CASES)
+def test_conv2d_kx1_forward_backward(B, Cin, Cout, H, P, K, stride, pad, slope, device):
+    g = torch.Generator().manual_seed(H * 13 + P)
+    x = torch.randn(B, Cin, H, P, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, K, 1, generator=g) / (Cin * K) ** 0.5).requires_grad_()
+    b = torch.randn(Cout, generator=g, requires_grad=True)
+    y_ref = F.conv2d(_lrelu(x, slope), w, b, stride=(stride, 1), padding=(pad, 0))
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    h_out = y_ref.shape[2]
+    desc = ops.make_conv_desc(B, Cin, Cout, H, h_out, K, stride, 1, pad, 1, width=P,
+                              pre_act="leaky_relu" if slope is not None else None, pre_slope=slope or 0.0)
+    xd = x.detach().reshape(B, Cin, H * P).to(device).contiguous()
+    wd = w.detach().reshape(Cout, Cin, K).to(device).contiguous()
+    bd = b.detach().to(device)
+    dyd = dy.reshape(B, Cout, h_out * P).to(device).contiguous()
+    y = ops.conv1d_forward(desc, xd, ops.pack_weight(desc, wd), bd)
+    _close(y.reshape(y_ref.shape), y_ref, "forward")
+    dx = ops.conv1d_backward_data(desc, dyd, ops.pack_weight_bwd(desc, wd), xd)
+    _close(dx.reshape(x.shape), x.grad, "backward_data")
+    dw, db = ops.conv1d_backward_weight(desc, xd, dyd, (Cout, Cin, K))
+    _close(dw.reshape(w.shape), w.grad, "backward_weight")
+    _close(db, b.grad, "backward_bias")
+
+
+@pytest.mark.parametrize("mode", ["reflect", "replicate"])
+def test_conv1d_reflect_replicate_padding_forward(mode, device):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 48, 90, generator=g)
+    w = torch.randn(48, 48, 3, generator=g) / 12
+    b = torch.randn(48, generator=g)
+    for d in (1, 9, 27):
+        y_ref = F.conv1d(F.pad(F.leaky_relu(x, 0.2), (d, d), mode=mode), w, b, dilation=d)
+        desc = ops.make_conv_desc(2, 48, 48, 90, 90, 3, 1, d, d, 1, pad_mode=mode, pre_act="leaky_relu", pre_slope=0.2)
+        y = ops.conv1d_forward(desc, x.to(device), ops.pack_weight(desc, w.to(device)), b.to(device))
+        _close(y, y_ref, f"{mode} d={d}")
+
+
+def test_fused_epilogue(device):
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 32, 200, generator=g)
+    w = torch.randn(32, 32, 3, generator=g) / 10
+    b = torch.randn(32, generator=g)
+    r1 = torch.randn(2, 32, 200, generator=g)
+    r2 = torch.randn(2, 32, 200, generator=g)
+    y_ref = torch.tanh((F.conv1d(F.leaky_relu(x, 0.1), w, b, padding=1) + r1 + r2) / 3)
+    desc = ops.make_conv_desc(2, 32, 32, 200, 200, 3, 1, 1, 1, 1, pre_act="leaky_relu", pre_slope=0.1,
+                              post_act="tanh", out_div=3.0)
+    y = ops.conv1d_forward(desc, x.to(device), ops.pack_weight(desc, w.to(device)), b.to(device), r1.to(device), r2.to(device))
+    _close(y, y_ref, "fused epilogue")
+
+
+def test_all_tile_configs_agree(device):
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 128, 300, generator=g).to(device)
+    w = (torch.randn(128, 128, 7, generator=g) / 30).to(device)
+    desc = ops.make_conv_desc(2, 128, 128, 300, 300, 7, 1, 3, 9, 1, pre_act="leaky_relu", pre_slope=0.1)
+    wp = ops.pack_weight(desc, w)
+    ref = F.conv1d(F.leaky_relu(x.cpu(), 0.1), w.cpu(), None, padding=9, dilation=3)
+    for cfg in range(ops.num_tile_configs()):
+        for dma in (True, False):
+            y = ops.conv1d_forward_cfg(desc, x, wp, tile_config=cfg, use_dma=dma)
+            _close(y, ref, f"cfg {cfg} dma={dma}")
