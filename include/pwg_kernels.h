@@ -162,6 +162,108 @@ int pwg_weight_norm_scale(const float* v, const float* g, float* scale, int32_t 
 int pwg_scale_rows(const float* v, const float* scale, float* w, int32_t n0, int32_t inner,
                    void* stream);
 
+/* ------------------------------------------------------------------------- */
+/* Activation / reparametrisation backward                                     */
+/* ------------------------------------------------------------------------- */
+/* dx = dy * scale * act'(.), act' written in terms of the activation OUTPUT y
+ * (tanh: 1-y^2; leaky_relu: y>0 ? 1 : slope; relu: y>0).  Replaces the autograd
+ * nodes of torch.nn.Tanh / LeakyReLU at models/hifigan.py:150, :329 etc.        */
+int pwg_act_backward(const float* dy, const float* y, float* dx, int64_t n, int32_t act, float slope,
+                     float scale, void* stream);
+/* Backward of old-style weight_norm (dim 0): given dw (torch layout) returns dv, dg. */
+int pwg_weight_norm_backward(const float* dw, const float* v, const float* g, float* dv, float* dg,
+                             int32_t n0, int32_t inner, void* stream);
+/* torch.nn.utils.spectral_norm (dim 0, one power iteration, eps 1e-12) as used by the first
+ * HiFi-GAN scale discriminator (models/hifigan.py:613-621,750-754).  w_orig viewed as
+ * (rows, cols) = (c_out, c_in/groups * k).  do_iter != 0 updates u (rows) and v (cols) in
+ * place (training-mode forward); sigma[0] = u^T W v; w = w_orig / sigma.
+ * tmp: max(rows, cols) floats of workspace.                                       */
+int pwg_spectral_norm_forward(const float* w_orig, float* u, float* v, float* sigma, float* w, float* tmp,
+                              int32_t rows, int32_t cols, int32_t do_iter, float eps, void* stream);
+/* dw_orig = dw / sigma - (<dw, w_orig> / sigma^2) u v^T ;  scratch: 1 float.       */
+int pwg_spectral_norm_backward(const float* dw, const float* w_orig, const float* u, const float* v,
+                               const float* sigma, float* dw_orig, float* scratch, int32_t rows,
+                               int32_t cols, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Pooling / explicit padding                                                  */
+/* ------------------------------------------------------------------------- */
+/* torch.nn.AvgPool1d over `rows` rows (models/hifigan.py:773-775: k4 s2 p2,
+ * count_include_pad=1; models/melgan.py:409-414: k4 s2 p1 count_include_pad=0).   */
+int pwg_avg_pool1d_forward(const float* x, float* y, int64_t rows, int32_t t_in, int32_t t_out,
+                           int32_t kernel, int32_t stride, int32_t pad, int32_t count_include_pad,
+                           void* stream);
+int pwg_avg_pool1d_backward(const float* dy, float* dx, int64_t rows, int32_t t_in, int32_t t_out,
+                            int32_t kernel, int32_t stride, int32_t pad, int32_t count_include_pad,
+                            void* stream);
+/* F.pad(x, (pad_left, pad_right), mode) for mode = PWG_PAD_* (period discriminator tail,
+ * models/hifigan.py:365-368; MelGAN ReflectionPad1d when training).                */
+int pwg_pad1d_forward(const float* x, float* y, int64_t rows, int32_t t_in, int32_t pad_left,
+                      int32_t pad_right, int32_t mode, void* stream);
+int pwg_pad1d_backward(const float* dy, float* dx, int64_t rows, int32_t t_in, int32_t pad_left,
+                       int32_t pad_right, int32_t mode, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Spectral losses: torch.stft(center=True, reflect) is computed as            */
+/*   frame_fold  (B,T) -> (B, hop, n_cols):  y[b][c][n] = reflect_pad(x)[n*hop+c] */
+/*   conv1d      Cin = hop, Cout = 2*bins, k = ceil(win/hop)  (windowed DFT basis  */
+/*               as the weight; runs on the MFMA conv kernel above)               */
+/*   stft_mag    sqrt(max(re^2+im^2, eps))                                        */
+/* replacing losses/stft_loss.py:16-40 and losses/mel_loss.py:95-110.             */
+/* ------------------------------------------------------------------------- */
+int pwg_frame_fold_forward(const float* x, float* y, int32_t batch, int32_t t, int32_t pad, int32_t hop,
+                           int32_t n_cols, void* stream);
+int pwg_frame_fold_backward(const float* dy, float* dx, int32_t batch, int32_t t, int32_t pad,
+                            int32_t hop, int32_t n_cols, void* stream);
+/* spec: (B, 2*bins, frames), rows [0,bins) real, [bins,2*bins) imaginary.         */
+int pwg_stft_mag_forward(const float* spec, float* mag, int32_t batch, int32_t bins, int32_t frames,
+                         float eps, void* stream);
+int pwg_stft_mag_backward(const float* spec, const float* mag, const float* dmag, float* dspec,
+                          int32_t batch, int32_t bins, int32_t frames, float eps, void* stream);
+/* y = log(max(x, eps)) / log_div  (log_div = 1, ln2, ln10: losses/mel_loss.py:71-79,108-110) */
+int pwg_log_clamp_forward(const float* x, float* y, int64_t n, float eps, float log_div, void* stream);
+int pwg_log_clamp_backward(const float* x, const float* dy, float* dx, int64_t n, float eps, float log_div,
+                           void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Loss reductions (deterministic two-stage sums)                              */
+/*   out[0] = scale * sum_i term_i ;  mode 0 |a-b| (F.l1_loss: feat_match_loss.py:44, */
+/*   mel_loss.py:163, stft_loss.py:82), 1 (a-b)^2 and 2 a^2 (Frobenius norms,        */
+/*   stft_loss.py:61), 3 (a-c)^2 (F.mse_loss against a constant: adversarial_loss.py */
+/*   :54-58,113-123), 4 a.  workspace: >= 512 floats.                                */
+/* ------------------------------------------------------------------------- */
+enum { PWG_RED_ABS_DIFF = 0, PWG_RED_SQ_DIFF = 1, PWG_RED_SQ = 2, PWG_RED_SQ_DIFF_CONST = 3, PWG_RED_SUM = 4 };
+int pwg_reduce_forward(const float* a, const float* b, float c, int64_t n, int32_t mode, float scale,
+                       float* out, float* workspace, void* stream);
+/* da = gout[0] * scale * dterm/da (db = -da); gout is a DEVICE scalar.            */
+int pwg_reduce_backward(const float* a, const float* b, float c, int64_t n, int32_t mode, float scale,
+                        const float* gout, float* da, float* db, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Fused multi-tensor optimizer steps over a device table of chunks            */
+/* (replaces the per-parameter Python loops of torch.optim.Adam and            */
+/* optimizers/radam.py:27-99)                                    */
+/* ------------------------------------------------------------------------- */
+typedef struct pwg_opt_chunk {
+  float* p;        /* parameter slice                                    */
+  const float* g;  /* gradient slice                                     */
+  float* m;        /* exp_avg                                            */
+  float* v;        /* exp_avg_sq                                         */
+  float* vmax;     /* max_exp_avg_sq (amsgrad) or NULL                   */
+  int32_t n;       /* elements in this slice                             */
+  int32_t pad_;
+} pwg_opt_chunk;
+/* `step` is the 1-based step count AFTER increment, as torch uses it for bias correction;
+ * gradients are multiplied by grad_scale first (1/world_size after a sum all-reduce).   */
+int pwg_adam_step(const void* chunks, int32_t n_chunks, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int32_t step, float grad_scale, void* stream);
+int pwg_radam_step(const void* chunks, int32_t n_chunks, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int32_t step, float grad_scale, void* stream);
+/* torch.nn.utils.clip_grad_norm_ (bin/train.py:289-293,329-333): out[0] = total L2 norm,
+ * out[1] = applied coefficient; gradients are scaled in place.  workspace >= n_chunks floats. */
+int pwg_clip_grad_norm(const void* chunks, int32_t n_chunks, float max_norm, float* out, float* workspace,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

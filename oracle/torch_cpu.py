@@ -144,3 +144,190 @@ def hifigan_inference(sd, c, normalize_before=False, **params):
         c = (c - sd["mean"]) / sd["scale"]
     y = hifigan_generator(sd, c.transpose(1, 0).unsqueeze(0), **params)
     return y.squeeze(0).transpose(1, 0)
+
+
+# ----------------------------------------------------------------------------
+# spectral norm (torch.nn.utils.spectral_norm, old hook API, dim=0, 1 iteration)
+# ----------------------------------------------------------------------------
+def spectral_norm_weight(sd, prefix, training, eps=1e-12):
+    """``weight = weight_orig / sigma``; in training mode one power iteration first, which
+    UPDATES ``sd[prefix.weight_u]`` / ``weight_v`` in place like the hook does
+    (call sites models/hifigan.py:613-621; torch/nn/utils/spectral_norm.py is third-party)."""
+    w = sd[prefix + ".weight_orig"]
+    u, v = sd[prefix + ".weight_u"], sd[prefix + ".weight_v"]
+    wm = w.reshape(w.shape[0], -1)
+    if training:
+        with torch.no_grad():
+            v = F.normalize(torch.mv(wm.t(), u), dim=0, eps=eps)
+            u = F.normalize(torch.mv(wm, v), dim=0, eps=eps)
+            sd[prefix + ".weight_u"], sd[prefix + ".weight_v"] = u, v
+    sigma = torch.dot(u, torch.mv(wm, v))
+    return w / sigma
+
+
+def get_weight_any(sd, prefix, training=False):
+    if prefix + ".weight_orig" in sd:
+        return spectral_norm_weight(sd, prefix, training)
+    return get_weight(sd, prefix)
+
+
+# ----------------------------------------------------------------------------
+# HiFi-GAN discriminators (models/hifigan.py:354-381, 586-601, 762-777, 850-864)
+# ----------------------------------------------------------------------------
+def hifigan_period_discriminator(sd, prefix, x, period, kernel_sizes=(5, 3), downsample_scales=(3, 3, 3, 3, 1),
+                                 slope=0.1, training=False):
+    """``HiFiGANPeriodDiscriminator.forward`` models/hifigan.py:354-381."""
+    b, c, t = x.shape
+    if t % period != 0:
+        n_pad = period - (t % period)
+        x = F.pad(x, (0, n_pad), "reflect")
+        t += n_pad
+    x = x.view(b, c, t // period, period)
+    outs = []
+    for i, s in enumerate(downsample_scales):
+        p = f"{prefix}.convs.{i}.0"
+        x = F.leaky_relu(F.conv2d(x, get_weight_any(sd, p, training), get_bias(sd, p), stride=(s, 1),
+                                  padding=((kernel_sizes[0] - 1) // 2, 0)), slope)
+        outs.append(x)
+    p = f"{prefix}.output_conv"
+    x = F.conv2d(x, get_weight_any(sd, p, training), get_bias(sd, p), stride=1,
+                 padding=((kernel_sizes[1] - 1) // 2, 0))
+    outs.append(torch.flatten(x, 1, -1))
+    return outs
+
+
+def hifigan_scale_discriminator(sd, prefix, x, kernel_sizes=(15, 41, 5, 3), channels=128,
+                                max_downsample_channels=1024, max_groups=16, downsample_scales=(2, 2, 4, 4, 1),
+                                slope=0.1, training=False):
+    """``HiFiGANScaleDiscriminator.forward`` models/hifigan.py:586-601 (layer list :501-568)."""
+    outs = []
+    p = f"{prefix}.layers.0.0"
+    x = F.leaky_relu(F.conv1d(x, get_weight_any(sd, p, training), get_bias(sd, p),
+                              padding=(kernel_sizes[0] - 1) // 2), slope)
+    outs.append(x)
+    groups = 4
+    n = 1
+    for s in downsample_scales:
+        p = f"{prefix}.layers.{n}.0"
+        x = F.leaky_relu(F.conv1d(x, get_weight_any(sd, p, training), get_bias(sd, p), stride=s,
+                                  padding=(kernel_sizes[1] - 1) // 2, groups=groups), slope)
+        outs.append(x)
+        groups = min(groups * 4, max_groups)
+        n += 1
+    p = f"{prefix}.layers.{n}.0"
+    x = F.leaky_relu(F.conv1d(x, get_weight_any(sd, p, training), get_bias(sd, p),
+                              padding=(kernel_sizes[2] - 1) // 2), slope)
+    outs.append(x)
+    p = f"{prefix}.layers.{n + 1}"
+    x = F.conv1d(x, get_weight_any(sd, p, training), get_bias(sd, p), padding=(kernel_sizes[3] - 1) // 2)
+    outs.append(x)
+    return outs
+
+
+def hifigan_msmpd(sd, x, scales=3, scale_downsample_pooling_params=None, scale_discriminator_params=None,
+                  periods=(2, 3, 5, 7, 11), period_discriminator_params=None, training=False, **_unused):
+    """``HiFiGANMultiScaleMultiPeriodDiscriminator.forward`` models/hifigan.py:850-864."""
+    pp = scale_downsample_pooling_params or {"kernel_size": 4, "stride": 2, "padding": 2}
+    sp = dict(scale_discriminator_params or {})
+    dp = dict(period_discriminator_params or {})
+    outs = []
+    xs = x
+    for i in range(scales):
+        outs.append(hifigan_scale_discriminator(
+            sd, f"msd.discriminators.{i}", xs, kernel_sizes=sp.get("kernel_sizes", (15, 41, 5, 3)),
+            channels=sp.get("channels", 128), max_downsample_channels=sp.get("max_downsample_channels", 1024),
+            max_groups=sp.get("max_groups", 16), downsample_scales=sp.get("downsample_scales", (2, 2, 4, 4, 1)),
+            slope=sp.get("nonlinear_activation_params", {}).get("negative_slope", 0.1), training=training))
+        xs = F.avg_pool1d(xs, pp["kernel_size"], pp["stride"], pp["padding"])
+    for i, period in enumerate(periods):
+        outs.append(hifigan_period_discriminator(
+            sd, f"mpd.discriminators.{i}", x, period, kernel_sizes=dp.get("kernel_sizes", (5, 3)),
+            downsample_scales=dp.get("downsample_scales", (3, 3, 3, 3, 1)),
+            slope=dp.get("nonlinear_activation_params", {}).get("negative_slope", 0.1), training=training))
+    return outs
+
+
+# ----------------------------------------------------------------------------
+# losses (losses/stft_loss.py, losses/mel_loss.py, adversarial_loss.py, feat_match_loss.py)
+# ----------------------------------------------------------------------------
+def stft_magnitude(x, fft_size, hop_size, win_length, eps=1e-7):
+    """``stft`` losses/stft_loss.py:16-40 -> (B, frames, bins)."""
+    window = torch.hann_window(win_length, dtype=x.dtype)
+    s = torch.stft(x, fft_size, hop_size, win_length, window, return_complex=True)
+    power = s.real ** 2 + s.imag ** 2
+    return torch.sqrt(torch.clamp(power, min=eps)).transpose(2, 1)
+
+
+def multi_resolution_stft_loss(x, y, fft_sizes=(1024, 2048, 512), hop_sizes=(120, 240, 50),
+                               win_lengths=(600, 1200, 240)):
+    """``MultiResolutionSTFTLoss.forward`` losses/stft_loss.py:146-170 (x predicted, y target)."""
+    if x.dim() == 3:
+        x = x.reshape(-1, x.size(2))
+        y = y.reshape(-1, y.size(2))
+    sc, mag = 0.0, 0.0
+    for n_fft, hop, win in zip(fft_sizes, hop_sizes, win_lengths):
+        xm = stft_magnitude(x, n_fft, hop, win)
+        ym = stft_magnitude(y, n_fft, hop, win)
+        sc = sc + torch.norm(ym - xm, p="fro") / torch.norm(ym, p="fro")
+        mag = mag + F.l1_loss(torch.log(ym), torch.log(xm))
+    return sc / len(fft_sizes), mag / len(fft_sizes)
+
+
+def mel_spectrogram(x, fs=22050, fft_size=1024, hop_size=256, win_length=None, num_mels=80, fmin=80, fmax=7600,
+                    eps=1e-10, log_base=10.0):
+    """``MelSpectrogram.forward`` losses/mel_loss.py:81-110 -> (B, mels, frames)."""
+    from . import slaney_mel
+
+    if x.dim() == 3:
+        x = x.reshape(-1, x.size(2))
+    win_length = fft_size if win_length is None else win_length
+    fmin = 0 if fmin is None else fmin
+    fmax = fs / 2 if fmax is None else fmax
+    melmat = torch.from_numpy(slaney_mel.mel(fs, fft_size, num_mels, fmin, fmax).T).float()
+    amp = stft_magnitude(x, fft_size, hop_size, win_length, eps=eps)  # (B, frames, bins)
+    mel = torch.clamp(torch.matmul(amp, melmat), min=eps)
+    log = {None: torch.log, 2.0: torch.log2, 10.0: torch.log10}[log_base]
+    return log(mel).transpose(1, 2)
+
+
+def mel_spectrogram_loss(y_hat, y, **params):
+    """``MelSpectrogramLoss.forward`` losses/mel_loss.py:150-165."""
+    return F.l1_loss(mel_spectrogram(y_hat, **params), mel_spectrogram(y, **params))
+
+
+def generator_adversarial_loss(outputs, average_by_discriminators=True):
+    """``GeneratorAdversarialLoss.forward`` (mse) losses/adversarial_loss.py:29-58."""
+    loss = 0.0
+    for i, o in enumerate(outputs):
+        o = o[-1] if isinstance(o, (list, tuple)) else o
+        loss = loss + F.mse_loss(o, torch.ones_like(o))
+    return loss / (i + 1) if average_by_discriminators else loss
+
+
+def discriminator_adversarial_loss(outputs_hat, outputs, average_by_discriminators=True):
+    """``DiscriminatorAdversarialLoss.forward`` (mse) losses/adversarial_loss.py:80-123."""
+    real, fake = 0.0, 0.0
+    for i, (oh, o) in enumerate(zip(outputs_hat, outputs)):
+        if isinstance(oh, (list, tuple)):
+            oh, o = oh[-1], o[-1]
+        real = real + F.mse_loss(o, torch.ones_like(o))
+        fake = fake + F.mse_loss(oh, torch.zeros_like(oh))
+    if average_by_discriminators:
+        real, fake = real / (i + 1), fake / (i + 1)
+    return real, fake
+
+
+def feature_match_loss(feats_hat, feats, average_by_layers=True, average_by_discriminators=True,
+                       include_final_outputs=False):
+    """``FeatureMatchLoss.forward`` losses/feat_match_loss.py:27-54."""
+    total = 0.0
+    for i, (fh, f) in enumerate(zip(feats_hat, feats)):
+        if not include_final_outputs:
+            fh, f = fh[:-1], f[:-1]
+        part = 0.0
+        for j, (a, b) in enumerate(zip(fh, f)):
+            part = part + F.l1_loss(a, b.detach())
+        if average_by_layers:
+            part = part / (j + 1)
+        total = total + part
+    return total / (i + 1) if average_by_discriminators else total

@@ -43,6 +43,8 @@ class ConvDesc(ctypes.Structure):
 _lib = None
 _vp = ctypes.c_void_p
 _i32 = ctypes.c_int32
+_i64 = ctypes.c_int64
+_f32 = ctypes.c_float
 
 # name -> (restype, argtypes); every symbol include/pwg_kernels.h declares
 SIGNATURES = {
@@ -64,6 +66,25 @@ SIGNATURES = {
     "pwg_conv1d_backward_weight": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
     "pwg_conv1d_num_tile_configs": (ctypes.c_int, []),
     "pwg_conv1d_forward_cfg": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "pwg_act_backward": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _f32, _vp]),
+    "pwg_weight_norm_backward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "pwg_spectral_norm_forward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
+    "pwg_spectral_norm_backward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "pwg_avg_pool1d_forward": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "pwg_avg_pool1d_backward": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "pwg_pad1d_forward": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "pwg_pad1d_backward": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "pwg_frame_fold_forward": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "pwg_frame_fold_backward": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "pwg_stft_mag_forward": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _vp]),
+    "pwg_stft_mag_backward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
+    "pwg_log_clamp_forward": (ctypes.c_int, [_vp, _vp, _i64, _f32, _f32, _vp]),
+    "pwg_log_clamp_backward": (ctypes.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _vp]),
+    "pwg_reduce_forward": (ctypes.c_int, [_vp, _vp, _f32, _i64, _i32, _f32, _vp, _vp, _vp]),
+    "pwg_reduce_backward": (ctypes.c_int, [_vp, _vp, _f32, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
+    "pwg_adam_step": (ctypes.c_int, [_vp, _i32, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
+    "pwg_radam_step": (ctypes.c_int, [_vp, _i32, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
+    "pwg_clip_grad_norm": (ctypes.c_int, [_vp, _i32, _f32, _vp, _vp, _vp]),
     "pwg_weight_norm_scale": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "pwg_scale_rows": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
 }

@@ -1,0 +1,346 @@
+"""Training runtime (drop-in surface of ``parallel_wavegan.bin.train``: ``Trainer``, ``Collater``).
+
+``Trainer`` keeps the reference's constructor, ``run`` / ``save_checkpoint`` / ``load_checkpoint``
+and checkpoint layout (/root/reference/parallel_wavegan/bin/train.py:49-187) and the loss
+composition of ``_train_step`` (:189-340).  What differs is how a step is executed on an MI355X:
+
+* every convolution, loss, reparametrisation and optimizer update is a HIP kernel from
+  libpwgkernels.so (see parallelwavegan_amd.functional / optimizers.fused);
+* loss scalars are kept on the device and fetched once per logging interval, instead of the
+  reference's 7-9 ``.item()`` host syncs per step;
+* during the generator phase the discriminator's parameters do not require grad, so its
+  weight-gradient kernels (whose results the reference computes and then discards at :327)
+  are never launched;
+* data parallelism: ``distributed.GradReducer`` (bucketed RCCL all-reduce overlapped with the
+  backward pass) instead of apex DDP.
+"""
+import logging
+import os
+from collections import defaultdict
+
+import torch
+
+from ..distributed import GradReducer
+from ..optimizers import clip_grad_norm_
+
+
+class _NullWriter:
+    def add_scalar(self, *a, **k):
+        pass
+
+    def close(self):
+        pass
+
+
+def _summary_writer(outdir):
+    try:
+        from tensorboardX import SummaryWriter
+
+        return SummaryWriter(outdir)
+    except Exception:  # tensorboardX is optional
+        return _NullWriter()
+
+
+class Trainer(object):
+    """Customized trainer for GAN vocoders on MI355X."""
+
+    def __init__(self, steps, epochs, data_loader, sampler, model, criterion, optimizer, scheduler, config,
+                 device=torch.device("cpu")):
+        self.steps = steps
+        self.epochs = epochs
+        self.data_loader = data_loader
+        self.sampler = sampler
+        self.model = model
+        self.criterion = criterion
+        self.optimizer = optimizer
+        self.scheduler = scheduler
+        self.config = config
+        self.device = device
+        self.writer = _summary_writer(config["outdir"]) if config.get("rank", 0) == 0 else _NullWriter()
+        self.finish_train = False
+        self.total_train_loss = defaultdict(float)
+        self.total_eval_loss = defaultdict(float)
+        gtype = config.get("generator_type", "ParallelWaveGANGenerator")
+        if "VQVAE" in gtype or "Duration" in gtype:
+            raise NotImplementedError(f"{gtype} is outside the accelerated hot path (SURVEY.md s2)")
+        self._pending = []  # (name, device scalar) of the current logging interval
+        self.reducers = None
+        if config.get("distributed", False):
+            self.reducers = {k: GradReducer(list(self._module(k).parameters())) for k in ("generator", "discriminator")}
+            for k, r in self.reducers.items():
+                m = self._module(k)
+                r.broadcast_parameters(list(m.parameters()) + list(m.buffers()))
+
+    # ------------------------------------------------------------------ plumbing
+    def _module(self, key):
+        m = self.model[key]
+        return m.module if hasattr(m, "module") else m
+
+    def run(self):
+        try:
+            from tqdm import tqdm
+
+            self.tqdm = tqdm(initial=self.steps, total=self.config["train_max_steps"], desc="[train]",
+                             disable=self.config.get("rank", 0) != 0 or not self.config.get("progress", True))
+        except Exception:
+            self.tqdm = None
+        while True:
+            self._train_epoch()
+            if self.finish_train:
+                break
+        if self.tqdm is not None:
+            self.tqdm.close()
+        logging.info("Finished training.")
+
+    def save_checkpoint(self, checkpoint_path):
+        state_dict = {
+            "optimizer": {k: self.optimizer[k].state_dict() for k in ("generator", "discriminator")},
+            "scheduler": {k: self.scheduler[k].state_dict() for k in ("generator", "discriminator")},
+            "steps": self.steps,
+            "epochs": self.epochs,
+            "model": {k: self._module(k).state_dict() for k in ("generator", "discriminator")},
+        }
+        d = os.path.dirname(checkpoint_path)
+        if d and not os.path.exists(d):
+            os.makedirs(d)
+        torch.save(state_dict, checkpoint_path)
+
+    def load_checkpoint(self, checkpoint_path, load_only_params=False):
+        state_dict = torch.load(checkpoint_path, map_location="cpu")
+        self._module("generator").load_state_dict(state_dict["model"]["generator"])
+        self._module("discriminator").load_state_dict(state_dict["model"]["discriminator"], strict=False)
+        if not load_only_params:
+            self.steps = state_dict["steps"]
+            self.epochs = state_dict["epochs"]
+            for k in ("generator", "discriminator"):
+                self.optimizer[k].load_state_dict(state_dict["optimizer"][k])
+                self.scheduler[k].load_state_dict(state_dict["scheduler"][k])
+
+    def _log(self, name, value):
+        """Record a loss scalar without synchronising the host."""
+        self._pending.append((name, value.detach()))
+
+    def _flush_pending(self):
+        if not self._pending:
+            return
+        names = [n for n, _ in self._pending]
+        vals = torch.stack([v.reshape(()) for _, v in self._pending]).cpu().tolist()  # ONE D2H copy
+        for n, v in zip(names, vals):
+            self.total_train_loss[n] += v
+        self._pending = []
+
+    # ------------------------------------------------------------------ one optimisation step
+    def _generator_forward(self, x):
+        y_ = self.model["generator"](*x)
+        y_mb_ = None
+        if self.config["generator_params"]["out_channels"] > 1:
+            y_mb_ = y_
+            y_ = self.criterion["pqmf"].synthesis(y_mb_)
+        return y_, y_mb_
+
+    def _step_optimizer(self, key, loss):
+        cfg = self.config
+        opt = self.optimizer[key]
+        params = list(self._module(key).parameters())
+        for p in params:
+            p.grad = None
+        reducer = self.reducers[key] if self.reducers else None
+        if reducer is not None:
+            reducer.prepare()
+        loss.backward()
+        if reducer is not None:
+            opt.grad_scale = reducer.finish()
+            opt.flat_grads = reducer.flat_grads
+            pairs = [(p, reducer.flat_grads[p]) for p in params]
+        else:
+            opt.grad_scale = 1.0
+            opt.flat_grads = None
+            pairs = [(p, p.grad) for p in params if p.grad is not None]
+        max_norm = cfg.get(f"{key}_grad_norm", -1)
+        if max_norm > 0:
+            if reducer is not None and reducer.world > 1:
+                for _, g in pairs:  # clip on the averaged gradient, as the reference does after DDP
+                    g.mul_(opt.grad_scale)
+                opt.grad_scale = 1.0
+            clip_grad_norm_(pairs, max_norm)
+        opt.step()
+        self.scheduler[key].step()
+
+    def _train_step(self, batch):
+        cfg = self.config
+        x, y = self._parse_batch(batch)
+        disc_on = self.steps > cfg["discriminator_train_start_steps"]
+
+        # ---------------- generator ----------------
+        if self.steps > cfg.get("generator_train_start_steps", 0):
+            y_, y_mb_ = self._generator_forward(x)
+            gen_loss = 0.0
+            if cfg["use_stft_loss"]:
+                sc_loss, mag_loss = self.criterion["stft"](y_, y)
+                gen_loss = gen_loss + sc_loss + mag_loss
+                self._log("train/spectral_convergence_loss", sc_loss)
+                self._log("train/log_stft_magnitude_loss", mag_loss)
+            if cfg.get("use_subband_stft_loss", False):
+                gen_loss = gen_loss * 0.5  # balance with the sub-band term (train.py:242-247)
+                y_mb = self.criterion["pqmf"].analysis(y)
+                sub_sc_loss, sub_mag_loss = self.criterion["sub_stft"](y_mb_, y_mb)
+                gen_loss = gen_loss + 0.5 * (sub_sc_loss + sub_mag_loss)
+                self._log("train/sub_spectral_convergence_loss", sub_sc_loss)
+                self._log("train/sub_log_stft_magnitude_loss", sub_mag_loss)
+            if cfg.get("use_mel_loss", False):
+                mel_loss = self.criterion["mel"](y_, y)
+                gen_loss = gen_loss + mel_loss
+                self._log("train/mel_loss", mel_loss)
+            gen_loss = gen_loss * cfg.get("lambda_aux", 1.0)
+            if disc_on:
+                # D acts as a fixed critic here: no D weight gradients (they would be discarded)
+                d_params = list(self._module("discriminator").parameters())
+                for p in d_params:
+                    p.requires_grad_(False)
+                p_ = self.model["discriminator"](y_)
+                adv_loss = self.criterion["gen_adv"](p_)
+                self._log("train/adversarial_loss", adv_loss)
+                if cfg.get("use_feat_match_loss", False):
+                    with torch.no_grad():
+                        p = self.model["discriminator"](y)
+                    fm_loss = self.criterion["feat_match"](p_, p)
+                    self._log("train/feature_matching_loss", fm_loss)
+                    adv_loss = adv_loss + cfg["lambda_feat_match"] * fm_loss
+                gen_loss = gen_loss + cfg["lambda_adv"] * adv_loss
+                for p in d_params:
+                    p.requires_grad_(True)
+            self._log("train/generator_loss", gen_loss)
+            self._step_optimizer("generator", gen_loss)
+
+        # ---------------- discriminator ----------------
+        if disc_on:
+            if cfg.get("update_prediction_after_generator_update", True):
+                with torch.no_grad():
+                    y_, _ = self._generator_forward(x)
+            p = self.model["discriminator"](y)
+            p_ = self.model["discriminator"](y_.detach())
+            real_loss, fake_loss = self.criterion["dis_adv"](p_, p)
+            dis_loss = real_loss + fake_loss
+            self._log("train/real_loss", real_loss)
+            self._log("train/fake_loss", fake_loss)
+            self._log("train/discriminator_loss", dis_loss)
+            self._step_optimizer("discriminator", dis_loss)
+
+        self.steps += 1
+        if getattr(self, "tqdm", None) is not None:
+            self.tqdm.update(1)
+        self._check_train_finish()
+
+    def _train_epoch(self):
+        for train_steps_per_epoch, batch in enumerate(self.data_loader["train"], 1):
+            self._train_step(batch)
+            if self.config.get("rank", 0) == 0:
+                self._check_log_interval()
+                self._check_eval_interval()
+                self._check_save_interval()
+            if self.finish_train:
+                return
+        self.epochs += 1
+        self.train_steps_per_epoch = train_steps_per_epoch
+        logging.info(f"(Steps: {self.steps}) Finished {self.epochs} epoch training "
+                     f"({self.train_steps_per_epoch} steps per epoch).")
+        if self.config.get("distributed", False) and self.sampler.get("train") is not None:
+            self.sampler["train"].set_epoch(self.epochs)
+
+    @torch.no_grad()
+    def _eval_step(self, batch):
+        cfg = self.config
+        x, y = self._parse_batch(batch)
+        y_, y_mb_ = self._generator_forward(x)
+        aux_loss = 0.0
+        if cfg["use_stft_loss"]:
+            sc_loss, mag_loss = self.criterion["stft"](y_, y)
+            aux_loss = aux_loss + sc_loss + mag_loss
+            self.total_eval_loss["eval/spectral_convergence_loss"] += sc_loss.item()
+            self.total_eval_loss["eval/log_stft_magnitude_loss"] += mag_loss.item()
+        if cfg.get("use_subband_stft_loss", False):
+            aux_loss = aux_loss * 0.5
+            y_mb = self.criterion["pqmf"].analysis(y)
+            sub_sc_loss, sub_mag_loss = self.criterion["sub_stft"](y_mb_, y_mb)
+            aux_loss = aux_loss + 0.5 * (sub_sc_loss + sub_mag_loss)
+        if cfg.get("use_mel_loss", False):
+            mel_loss = self.criterion["mel"](y_, y)
+            aux_loss = aux_loss + mel_loss
+            self.total_eval_loss["eval/mel_loss"] += mel_loss.item()
+        aux_loss = aux_loss * cfg.get("lambda_aux", 1.0)
+        p_ = self.model["discriminator"](y_)
+        adv_loss = self.criterion["gen_adv"](p_)
+        gen_loss = aux_loss + cfg["lambda_adv"] * adv_loss
+        p = self.model["discriminator"](y)
+        if cfg.get("use_feat_match_loss", False):
+            fm_loss = self.criterion["feat_match"](p_, p)
+            self.total_eval_loss["eval/feature_matching_loss"] += fm_loss.item()
+            gen_loss = gen_loss + cfg["lambda_adv"] * cfg["lambda_feat_match"] * fm_loss
+        real_loss, fake_loss = self.criterion["dis_adv"](p_, p)
+        self.total_eval_loss["eval/adversarial_loss"] += adv_loss.item()
+        self.total_eval_loss["eval/generator_loss"] += float(gen_loss)
+        self.total_eval_loss["eval/real_loss"] += real_loss.item()
+        self.total_eval_loss["eval/fake_loss"] += fake_loss.item()
+        self.total_eval_loss["eval/discriminator_loss"] += (real_loss + fake_loss).item()
+
+    def _eval_epoch(self):
+        logging.info(f"(Steps: {self.steps}) Start evaluation.")
+        for key in self.model.keys():
+            self.model[key].eval()
+        n = 0
+        for n, batch in enumerate(self.data_loader["dev"], 1):
+            self._eval_step(batch)
+        for key in self.total_eval_loss.keys():
+            self.total_eval_loss[key] /= max(n, 1)
+            logging.info(f"(Steps: {self.steps}) {key} = {self.total_eval_loss[key]:.4f}.")
+        self._write_to_tensorboard(self.total_eval_loss)
+        self.total_eval_loss = defaultdict(float)
+        for key in self.model.keys():
+            self.model[key].train()
+
+    @torch.no_grad()
+    def _parse_batch(self, batch):
+        inputs, targets = batch
+
+        def dev(t):
+            return None if t is None else t.to(self.device, non_blocking=True)
+
+        if isinstance(inputs, torch.Tensor):
+            x = [dev(inputs)]
+        elif isinstance(inputs, (tuple, list)):
+            x = [dev(t) for t in inputs]
+        else:
+            raise ValueError(f"Not supported type ({type(inputs)}).")
+        if isinstance(targets, torch.Tensor):
+            y = dev(targets)
+        elif isinstance(targets, (tuple, list)):
+            y = [dev(t) for t in targets]
+        else:
+            raise ValueError(f"Not supported type ({type(targets)}).")
+        return x, y
+
+    def _write_to_tensorboard(self, loss):
+        for key, value in loss.items():
+            self.writer.add_scalar(key, value, self.steps)
+
+    def _check_save_interval(self):
+        if self.steps % self.config["save_interval_steps"] == 0:
+            self.save_checkpoint(os.path.join(self.config["outdir"], f"checkpoint-{self.steps}steps.pkl"))
+            logging.info(f"Successfully saved checkpoint @ {self.steps} steps.")
+
+    def _check_eval_interval(self):
+        if self.steps % self.config["eval_interval_steps"] == 0:
+            self._eval_epoch()
+
+    def _check_log_interval(self):
+        if self.steps % self.config["log_interval_steps"] == 0:
+            self._flush_pending()
+            for key in self.total_train_loss.keys():
+                self.total_train_loss[key] /= self.config["log_interval_steps"]
+                logging.info(f"(Steps: {self.steps}) {key} = {self.total_train_loss[key]:.4f}.")
+            self._write_to_tensorboard(self.total_train_loss)
+            self.total_train_loss = defaultdict(float)
+
+    def _check_train_finish(self):
+        if self.steps >= self.config["train_max_steps"]:
+            self.finish_train = True

@@ -1,0 +1,474 @@
+// elementwise.hip -- HBM-bound helper kernels around the convolutions: activation backward,
+// weight/spectral-norm reparametrisation (forward pieces are in conv1d.hip), pooling, explicit
+// padding, STFT framing / magnitude / log.  All are single-pass, coalesced along time.
+#include "common.h"
+
+namespace pwg {
+
+static inline int grid_for(long n, int block = 256, int max_blocks = 4096) {
+  long b = (n + block - 1) / block;
+  if (b > max_blocks) b = max_blocks;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+#define GRID_STRIDE(i, n) \
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
+
+// dx = dy * act'(.) * scale, with act' expressed through the activation OUTPUT y
+//   tanh: 1 - y^2;  leaky_relu (slope > 0): y > 0 ? 1 : slope;  relu: y > 0;  none: 1
+__global__ void act_backward_kernel(const float* dy, const float* y, float* dx, long n, int act, float slope,
+                                    float scale) {
+  GRID_STRIDE(i, n) {
+    float g = dy[i] * scale;
+    if (act == PWG_ACT_TANH) {
+      const float t = y[i];
+      g *= (1.f - t * t);
+    } else if (act == PWG_ACT_LEAKY_RELU) {
+      g *= (y[i] > 0.f ? 1.f : slope);
+    } else if (act == PWG_ACT_RELU) {
+      g *= (y[i] > 0.f ? 1.f : 0.f);
+    }
+    dx[i] = g;
+  }
+}
+
+__device__ __forceinline__ float block_sum_256(float s, float* red) {
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float t = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  return t;
+}
+
+// old-style weight_norm (dim 0) backward; one workgroup per dim-0 slice:
+//   w = g v / |v|   =>   dg = <dw, v> / |v| ;  dv = (g/|v|) (dw - v <dw,v> / |v|^2)
+__global__ void weight_norm_backward_kernel(const float* dw, const float* v, const float* g, float* dv, float* dg,
+                                            int inner) {
+  __shared__ float red[4];
+  const long base = (long)blockIdx.x * inner;
+  float svv = 0.f, sdv = 0.f;
+  for (int i = threadIdx.x; i < inner; i += blockDim.x) {
+    const float a = v[base + i], b = dw[base + i];
+    svv += a * a;
+    sdv += a * b;
+  }
+  svv = block_sum_256(svv, red);
+  sdv = block_sum_256(sdv, red);
+  const float norm = sqrtf(svv);
+  const float gg = g[blockIdx.x];
+  if (threadIdx.x == 0) dg[blockIdx.x] = sdv / norm;
+  const float c1 = gg / norm, c2 = sdv / svv;
+  for (int i = threadIdx.x; i < inner; i += blockDim.x) dv[base + i] = c1 * (dw[base + i] - v[base + i] * c2);
+}
+
+// AvgPool1d over rows of length t_in
+__global__ void avg_pool1d_fwd_kernel(const float* x, float* y, long rows, int t_in, int t_out, int k, int s, int p,
+                                      int count_include_pad) {
+  const long n = rows * t_out;
+  GRID_STRIDE(i, n) {
+    const long r = i / t_out;
+    const int o = (int)(i - r * t_out);
+    const int start = o * s - p;
+    int lo = start < 0 ? 0 : start;
+    int hi = start + k > t_in ? t_in : start + k;
+    float acc = 0.f;
+    const float* xr = x + r * t_in;
+    for (int t = lo; t < hi; ++t) acc += xr[t];
+    // torch: with count_include_pad the divisor counts padded zeros but not positions past t_in + p
+    int div;
+    if (count_include_pad) {
+      int e = start + k;
+      if (e > t_in + p) e = t_in + p;
+      div = e - start;
+    } else {
+      div = hi - lo;
+    }
+    y[i] = acc / (float)div;
+  }
+}
+
+__global__ void avg_pool1d_bwd_kernel(const float* dy, float* dx, long rows, int t_in, int t_out, int k, int s, int p,
+                                      int count_include_pad) {
+  const long n = rows * t_in;
+  GRID_STRIDE(i, n) {
+    const long r = i / t_in;
+    const int t = (int)(i - r * t_in);
+    // outputs o with o*s - p <= t < o*s - p + k
+    int o_hi = (t + p) / s;
+    int o_lo = (t + p - k + s) / s;  // ceil((t + p - k + 1) / s)
+    if (t + p - k + 1 <= 0) o_lo = 0;
+    if (o_hi > t_out - 1) o_hi = t_out - 1;
+    float acc = 0.f;
+    const float* gr = dy + r * t_out;
+    for (int o = o_lo; o <= o_hi; ++o) {
+      const int start = o * s - p;
+      int div;
+      if (count_include_pad) {
+        int e = start + k;
+        if (e > t_in + p) e = t_in + p;
+        div = e - start;
+      } else {
+        const int lo = start < 0 ? 0 : start;
+        const int hi = start + k > t_in ? t_in : start + k;
+        div = hi - lo;
+      }
+      acc += gr[o] / (float)div;
+    }
+    dx[i] = acc;
+  }
+}
+
+__device__ __forceinline__ int pad_src(int j, int t_in, int mode) {  // j: index in the un-padded frame
+  if (j >= 0 && j < t_in) return j;
+  if (mode == PWG_PAD_REFLECT) return j < 0 ? -j : 2 * (t_in - 1) - j;
+  if (mode == PWG_PAD_REPLICATE) return j < 0 ? 0 : t_in - 1;
+  return -1;
+}
+
+// explicit padding: y[r][i] = x[r][src(i - pl)]
+__global__ void pad1d_fwd_kernel(const float* x, float* y, long rows, int t_in, int pl, int pr, int mode) {
+  const int t_out = t_in + pl + pr;
+  const long n = rows * t_out;
+  GRID_STRIDE(i, n) {
+    const long r = i / t_out;
+    const int o = (int)(i - r * t_out);
+    const int j = pad_src(o - pl, t_in, mode);
+    y[i] = j >= 0 ? x[r * t_in + j] : 0.f;
+  }
+}
+
+// dx[r][t] = dy[r][t + pl] + reflected / replicated contributions (gather form, no atomics)
+__global__ void pad1d_bwd_kernel(const float* dy, float* dx, long rows, int t_in, int pl, int pr, int mode) {
+  const int t_out = t_in + pl + pr;
+  const long n = rows * t_in;
+  GRID_STRIDE(i, n) {
+    const long r = i / t_in;
+    const int t = (int)(i - r * t_in);
+    const float* g = dy + r * t_out;
+    float acc = g[t + pl];
+    if (mode == PWG_PAD_REFLECT) {
+      if (t >= 1 && t <= pl) acc += g[pl - t];                                  // left mirror of x[t]
+      if (t <= t_in - 2 && t >= t_in - 1 - pr) acc += g[pl + 2 * (t_in - 1) - t];  // right mirror
+    } else if (mode == PWG_PAD_REPLICATE) {
+      if (t == 0)
+        for (int o = 0; o < pl; ++o) acc += g[o];
+      if (t == t_in - 1)
+        for (int o = 0; o < pr; ++o) acc += g[pl + t_in + o];
+    }
+    dx[i] = acc;
+  }
+}
+
+// STFT framing as a channel fold: y[b][c][n] = xr[b][n*hop + c - pad], c < hop, n < nn, where xr is x
+// extended by reflection (torch.stft center=True pads n_fft/2; a window shorter than n_fft just
+// shifts the frame start, which the caller folds into `pad`).  Indices further than one
+// reflection away from the signal read 0 (they only meet zero filter taps).
+__global__ void frame_fold_fwd_kernel(const float* x, float* y, int batch, int t, int pad, int hop, int nn) {
+  const long n = (long)batch * hop * nn;
+  GRID_STRIDE(i, n) {
+    long r = i / nn;
+    const int col = (int)(i - r * nn);
+    const int c = (int)(r % hop);
+    const int b = (int)(r / hop);
+    const int j = col * hop + c - pad;  // index in the un-padded signal
+    float v = 0.f;
+    if (j > -t && j < 2 * t - 1) v = x[(long)b * t + pad_src(j, t, PWG_PAD_REFLECT)];
+    y[i] = v;
+  }
+}
+
+__global__ void frame_fold_bwd_kernel(const float* dy, float* dx, int batch, int t, int pad, int hop, int nn) {
+  const long n = (long)batch * t;
+  GRID_STRIDE(i, n) {
+    const int b = (int)(i / t);
+    const int tt = (int)(i - (long)b * t);
+    const float* g = dy + (long)b * hop * nn;
+    float acc = 0.f;
+    // folded positions p = j + pad whose source is x[tt]: j = tt, j = -tt (tt >= 1), j = 2(t-1) - tt (tt <= t-2)
+    int js[3];
+    int np = 0;
+    js[np++] = tt;
+    if (tt >= 1) js[np++] = -tt;
+    if (tt <= t - 2) js[np++] = 2 * (t - 1) - tt;
+    for (int q = 0; q < np; ++q) {
+      const int p = js[q] + pad;
+      if (p < 0) continue;
+      const int col = p / hop, c = p - col * hop;
+      if (col < nn) acc += g[(long)c * nn + col];
+    }
+    dx[i] = acc;
+  }
+}
+
+// spec: (B, 2*bins, frames) with rows [0,bins) = real, [bins, 2 bins) = imaginary
+// mag = sqrt(max(re^2 + im^2, eps))      (losses/stft_loss.py:36-40, losses/mel_loss.py:101-104)
+__global__ void stft_mag_fwd_kernel(const float* spec, float* mag, int batch, int bins, int frames, float eps) {
+  const long n = (long)batch * bins * frames;
+  const long plane = (long)bins * frames;
+  GRID_STRIDE(i, n) {
+    const long b = i / plane;
+    const long r = i - b * plane;
+    const float re = spec[b * 2 * plane + r], im = spec[b * 2 * plane + plane + r];
+    const float p = re * re + im * im;
+    mag[i] = sqrtf(p > eps ? p : eps);
+  }
+}
+
+__global__ void stft_mag_bwd_kernel(const float* spec, const float* mag, const float* dmag, float* dspec, int batch,
+                                    int bins, int frames, float eps) {
+  const long n = (long)batch * bins * frames;
+  const long plane = (long)bins * frames;
+  GRID_STRIDE(i, n) {
+    const long b = i / plane;
+    const long r = i - b * plane;
+    const float re = spec[b * 2 * plane + r], im = spec[b * 2 * plane + plane + r];
+    const float p = re * re + im * im;
+    float gr = 0.f, gi = 0.f;
+    if (p > eps) {  // clamp passes no gradient below the floor
+      const float s = dmag[i] / mag[i];
+      gr = s * re;
+      gi = s * im;
+    }
+    dspec[b * 2 * plane + r] = gr;
+    dspec[b * 2 * plane + plane + r] = gi;
+  }
+}
+
+// y = log(max(x, eps)) / log_div     (log_div = 1, ln 2 or ln 10)
+__global__ void log_clamp_fwd_kernel(const float* x, float* y, long n, float eps, float log_div) {
+  GRID_STRIDE(i, n) {
+    const float v = x[i] > eps ? x[i] : eps;
+    y[i] = logf(v) / log_div;
+  }
+}
+
+__global__ void log_clamp_bwd_kernel(const float* x, const float* dy, float* dx, long n, float eps, float log_div) {
+  GRID_STRIDE(i, n) { dx[i] = x[i] > eps ? dy[i] / (x[i] * log_div) : 0.f; }
+}
+
+// ---- spectral norm (torch.nn.utils.spectral_norm, dim 0, 1 power iteration) --------------
+// t[c] = sum_r W[r][c] u[r]        (coalesced over columns)
+__global__ void matvec_t_kernel(const float* w, const float* u, float* t, int rows, int cols) {
+  GRID_STRIDE(c, cols) {
+    float acc = 0.f;
+    for (int r = 0; r < rows; ++r) acc += w[(long)r * cols + c] * u[r];
+    t[c] = acc;
+  }
+}
+// s[r] = sum_c W[r][c] v[c]        (one workgroup per row)
+__global__ void matvec_kernel(const float* w, const float* v, float* s, int cols) {
+  __shared__ float red[4];
+  const long base = (long)blockIdx.x * cols;
+  float acc = 0.f;
+  for (int c = threadIdx.x; c < cols; c += blockDim.x) acc += w[base + c] * v[c];
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0) s[blockIdx.x] = acc;
+}
+// out = in / max(|in|, eps)   and optionally dot = <a, b>   (single workgroup)
+__global__ void normalize_kernel(const float* in, float* out, int n, float eps) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += in[i] * in[i];
+  s = block_sum_256(s, red);
+  const float d = fmaxf(sqrtf(s), eps);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = in[i] / d;
+}
+__global__ void dot_kernel(const float* a, const float* b, float* out, int n) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += a[i] * b[i];
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) out[0] = s;
+}
+// dW_orig = dW / sigma - (<dW, W_orig> / sigma^2) u v^T ; dot2[0] must hold <dW, W_orig>
+__global__ void spectral_norm_bwd_kernel(const float* dw, const float* u, const float* v, const float* sigma,
+                                         const float* dot_dw_w, float* dwo, int rows, int cols) {
+  const long n = (long)rows * cols;
+  const float sg = sigma[0];
+  const float coef = dot_dw_w[0] / (sg * sg);
+  GRID_STRIDE(i, n) {
+    const int r = (int)(i / cols);
+    const int c = (int)(i - (long)r * cols);
+    dwo[i] = dw[i] / sg - coef * u[r] * v[c];
+  }
+}
+__global__ void dot_big_kernel(const float* a, const float* b, float* out, long n) {  // atomics; out pre-zeroed
+  __shared__ float red[4];
+  float s = 0.f;
+  GRID_STRIDE(i, n) s += a[i] * b[i];
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) atomicAdd(out, s);
+}
+// w = w_orig / sigma
+__global__ void div_scalar_kernel(const float* x, const float* s, float* y, long n) {
+  const float d = s[0];
+  GRID_STRIDE(i, n) y[i] = x[i] / d;
+}
+
+}  // namespace pwg
+
+using namespace pwg;
+
+#define LAUNCH1D(kern, n, stream, ...)                                                         \
+  do {                                                                                         \
+    hipLaunchKernelGGL(kern, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)(stream), __VA_ARGS__); \
+    PWG_CHECK_LAUNCH(#kern);                                                                   \
+  } while (0)
+
+extern "C" int pwg_act_backward(const float* dy, const float* y, float* dx, int64_t n, int32_t act, float slope,
+                                float scale, void* stream) {
+  PWG_REQUIRE(dy && dx && (y || act == PWG_ACT_NONE), PWG_ERR_NULL, "act_backward: NULL pointer");
+  PWG_REQUIRE(n > 0, PWG_ERR_BAD_SHAPE, "act_backward: n must be positive");
+  ProfScope prof((hipStream_t)stream, "act_backward_kernel", 0, 12.0 * n);
+  LAUNCH1D(act_backward_kernel, n, stream, dy, y, dx, (long)n, act, slope, scale);
+  return PWG_OK;
+}
+
+extern "C" int pwg_weight_norm_backward(const float* dw, const float* v, const float* g, float* dv, float* dg,
+                                        int32_t n0, int32_t inner, void* stream) {
+  PWG_REQUIRE(dw && v && g && dv && dg, PWG_ERR_NULL, "weight_norm_backward: NULL pointer");
+  PWG_REQUIRE(n0 > 0 && inner > 0, PWG_ERR_BAD_SHAPE, "weight_norm_backward: bad shape");
+  ProfScope prof((hipStream_t)stream, "weight_norm_backward_kernel", 0, 16.0 * n0 * inner);
+  hipLaunchKernelGGL(weight_norm_backward_kernel, dim3(n0), dim3(256), 0, (hipStream_t)stream, dw, v, g, dv, dg, inner);
+  PWG_CHECK_LAUNCH("weight_norm_backward");
+  return PWG_OK;
+}
+
+extern "C" int pwg_avg_pool1d_forward(const float* x, float* y, int64_t rows, int32_t t_in, int32_t t_out,
+                                      int32_t kernel, int32_t stride, int32_t pad, int32_t count_include_pad,
+                                      void* stream) {
+  PWG_REQUIRE(x && y, PWG_ERR_NULL, "avg_pool1d_forward: NULL pointer");
+  PWG_REQUIRE(rows > 0 && t_in > 0 && t_out > 0 && kernel > 0 && stride > 0 && pad >= 0 && 2 * pad <= kernel,
+              PWG_ERR_BAD_SHAPE, "avg_pool1d: bad geometry");
+  const long n = rows * t_out;
+  ProfScope prof((hipStream_t)stream, "avg_pool1d_fwd_kernel", 0, 4.0 * rows * (t_in + t_out));
+  LAUNCH1D(avg_pool1d_fwd_kernel, n, stream, x, y, (long)rows, t_in, t_out, kernel, stride, pad, count_include_pad);
+  return PWG_OK;
+}
+
+extern "C" int pwg_avg_pool1d_backward(const float* dy, float* dx, int64_t rows, int32_t t_in, int32_t t_out,
+                                       int32_t kernel, int32_t stride, int32_t pad, int32_t count_include_pad,
+                                       void* stream) {
+  PWG_REQUIRE(dy && dx, PWG_ERR_NULL, "avg_pool1d_backward: NULL pointer");
+  PWG_REQUIRE(rows > 0 && t_in > 0 && t_out > 0 && kernel > 0 && stride > 0 && pad >= 0, PWG_ERR_BAD_SHAPE,
+              "avg_pool1d: bad geometry");
+  const long n = rows * t_in;
+  ProfScope prof((hipStream_t)stream, "avg_pool1d_bwd_kernel", 0, 4.0 * rows * (t_in + t_out));
+  LAUNCH1D(avg_pool1d_bwd_kernel, n, stream, dy, dx, (long)rows, t_in, t_out, kernel, stride, pad, count_include_pad);
+  return PWG_OK;
+}
+
+extern "C" int pwg_pad1d_forward(const float* x, float* y, int64_t rows, int32_t t_in, int32_t pad_left,
+                                 int32_t pad_right, int32_t mode, void* stream) {
+  PWG_REQUIRE(x && y, PWG_ERR_NULL, "pad1d_forward: NULL pointer");
+  PWG_REQUIRE(rows > 0 && t_in > 0 && pad_left >= 0 && pad_right >= 0, PWG_ERR_BAD_SHAPE, "pad1d: bad geometry");
+  PWG_REQUIRE(mode != PWG_PAD_REFLECT || (pad_left < t_in && pad_right < t_in), PWG_ERR_BAD_SHAPE,
+              "pad1d: reflect padding (%d,%d) must be smaller than the input length %d", pad_left, pad_right, t_in);
+  const long n = rows * (t_in + pad_left + pad_right);
+  LAUNCH1D(pad1d_fwd_kernel, n, stream, x, y, (long)rows, t_in, pad_left, pad_right, mode);
+  return PWG_OK;
+}
+
+extern "C" int pwg_pad1d_backward(const float* dy, float* dx, int64_t rows, int32_t t_in, int32_t pad_left,
+                                  int32_t pad_right, int32_t mode, void* stream) {
+  PWG_REQUIRE(dy && dx, PWG_ERR_NULL, "pad1d_backward: NULL pointer");
+  PWG_REQUIRE(rows > 0 && t_in > 0 && pad_left >= 0 && pad_right >= 0, PWG_ERR_BAD_SHAPE, "pad1d: bad geometry");
+  const long n = rows * t_in;
+  LAUNCH1D(pad1d_bwd_kernel, n, stream, dy, dx, (long)rows, t_in, pad_left, pad_right, mode);
+  return PWG_OK;
+}
+
+extern "C" int pwg_frame_fold_forward(const float* x, float* y, int32_t batch, int32_t t, int32_t pad, int32_t hop,
+                                      int32_t n_cols, void* stream) {
+  PWG_REQUIRE(x && y, PWG_ERR_NULL, "frame_fold_forward: NULL pointer");
+  PWG_REQUIRE(batch > 0 && t > pad && pad >= 0 && hop > 0 && n_cols > 0, PWG_ERR_BAD_SHAPE,
+              "frame_fold: bad geometry (T=%d pad=%d hop=%d)", t, pad, hop);
+  const long n = (long)batch * hop * n_cols;
+  ProfScope prof((hipStream_t)stream, "frame_fold_fwd_kernel", 0, 4.0 * ((double)batch * t + n));
+  LAUNCH1D(frame_fold_fwd_kernel, n, stream, x, y, batch, t, pad, hop, n_cols);
+  return PWG_OK;
+}
+
+extern "C" int pwg_frame_fold_backward(const float* dy, float* dx, int32_t batch, int32_t t, int32_t pad,
+                                       int32_t hop, int32_t n_cols, void* stream) {
+  PWG_REQUIRE(dy && dx, PWG_ERR_NULL, "frame_fold_backward: NULL pointer");
+  PWG_REQUIRE(batch > 0 && t > pad && pad >= 0 && hop > 0 && n_cols > 0, PWG_ERR_BAD_SHAPE, "frame_fold: bad geometry");
+  const long n = (long)batch * t;
+  LAUNCH1D(frame_fold_bwd_kernel, n, stream, dy, dx, batch, t, pad, hop, n_cols);
+  return PWG_OK;
+}
+
+extern "C" int pwg_stft_mag_forward(const float* spec, float* mag, int32_t batch, int32_t bins, int32_t frames,
+                                    float eps, void* stream) {
+  PWG_REQUIRE(spec && mag, PWG_ERR_NULL, "stft_mag_forward: NULL pointer");
+  PWG_REQUIRE(batch > 0 && bins > 0 && frames > 0, PWG_ERR_BAD_SHAPE, "stft_mag: bad shape");
+  const long n = (long)batch * bins * frames;
+  ProfScope prof((hipStream_t)stream, "stft_mag_fwd_kernel", 0, 12.0 * n);
+  LAUNCH1D(stft_mag_fwd_kernel, n, stream, spec, mag, batch, bins, frames, eps);
+  return PWG_OK;
+}
+
+extern "C" int pwg_stft_mag_backward(const float* spec, const float* mag, const float* dmag, float* dspec,
+                                     int32_t batch, int32_t bins, int32_t frames, float eps, void* stream) {
+  PWG_REQUIRE(spec && mag && dmag && dspec, PWG_ERR_NULL, "stft_mag_backward: NULL pointer");
+  PWG_REQUIRE(batch > 0 && bins > 0 && frames > 0, PWG_ERR_BAD_SHAPE, "stft_mag: bad shape");
+  const long n = (long)batch * bins * frames;
+  LAUNCH1D(stft_mag_bwd_kernel, n, stream, spec, mag, dmag, dspec, batch, bins, frames, eps);
+  return PWG_OK;
+}
+
+extern "C" int pwg_log_clamp_forward(const float* x, float* y, int64_t n, float eps, float log_div, void* stream) {
+  PWG_REQUIRE(x && y, PWG_ERR_NULL, "log_clamp_forward: NULL pointer");
+  PWG_REQUIRE(n > 0 && log_div > 0.f, PWG_ERR_BAD_SHAPE, "log_clamp: bad arguments");
+  LAUNCH1D(log_clamp_fwd_kernel, n, stream, x, y, (long)n, eps, log_div);
+  return PWG_OK;
+}
+
+extern "C" int pwg_log_clamp_backward(const float* x, const float* dy, float* dx, int64_t n, float eps, float log_div,
+                                      void* stream) {
+  PWG_REQUIRE(x && dy && dx, PWG_ERR_NULL, "log_clamp_backward: NULL pointer");
+  PWG_REQUIRE(n > 0 && log_div > 0.f, PWG_ERR_BAD_SHAPE, "log_clamp: bad arguments");
+  LAUNCH1D(log_clamp_bwd_kernel, n, stream, x, dy, dx, (long)n, eps, log_div);
+  return PWG_OK;
+}
+
+// u (rows), v (cols) are updated in place when do_iter != 0 (training-mode forward of
+// torch.nn.utils.spectral_norm: models/hifigan.py:613-621); sigma[0] = u^T W v; w = w_orig / sigma.
+// tmp: workspace of max(rows, cols) floats.
+extern "C" int pwg_spectral_norm_forward(const float* w_orig, float* u, float* v, float* sigma, float* w,
+                                         float* tmp, int32_t rows, int32_t cols, int32_t do_iter, float eps,
+                                         void* stream_) {
+  PWG_REQUIRE(w_orig && u && v && sigma && w && tmp, PWG_ERR_NULL, "spectral_norm_forward: NULL pointer");
+  PWG_REQUIRE(rows > 0 && cols > 0, PWG_ERR_BAD_SHAPE, "spectral_norm: bad shape");
+  hipStream_t stream = (hipStream_t)stream_;
+  if (do_iter) {
+    hipLaunchKernelGGL(matvec_t_kernel, dim3(grid_for(cols)), dim3(256), 0, stream, w_orig, u, tmp, rows, cols);
+    hipLaunchKernelGGL(normalize_kernel, dim3(1), dim3(256), 0, stream, tmp, v, cols, eps);
+    hipLaunchKernelGGL(matvec_kernel, dim3(rows), dim3(256), 0, stream, w_orig, v, tmp, cols);
+    hipLaunchKernelGGL(normalize_kernel, dim3(1), dim3(256), 0, stream, tmp, u, rows, eps);
+  }
+  hipLaunchKernelGGL(matvec_kernel, dim3(rows), dim3(256), 0, stream, w_orig, v, tmp, cols);
+  hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, stream, u, tmp, sigma, rows);
+  const long n = (long)rows * cols;
+  hipLaunchKernelGGL(div_scalar_kernel, dim3(grid_for(n)), dim3(256), 0, stream, w_orig, sigma, w, n);
+  PWG_CHECK_LAUNCH("spectral_norm_forward");
+  return PWG_OK;
+}
+
+// dw_orig = dw / sigma - (<dw, w_orig> / sigma^2) u v^T ; scratch: one float
+extern "C" int pwg_spectral_norm_backward(const float* dw, const float* w_orig, const float* u, const float* v,
+                                          const float* sigma, float* dw_orig, float* scratch, int32_t rows,
+                                          int32_t cols, void* stream_) {
+  PWG_REQUIRE(dw && w_orig && u && v && sigma && dw_orig && scratch, PWG_ERR_NULL, "spectral_norm_backward: NULL pointer");
+  PWG_REQUIRE(rows > 0 && cols > 0, PWG_ERR_BAD_SHAPE, "spectral_norm: bad shape");
+  hipStream_t stream = (hipStream_t)stream_;
+  const long n = (long)rows * cols;
+  (void)hipMemsetAsync(scratch, 0, sizeof(float), stream);
+  hipLaunchKernelGGL(dot_big_kernel, dim3(grid_for(n, 256, 256)), dim3(256), 0, stream, dw, w_orig, scratch, n);
+  hipLaunchKernelGGL(spectral_norm_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, dw, u, v, sigma, scratch,
+                     dw_orig, rows, cols);
+  PWG_CHECK_LAUNCH("spectral_norm_backward");
+  return PWG_OK;
+}

@@ -1,0 +1,244 @@
+// reduce_optim.hip -- loss reductions (deterministic two-stage sums) and fused multi-tensor
+// optimizer steps.  All HBM-bound: one read of each operand, 16-B accesses where aligned.
+#include "common.h"
+
+namespace pwg {
+
+enum { RED_ABS_DIFF = 0, RED_SQ_DIFF = 1, RED_SQ = 2, RED_SQ_DIFF_CONST = 3, RED_SUM = 4 };
+constexpr int RED_BLOCKS = 512;
+
+__device__ __forceinline__ float red_term(int mode, float a, float b, float c) {
+  switch (mode) {
+    case RED_ABS_DIFF: return fabsf(a - b);
+    case RED_SQ_DIFF: return (a - b) * (a - b);
+    case RED_SQ: return a * a;
+    case RED_SQ_DIFF_CONST: return (a - c) * (a - c);
+    default: return a;
+  }
+}
+
+__device__ __forceinline__ float block_sum(float s, float* red) {
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float t = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  return t;
+}
+
+// stage 1: partial[blockIdx] = sum over a grid-strided slice (fixed grid => deterministic)
+__global__ void reduce_stage1_kernel(const float* a, const float* b, float c, long n, int mode, float* partial) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    s += red_term(mode, a[i], b ? b[i] : 0.f, c);
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+// stage 2: out[0] = (sum partial) * scale
+__global__ void reduce_stage2_kernel(const float* partial, int np, float scale, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < np; i += blockDim.x) s += partial[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out[0] = s * scale;
+}
+
+// gradient of out = scale * sum term(a, b):  da = gout * scale * dterm/da  (db = -da for diffs)
+__global__ void reduce_backward_kernel(const float* a, const float* b, float c, long n, int mode, float scale,
+                                       const float* gout, float* da, float* db) {
+  const float gs = gout[0] * scale;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float g;
+    const float av = a[i];
+    switch (mode) {
+      case RED_ABS_DIFF: {
+        const float d = av - b[i];
+        g = d > 0.f ? gs : (d < 0.f ? -gs : 0.f);
+        break;
+      }
+      case RED_SQ_DIFF: g = 2.f * (av - b[i]) * gs; break;
+      case RED_SQ: g = 2.f * av * gs; break;
+      case RED_SQ_DIFF_CONST: g = 2.f * (av - c) * gs; break;
+      default: g = gs;
+    }
+    if (da) da[i] = g;
+    if (db) db[i] = -g;
+  }
+}
+
+// ---- fused multi-tensor Adam / RAdam ------------------------------------------------------
+struct OptChunk {  // one 64 Ki-element slice of one parameter tensor
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  float* vmax;  // amsgrad only (else NULL)
+  int n;
+  int pad_;
+};
+
+// torch.optim.Adam (non-fused, weight_decay L2, optional amsgrad) semantics:
+//   g += wd * p;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2
+//   denom = sqrt(max? v) / sqrt(1 - b2^t) + eps;  p -= lr / (1 - b1^t) * m / denom
+__global__ void adam_multi_kernel(const OptChunk* chunks, float lr, float b1, float b2, float eps, float wd,
+                                  float bias_c1, float sqrt_bias_c2, float grad_scale) {
+  const OptChunk c = chunks[blockIdx.x];
+  const float step = lr / bias_c1;
+  for (int i = threadIdx.x; i < c.n; i += blockDim.x) {
+    float p = c.p[i];
+    float g = c.g[i] * grad_scale;
+    if (wd != 0.f) g += wd * p;
+    const float m = b1 * c.m[i] + (1.f - b1) * g;
+    const float v = b2 * c.v[i] + (1.f - b2) * g * g;
+    c.m[i] = m;
+    c.v[i] = v;
+    float vv = v;
+    if (c.vmax) {
+      vv = fmaxf(c.vmax[i], v);
+      c.vmax[i] = vv;
+    }
+    const float denom = sqrtf(vv) / sqrt_bias_c2 + eps;
+    c.p[i] = p - step * (m / denom);
+  }
+}
+
+// RAdam as in the reference's optimizers/radam.py:27-99 (LiyuanLucasLiu):
+//   v = b2 v + (1-b2) g^2 ; m = b1 m + (1-b1) g ; if wd: p -= wd*lr*p
+//   N_sma >= 5:  p -= step_size * m / (sqrt(v) + eps)      else:  p -= step_size * m
+// step_size (incl. the rectification term) is computed on the host per step.
+__global__ void radam_multi_kernel(const OptChunk* chunks, float lr, float b1, float b2, float eps, float wd,
+                                   float step_size, int rectified, float grad_scale) {
+  const OptChunk c = chunks[blockIdx.x];
+  for (int i = threadIdx.x; i < c.n; i += blockDim.x) {
+    float p = c.p[i];
+    const float g = c.g[i] * grad_scale;
+    const float v = b2 * c.v[i] + (1.f - b2) * g * g;
+    const float m = b1 * c.m[i] + (1.f - b1) * g;
+    c.m[i] = m;
+    c.v[i] = v;
+    if (wd != 0.f) p += -wd * lr * p;
+    if (rectified)
+      p += -step_size * (m / (sqrtf(v) + eps));
+    else
+      p += -step_size * m;
+    c.p[i] = p;
+  }
+}
+
+// sum of squares of many tensors (grad-norm clipping): partial per chunk, then one block
+__global__ void sqsum_multi_kernel(const OptChunk* chunks, float* partial) {
+  __shared__ float red[4];
+  const OptChunk c = chunks[blockIdx.x];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < c.n; i += blockDim.x) {
+    const float g = c.g[i];
+    s += g * g;
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+// out[0] = total_norm ; out[1] = clip coefficient = min(1, max_norm / (total_norm + 1e-6))
+__global__ void clip_coef_kernel(const float* partial, int np, float max_norm, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < np; i += blockDim.x) s += partial[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) {
+    const float norm = sqrtf(s);
+    out[0] = norm;
+    const float c = max_norm / (norm + 1e-6f);
+    out[1] = c < 1.f ? c : 1.f;
+  }
+}
+__global__ void scale_grads_multi_kernel(const OptChunk* chunks, const float* coef) {
+  const OptChunk c = chunks[blockIdx.x];
+  const float k = coef[1];
+  if (k >= 1.f) return;
+  float* g = const_cast<float*>(c.g);
+  for (int i = threadIdx.x; i < c.n; i += blockDim.x) g[i] *= k;
+}
+
+}  // namespace pwg
+
+using namespace pwg;
+
+// out[0] = scale * sum_i term(a_i, b_i)   mode: 0 |a-b|, 1 (a-b)^2, 2 a^2, 3 (a-c)^2, 4 a
+// workspace: >= 512 floats.  Deterministic (fixed grid, fixed order).
+extern "C" int pwg_reduce_forward(const float* a, const float* b, float c, int64_t n, int32_t mode, float scale,
+                                  float* out, float* workspace, void* stream_) {
+  PWG_REQUIRE(a && out && workspace, PWG_ERR_NULL, "reduce_forward: NULL pointer");
+  PWG_REQUIRE((mode != RED_ABS_DIFF && mode != RED_SQ_DIFF) || b, PWG_ERR_NULL, "reduce_forward: mode needs b");
+  PWG_REQUIRE(n > 0 && mode >= 0 && mode <= 4, PWG_ERR_BAD_SHAPE, "reduce_forward: bad arguments");
+  hipStream_t stream = (hipStream_t)stream_;
+  long blocks = (n + 1023) / 1024;
+  if (blocks > RED_BLOCKS) blocks = RED_BLOCKS;
+  ProfScope prof(stream, "reduce_stage1_kernel", 0, 4.0 * n * (b ? 2 : 1));
+  hipLaunchKernelGGL(reduce_stage1_kernel, dim3((int)blocks), dim3(256), 0, stream, a, b, c, (long)n, mode, workspace);
+  hipLaunchKernelGGL(reduce_stage2_kernel, dim3(1), dim3(256), 0, stream, workspace, (int)blocks, scale, out);
+  PWG_CHECK_LAUNCH("reduce_forward");
+  return PWG_OK;
+}
+
+extern "C" int pwg_reduce_backward(const float* a, const float* b, float c, int64_t n, int32_t mode, float scale,
+                                   const float* gout, float* da, float* db, void* stream) {
+  PWG_REQUIRE(a && gout && (da || db), PWG_ERR_NULL, "reduce_backward: NULL pointer");
+  PWG_REQUIRE(n > 0 && mode >= 0 && mode <= 4, PWG_ERR_BAD_SHAPE, "reduce_backward: bad arguments");
+  long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(reduce_backward_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, a, b, c, (long)n,
+                     mode, scale, gout, da, db);
+  PWG_CHECK_LAUNCH("reduce_backward");
+  return PWG_OK;
+}
+
+// chunks: device array of n_chunks pwg_opt_chunk records (see header)
+extern "C" int pwg_adam_step(const void* chunks, int32_t n_chunks, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, int32_t step, float grad_scale, void* stream) {
+  PWG_REQUIRE(chunks, PWG_ERR_NULL, "adam_step: NULL chunk table");
+  PWG_REQUIRE(n_chunks > 0 && step >= 1, PWG_ERR_BAD_SHAPE, "adam_step: bad arguments");
+  const double c1 = 1.0 - pow((double)beta1, step), c2 = 1.0 - pow((double)beta2, step);
+  ProfScope prof((hipStream_t)stream, "adam_multi_kernel", 0, 28.0 * 65536.0 * n_chunks);
+  hipLaunchKernelGGL(adam_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream,
+                     (const OptChunk*)chunks, lr, beta1, beta2, eps, weight_decay, (float)c1, (float)sqrt(c2),
+                     grad_scale);
+  PWG_CHECK_LAUNCH("adam_step");
+  return PWG_OK;
+}
+
+extern "C" int pwg_radam_step(const void* chunks, int32_t n_chunks, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, int32_t step, float grad_scale, void* stream) {
+  PWG_REQUIRE(chunks, PWG_ERR_NULL, "radam_step: NULL chunk table");
+  PWG_REQUIRE(n_chunks > 0 && step >= 1, PWG_ERR_BAD_SHAPE, "radam_step: bad arguments");
+  // optimizers/radam.py:63-86
+  const double beta2_t = pow((double)beta2, step);
+  const double n_sma_max = 2.0 / (1.0 - beta2) - 1.0;
+  const double n_sma = n_sma_max - 2.0 * step * beta2_t / (1.0 - beta2_t);
+  double step_size;
+  int rectified = n_sma >= 5.0;
+  if (rectified)
+    step_size = lr * sqrt((1.0 - beta2_t) * (n_sma - 4.0) / (n_sma_max - 4.0) * (n_sma - 2.0) / n_sma * n_sma_max /
+                          (n_sma_max - 2.0)) /
+                (1.0 - pow((double)beta1, step));
+  else
+    step_size = lr / (1.0 - pow((double)beta1, step));
+  hipLaunchKernelGGL(radam_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream,
+                     (const OptChunk*)chunks, lr, beta1, beta2, eps, weight_decay, (float)step_size, rectified,
+                     grad_scale);
+  PWG_CHECK_LAUNCH("radam_step");
+  return PWG_OK;
+}
+
+// torch.nn.utils.clip_grad_norm_ (L2) over a chunk table: out[0] = total norm, out[1] = coefficient
+// applied; workspace >= n_chunks floats.
+extern "C" int pwg_clip_grad_norm(const void* chunks, int32_t n_chunks, float max_norm, float* out, float* workspace,
+                                  void* stream_) {
+  PWG_REQUIRE(chunks && out && workspace, PWG_ERR_NULL, "clip_grad_norm: NULL pointer");
+  PWG_REQUIRE(n_chunks > 0 && max_norm > 0.f, PWG_ERR_BAD_SHAPE, "clip_grad_norm: bad arguments");
+  hipStream_t stream = (hipStream_t)stream_;
+  hipLaunchKernelGGL(sqsum_multi_kernel, dim3(n_chunks), dim3(256), 0, stream, (const OptChunk*)chunks, workspace);
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, stream, workspace, n_chunks, max_norm, out);
+  hipLaunchKernelGGL(scale_grads_multi_kernel, dim3(n_chunks), dim3(256), 0, stream, (const OptChunk*)chunks, out);
+  PWG_CHECK_LAUNCH("clip_grad_norm");
+  return PWG_OK;
+}

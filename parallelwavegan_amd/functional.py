@@ -1,0 +1,345 @@
+"""Differentiable wrappers: ``torch.autograd.Function`` nodes whose forward AND backward are
+HIP kernels from libpwgkernels.so.  torch's autograd engine only orders the nodes and sums
+gradients of tensors used more than once; it performs no convolution/loss arithmetic here.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib, ops
+from .ops import _ptr, _require_device, _stream
+
+_L = _lib.lib
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
+# weight reparametrisations
+# ---------------------------------------------------------------------------------------------
+class WeightNormFn(torch.autograd.Function):
+    """w = g * v / ||v||  (old-style torch.nn.utils.weight_norm, dim=0)."""
+
+    @staticmethod
+    def forward(ctx, v, g):
+        v = _c(v)
+        g = _c(g)
+        scale = ops.weight_norm_scale(v, g.reshape(-1))
+        ctx.save_for_backward(v, g)
+        return ops.scale_rows(v, scale)
+
+    @staticmethod
+    def backward(ctx, dw):
+        v, g = ctx.saved_tensors
+        dw = _c(dw)
+        _require_device(dw)
+        dv = torch.empty_like(v)
+        dg = torch.empty_like(g)
+        n0 = v.shape[0]
+        _lib.check(_L().pwg_weight_norm_backward(_ptr(dw), _ptr(v), _ptr(g), _ptr(dv), _ptr(dg), n0,
+                                                 v.numel() // n0, _stream()), "weight_norm_backward")
+        return dv, dg
+
+
+class SpectralNormFn(torch.autograd.Function):
+    """w = w_orig / sigma, sigma = u^T W v after (optionally) one power iteration that updates the
+    ``u``/``v`` buffers in place, as torch.nn.utils.spectral_norm does in training mode."""
+
+    @staticmethod
+    def forward(ctx, w_orig, u, v, do_iter, eps):
+        w_orig = _c(w_orig)
+        _require_device(w_orig, u, v)
+        rows = w_orig.shape[0]
+        cols = w_orig.numel() // rows
+        sigma = torch.empty(1, device=w_orig.device, dtype=torch.float32)
+        w = torch.empty_like(w_orig)
+        tmp = torch.empty(max(rows, cols), device=w_orig.device, dtype=torch.float32)
+        _lib.check(_L().pwg_spectral_norm_forward(_ptr(w_orig), _ptr(u), _ptr(v), _ptr(sigma), _ptr(w), _ptr(tmp),
+                                                  rows, cols, int(bool(do_iter)), float(eps), _stream()),
+                   "spectral_norm_forward")
+        # torch clones u, v after the iteration so that later in-place updates do not alter this graph
+        ctx.save_for_backward(w_orig, u.clone(), v.clone(), sigma)
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        w_orig, u, v, sigma = ctx.saved_tensors
+        dw = _c(dw)
+        rows = w_orig.shape[0]
+        cols = w_orig.numel() // rows
+        dwo = torch.empty_like(w_orig)
+        scratch = torch.empty(1, device=dw.device, dtype=torch.float32)
+        _lib.check(_L().pwg_spectral_norm_backward(_ptr(dw), _ptr(w_orig), _ptr(u), _ptr(v), _ptr(sigma), _ptr(dwo),
+                                                   _ptr(scratch), rows, cols, _stream()), "spectral_norm_backward")
+        return dwo, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# fused convolution
+# ---------------------------------------------------------------------------------------------
+class FusedConvFn(torch.autograd.Function):
+    """y = post_act((conv(pre_act(x), w) + bias + add1 + add2) * out_mul / out_div).
+
+    ``geom`` = dict(kernel, stride, dilation, padding, groups, transposed, output_padding, width,
+    pad_mode); ``fused`` = dict(pre_act, pre_slope, post_act, post_slope, out_mul, out_div).
+    ``packed`` optionally carries a cached forward weight image (inference).
+    """
+
+    @staticmethod
+    def forward(ctx, x, w, bias, add1, add2, geom, fused, packed):
+        x = _c(x)
+        b = x.shape[0]
+        width = geom.get("width", 1)
+        t_in = x.shape[-1] // width if x.dim() == 3 else x.shape[2]
+        x3 = x.reshape(b, x.shape[1], -1)
+        c_in = x3.shape[1]
+        transposed = geom["transposed"]
+        k = geom["kernel"]
+        if transposed:
+            c_out = w.shape[1] * geom["groups"]
+            t_out = ops.conv_transpose_out_length(t_in, k, geom["stride"], geom["padding"], geom["output_padding"])
+        else:
+            c_out = w.shape[0]
+            t_out = geom.get("t_out")
+            if t_out is None:
+                t_out = ops.conv_out_length(t_in, k, geom["stride"], geom["dilation"], geom["padding"],
+                                            geom.get("padding_right", geom["padding"]))
+        desc = ops.make_conv_desc(b, c_in, c_out, t_in, t_out, k, geom["stride"], geom["dilation"], geom["padding"],
+                                  geom["groups"], transposed=transposed, width=width,
+                                  pad_mode=geom.get("pad_mode", "zero"), **fused)
+        wc = _c(w.reshape(w.shape[0], w.shape[1], -1))
+        if packed is None:
+            packed = ops.pack_weight(desc, wc)
+        add1c = None if add1 is None else _c(add1).reshape(b, c_out, -1)
+        add2c = None if add2 is None else _c(add2).reshape(b, c_out, -1)
+        y = ops.conv1d_forward(desc, x3, packed, None if bias is None else _c(bias), add1c, add2c)
+        ctx.desc = desc
+        ctx.has = (bias is not None, add1 is not None, add2 is not None)
+        ctx.fused = fused
+        ctx.w_shape = tuple(wc.shape)
+        ctx.w_orig_shape = tuple(w.shape)
+        ctx.x_shape = tuple(x.shape)
+        need_y = fused.get("post_act") not in (None, "none")
+        ctx.save_for_backward(x3, wc, y if need_y else None)
+        if width > 1:
+            return y.reshape(b, c_out, t_out, width)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x3, wc, y = ctx.saved_tensors
+        desc, fused = ctx.desc, ctx.fused
+        dy = _c(dy).reshape(desc.batch, desc.c_out, -1)
+        _require_device(dy)
+        has_bias, has_add1, has_add2 = ctx.has
+        # gradient w.r.t. the pre-post_act, pre-scale sum
+        scale = float(fused.get("out_mul", 1.0)) / float(fused.get("out_div", 1.0))
+        post = fused.get("post_act")
+        if post not in (None, "none") or scale != 1.0:
+            g = torch.empty_like(dy)
+            _lib.check(_L().pwg_act_backward(_ptr(dy), _ptr(y), _ptr(g), dy.numel(), ops.ACT[post],
+                                             float(fused.get("post_slope", 0.0)), scale, _stream()), "act_backward")
+        else:
+            g = dy
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        dx = dw = db = None
+        if need_x:
+            dx = ops.conv1d_backward_data(desc, g, ops.pack_weight_bwd(desc, wc), x3).reshape(ctx.x_shape)
+        if need_w or (need_b and has_bias):
+            dw, db = ops.conv1d_backward_weight(desc, x3, g, ctx.w_shape, need_dw=need_w, need_db=need_b and has_bias)
+            if dw is not None:
+                dw = dw.reshape(ctx.w_orig_shape)
+        gshape = dy.shape if desc.width == 1 else (desc.batch, desc.c_out, desc.t_out, desc.width)
+        dadd1 = g.reshape(gshape) if has_add1 and ctx.needs_input_grad[3] else None
+        dadd2 = g.reshape(gshape) if has_add2 and ctx.needs_input_grad[4] else None
+        return dx, dw, db, dadd1, dadd2, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# pooling / padding
+# ---------------------------------------------------------------------------------------------
+class AvgPool1dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kernel, stride, pad, count_include_pad):
+        x = _c(x)
+        _require_device(x)
+        t_in = x.shape[-1]
+        t_out = (t_in + 2 * pad - kernel) // stride + 1
+        rows = x.numel() // t_in
+        y = torch.empty(x.shape[:-1] + (t_out,), device=x.device, dtype=torch.float32)
+        _lib.check(_L().pwg_avg_pool1d_forward(_ptr(x), _ptr(y), rows, t_in, t_out, kernel, stride, pad,
+                                               int(bool(count_include_pad)), _stream()), "avg_pool1d_forward")
+        ctx.cfg = (rows, t_in, t_out, kernel, stride, pad, int(bool(count_include_pad)), tuple(x.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        rows, t_in, t_out, kernel, stride, pad, cip, shape = ctx.cfg
+        dy = _c(dy)
+        dx = torch.empty(shape, device=dy.device, dtype=torch.float32)
+        _lib.check(_L().pwg_avg_pool1d_backward(_ptr(dy), _ptr(dx), rows, t_in, t_out, kernel, stride, pad, cip,
+                                                _stream()), "avg_pool1d_backward")
+        return dx, None, None, None, None
+
+
+class Pad1dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pad_left, pad_right, mode):
+        x = _c(x)
+        _require_device(x)
+        t_in = x.shape[-1]
+        rows = x.numel() // t_in
+        y = torch.empty(x.shape[:-1] + (t_in + pad_left + pad_right,), device=x.device, dtype=torch.float32)
+        _lib.check(_L().pwg_pad1d_forward(_ptr(x), _ptr(y), rows, t_in, pad_left, pad_right, ops.PAD[mode], _stream()),
+                   "pad1d_forward")
+        ctx.cfg = (rows, t_in, pad_left, pad_right, ops.PAD[mode], tuple(x.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        rows, t_in, pl, pr, mode, shape = ctx.cfg
+        dy = _c(dy)
+        dx = torch.empty(shape, device=dy.device, dtype=torch.float32)
+        _lib.check(_L().pwg_pad1d_backward(_ptr(dy), _ptr(dx), rows, t_in, pl, pr, mode, _stream()), "pad1d_backward")
+        return dx, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# spectral-loss pieces
+# ---------------------------------------------------------------------------------------------
+class FrameFoldFn(torch.autograd.Function):
+    """(B, T) -> (B, hop, n_cols): y[b][c][n] = reflect_pad(x, pad)[b][n*hop + c] (zero past the end)."""
+
+    @staticmethod
+    def forward(ctx, x, pad, hop, n_cols):
+        x = _c(x)
+        _require_device(x)
+        b, t = x.shape
+        y = torch.empty(b, hop, n_cols, device=x.device, dtype=torch.float32)
+        _lib.check(_L().pwg_frame_fold_forward(_ptr(x), _ptr(y), b, t, pad, hop, n_cols, _stream()), "frame_fold_forward")
+        ctx.cfg = (b, t, pad, hop, n_cols)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        b, t, pad, hop, n_cols = ctx.cfg
+        dy = _c(dy)
+        dx = torch.empty(b, t, device=dy.device, dtype=torch.float32)
+        _lib.check(_L().pwg_frame_fold_backward(_ptr(dy), _ptr(dx), b, t, pad, hop, n_cols, _stream()), "frame_fold_backward")
+        return dx, None, None, None
+
+
+class StftMagFn(torch.autograd.Function):
+    """(B, 2*bins, frames) [re rows | im rows] -> (B, bins, frames): sqrt(max(re^2+im^2, eps))."""
+
+    @staticmethod
+    def forward(ctx, spec, eps):
+        spec = _c(spec)
+        _require_device(spec)
+        b, two_bins, frames = spec.shape
+        bins = two_bins // 2
+        mag = torch.empty(b, bins, frames, device=spec.device, dtype=torch.float32)
+        _lib.check(_L().pwg_stft_mag_forward(_ptr(spec), _ptr(mag), b, bins, frames, float(eps), _stream()), "stft_mag_forward")
+        ctx.save_for_backward(spec, mag)
+        ctx.eps = float(eps)
+        return mag
+
+    @staticmethod
+    def backward(ctx, dmag):
+        spec, mag = ctx.saved_tensors
+        dmag = _c(dmag)
+        b, bins, frames = mag.shape
+        dspec = torch.empty_like(spec)
+        _lib.check(_L().pwg_stft_mag_backward(_ptr(spec), _ptr(mag), _ptr(dmag), _ptr(dspec), b, bins, frames, ctx.eps,
+                                              _stream()), "stft_mag_backward")
+        return dspec, None
+
+
+class LogClampFn(torch.autograd.Function):
+    """y = log(max(x, eps)) / log_div."""
+
+    @staticmethod
+    def forward(ctx, x, eps, log_div):
+        x = _c(x)
+        _require_device(x)
+        y = torch.empty_like(x)
+        _lib.check(_L().pwg_log_clamp_forward(_ptr(x), _ptr(y), x.numel(), float(eps), float(log_div), _stream()), "log_clamp_forward")
+        ctx.save_for_backward(x)
+        ctx.cfg = (float(eps), float(log_div))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        _lib.check(_L().pwg_log_clamp_backward(_ptr(x), _ptr(dy), _ptr(dx), x.numel(), ctx.cfg[0], ctx.cfg[1], _stream()), "log_clamp_backward")
+        return dx, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# loss reductions
+# ---------------------------------------------------------------------------------------------
+RED = {"abs_diff": 0, "sq_diff": 1, "sq": 2, "sq_diff_const": 3, "sum": 4}
+
+
+class ReduceFn(torch.autograd.Function):
+    """0-dim tensor  scale * sum_i term(a_i, b_i | c)  with a deterministic two-stage HIP reduction."""
+
+    @staticmethod
+    def forward(ctx, a, b, mode, scale, const):
+        a = _c(a)
+        _require_device(a)
+        if b is not None:
+            b = _c(b)
+            _require_device(b)
+            assert b.shape == a.shape, (a.shape, b.shape)
+        out = torch.empty(1, device=a.device, dtype=torch.float32)
+        ws = torch.empty(512, device=a.device, dtype=torch.float32)
+        _lib.check(_L().pwg_reduce_forward(_ptr(a), _ptr(b), float(const), a.numel(), RED[mode], float(scale), _ptr(out),
+                                           _ptr(ws), _stream()), "reduce_forward")
+        ctx.save_for_backward(a, b)
+        ctx.cfg = (RED[mode], float(scale), float(const))
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, b = ctx.saved_tensors
+        mode, scale, const = ctx.cfg
+        gout = _c(gout).reshape(1)
+        need_a, need_b = ctx.needs_input_grad[0], (b is not None and ctx.needs_input_grad[1])
+        da = torch.empty_like(a) if need_a else None
+        db = torch.empty_like(a) if need_b else None
+        if need_a or need_b:
+            _lib.check(_L().pwg_reduce_backward(_ptr(a), _ptr(b), const, a.numel(), mode, scale, _ptr(gout), _ptr(da),
+                                                _ptr(db), _stream()), "reduce_backward")
+        return da, db, None, None, None
+
+
+def l1_mean(a, b):
+    """F.l1_loss(a, b) (mean)."""
+    return ReduceFn.apply(a, b, "abs_diff", 1.0 / a.numel(), 0.0)
+
+
+def mse_to_const_mean(a, const):
+    """F.mse_loss(a, full_like(a, const)) (mean)."""
+    return ReduceFn.apply(a, None, "sq_diff_const", 1.0 / a.numel(), float(const))
+
+
+def sq_diff_sum(a, b):
+    return ReduceFn.apply(a, b, "sq_diff", 1.0, 0.0)
+
+
+def sq_sum(a):
+    return ReduceFn.apply(a, None, "sq", 1.0, 0.0)
+
+
+def avg_pool1d(x, kernel, stride, pad, count_include_pad=True):
+    return AvgPool1dFn.apply(x, kernel, stride, pad, count_include_pad)
+
+
+def pad1d(x, pad_left, pad_right, mode="reflect"):
+    return Pad1dFn.apply(x, pad_left, pad_right, mode)

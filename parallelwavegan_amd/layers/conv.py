@@ -1,24 +1,28 @@
 """Convolution modules whose arithmetic runs in libpwgkernels.so.
 
-They replace ``torch.nn.Conv1d`` / ``torch.nn.ConvTranspose1d`` (+ the old-style
-``torch.nn.utils.weight_norm`` hook) at the reference's call sites and keep the
-same parameter names and shapes, so reference checkpoints load unchanged:
-``weight``/``bias`` or, with weight norm, ``weight_g``/``weight_v``/``bias``
-(e.g. /root/reference/parallel_wavegan/models/hifigan.py:221-231).
+They replace ``torch.nn.Conv1d`` / ``torch.nn.ConvTranspose1d`` / ``torch.nn.Conv2d`` with
+``(k, 1)`` kernels, together with the old-style ``torch.nn.utils.weight_norm`` /
+``spectral_norm`` hooks, at the reference's call sites.  Parameter and buffer names and shapes
+are the reference's, so its checkpoints load unchanged:
+``weight``/``bias``; with weight norm ``weight_g``/``weight_v``/``bias``; with spectral norm
+``weight_orig``/``weight_u``/``weight_v``/``bias``
+(e.g. /root/reference/parallel_wavegan/models/hifigan.py:221-231, :383-402, :603-621).
 
-The packed kernel weight image ([group][tap][ci][m], see csrc/conv1d.hip) is
-derived from the parameters on the device (weight-norm scale + pack in two tiny
-kernels) and cached until a parameter changes.
+Inference (no grad): the packed kernel weight image is derived once on the device and cached
+until a parameter changes.  Training: the effective weight is a differentiable HIP node
+(functional.WeightNormFn / SpectralNormFn) feeding functional.FusedConvFn.
 """
 import math
 
 import torch
 
+from .. import functional as Fn
 from .. import ops
 
 
 class _ConvNd(torch.nn.Module):
     transposed = False
+    width_mode = False  # True for the (k, 1) Conv2d: input is (B, C, H, W)
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
                  bias=True, output_padding=0, pad_mode="zero"):
@@ -29,43 +33,57 @@ class _ConvNd(torch.nn.Module):
         self.kernel_size, self.stride, self.padding = int(kernel_size), int(stride), int(padding)
         self.dilation, self.groups, self.output_padding = int(dilation), int(groups), int(output_padding)
         self.pad_mode = pad_mode
-        if self.transposed:
-            shape = (in_channels, out_channels // groups, self.kernel_size)
-        else:
-            shape = (out_channels, in_channels // groups, self.kernel_size)
-        self.weight = torch.nn.Parameter(torch.empty(shape))
+        self.weight = torch.nn.Parameter(torch.empty(self._weight_shape()))
         if bias:
             self.bias = torch.nn.Parameter(torch.empty(out_channels))
         else:
             self.register_parameter("bias", None)
         self._cache_key = None
         self._cache_packed = None
+        self.spectral_eps = 1e-12
         self.reset_parameters()
+
+    def _weight_shape(self):
+        if self.transposed:
+            return (self.in_channels, self.out_channels // self.groups, self.kernel_size)
+        return (self.out_channels, self.in_channels // self.groups, self.kernel_size)
 
     # -- initialisation identical in distribution to torch.nn.Conv1d's default
     def reset_parameters(self):
-        w = self._raw_weight_for_init()
-        fan_in = w.shape[1] * w.shape[2]
+        w = self.raw_weight
+        fan_in = int(w[0].numel())
         bound = 1.0 / math.sqrt(fan_in) if fan_in > 0 else 0.0
         with torch.no_grad():
             w.uniform_(-bound, bound)  # kaiming_uniform_(a=sqrt(5)) == U(-1/sqrt(fan_in), 1/sqrt(fan_in))
             if self.bias is not None:
                 self.bias.uniform_(-bound, bound)
 
-    def _raw_weight_for_init(self):
-        return self.weight if self.has_weight_norm is False else self.weight_v
+    @property
+    def raw_weight(self):
+        """The directly trainable weight-shaped parameter (weight / weight_v / weight_orig)."""
+        if self.has_weight_norm:
+            return self.weight_v
+        if self.has_spectral_norm:
+            return self.weight_orig
+        return self.weight
 
     # -- old-style weight norm (dim=0): w = g * v / ||v||
     @property
     def has_weight_norm(self):
         return "weight_g" in self._parameters
 
+    @property
+    def has_spectral_norm(self):
+        return "weight_orig" in self._parameters
+
     def apply_weight_norm(self):
         if self.has_weight_norm:
             return self
+        if self.has_spectral_norm:
+            raise ValueError("spectral norm is already applied")
         w = self._parameters.pop("weight")
         with torch.no_grad():
-            g = w.detach().reshape(w.shape[0], -1).norm(dim=1).reshape(-1, 1, 1)
+            g = w.detach().reshape(w.shape[0], -1).norm(dim=1).reshape((-1,) + (1,) * (w.dim() - 1))
         self.weight_g = torch.nn.Parameter(g.clone())
         self.weight_v = torch.nn.Parameter(w.detach().clone())
         self._cache_key = None
@@ -75,63 +93,148 @@ class _ConvNd(torch.nn.Module):
         if not self.has_weight_norm:
             raise ValueError(f"weight norm is not applied to {self.__class__.__name__}")
         g, v = self._parameters.pop("weight_g"), self._parameters.pop("weight_v")
-        with torch.no_grad():
-            if v.is_cuda:
-                w = ops.scale_rows(v.detach().contiguous(), ops.weight_norm_scale(v.detach().contiguous(),
-                                                                               g.detach().reshape(-1).contiguous()))
-            else:  # host-side bookkeeping only (checkpoint conversion); not a compute path
-                n = v.detach().reshape(v.shape[0], -1).norm(dim=1).reshape(-1, 1, 1)
-                w = v.detach() * (g.detach() / n)
-        self.weight = torch.nn.Parameter(w)
+        self.weight = torch.nn.Parameter(self._bake_weight_norm(g.detach(), v.detach()))
         self._cache_key = None
         return self
 
-    def effective_weight(self):
-        """torch-layout weight tensor on the device (materialised by HIP kernels)."""
-        if not self.has_weight_norm:
-            return self.weight
-        v = self.weight_v.detach().contiguous()
-        return ops.scale_rows(v, ops.weight_norm_scale(v, self.weight_g.detach().reshape(-1).contiguous()))
+    @staticmethod
+    def _bake_weight_norm(g, v):
+        """One-off parameter conversion for ``remove_weight_norm`` (checkpoint bookkeeping; the
+        reference calls it on CPU before ``.to(device)``, bin/decode.py:147-149).  On the device
+        it runs on the HIP kernels; on the host it is plain parameter arithmetic, never a
+        substitute for the compute path."""
+        if v.is_cuda:
+            vc = v.contiguous()
+            return ops.scale_rows(vc, ops.weight_norm_scale(vc, g.reshape(-1).contiguous()))
+        n = v.reshape(v.shape[0], -1).norm(dim=1).reshape(g.shape)
+        return v * (g / n)
 
-    # -- packed image
-    def _geometry_desc(self, batch=1, t_in=None):
-        t_in = t_in if t_in is not None else self.kernel_size * self.dilation + self.stride
-        return self.make_desc(batch, t_in)
+    # -- old-style spectral norm (dim=0, one power iteration per training forward)
+    def apply_spectral_norm(self):
+        if self.has_spectral_norm:
+            return self
+        if self.has_weight_norm:
+            raise ValueError("weight norm is already applied")
+        w = self._parameters.pop("weight")
+        rows, cols = w.shape[0], w[0].numel()
+        with torch.no_grad():
+            # torch.nn.utils.spectral_norm: u ~ N(0,1) normalised, v likewise, then 15 warm-up
+            # iterations at construction time (host-side initialisation only)
+            u = torch.nn.functional.normalize(torch.randn(rows), dim=0, eps=self.spectral_eps)
+            v = torch.nn.functional.normalize(torch.randn(cols), dim=0, eps=self.spectral_eps)
+            wm = w.detach().reshape(rows, cols)
+            for _ in range(15):
+                v = torch.nn.functional.normalize(torch.mv(wm.t(), u), dim=0, eps=self.spectral_eps)
+                u = torch.nn.functional.normalize(torch.mv(wm, v), dim=0, eps=self.spectral_eps)
+        self.weight_orig = torch.nn.Parameter(w.detach().clone())
+        self.register_buffer("weight_u", u)
+        self.register_buffer("weight_v", v)
+        self._cache_key = None
+        return self
+
+    def remove_spectral_norm(self):
+        if not self.has_spectral_norm:
+            raise ValueError(f"spectral norm is not applied to {self.__class__.__name__}")
+        w = self._parameters.pop("weight_orig")
+        u, v = self._buffers.pop("weight_u"), self._buffers.pop("weight_v")
+        with torch.no_grad():
+            wm = w.detach().reshape(w.shape[0], -1)
+            sigma = torch.dot(u, torch.mv(wm, v))
+        self.weight = torch.nn.Parameter(w.detach() / sigma)
+        self._cache_key = None
+        return self
+
+    # -- effective weight
+    def weight_tensor(self):
+        """Differentiable effective weight (torch layout) computed by HIP kernels."""
+        if self.has_weight_norm:
+            return Fn.WeightNormFn.apply(self.weight_v, self.weight_g)
+        if self.has_spectral_norm:
+            return Fn.SpectralNormFn.apply(self.weight_orig, self.weight_u, self.weight_v, self.training,
+                                           self.spectral_eps)
+        return self.weight
+
+    def effective_weight(self):
+        with torch.no_grad():
+            return self.weight_tensor().detach()
+
+    def _params_key(self):
+        ps = [self.raw_weight] + ([self.weight_g] if self.has_weight_norm else [])
+        if self.has_spectral_norm:
+            ps += [self.weight_u, self.weight_v]
+        return tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
 
     def packed_weight(self):
-        params = [self.weight_g, self.weight_v] if self.has_weight_norm else [self.weight]
-        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
+        """Cached forward weight image (no-grad path)."""
+        if self.has_spectral_norm and self.training:
+            # every training-mode forward performs a power iteration: nothing to cache
+            return ops.pack_weight(self.make_desc(1, self._probe_len()), self._w3(self.effective_weight()))
+        key = self._params_key()
         if key != self._cache_key:
-            desc = self._geometry_desc()
+            desc = self.make_desc(1, self._probe_len())
             with torch.no_grad():
                 if self.has_weight_norm:
-                    v = self.weight_v.detach().contiguous()
+                    v = self._w3(self.weight_v.detach())
                     scale = ops.weight_norm_scale(v, self.weight_g.detach().reshape(-1).contiguous())
                     self._cache_packed = ops.pack_weight(desc, v, scale)
                 else:
-                    self._cache_packed = ops.pack_weight(desc, self.weight.detach().contiguous())
+                    self._cache_packed = ops.pack_weight(desc, self._w3(self.effective_weight()))
             self._cache_key = key
         return self._cache_packed
+
+    @staticmethod
+    def _w3(w):
+        return w.reshape(w.shape[0], w.shape[1], -1).contiguous()
+
+    def _probe_len(self):
+        return self.kernel_size * self.dilation + self.stride
+
+    def geom(self):
+        return dict(kernel=self.kernel_size, stride=self.stride, dilation=self.dilation, padding=self.padding,
+                    groups=self.groups, transposed=self.transposed, output_padding=self.output_padding,
+                    width=1, pad_mode=self.pad_mode)
 
     def out_length(self, t_in):
         raise NotImplementedError
 
-    def make_desc(self, batch, t_in, **fused):
+    def make_desc(self, batch, t_in, width=1, **fused):
         raise NotImplementedError
 
+    def _needs_grad(self, *tensors):
+        if not torch.is_grad_enabled():
+            return False
+        if any(p.requires_grad for p in self.parameters(recurse=False)):
+            return True
+        return any(t is not None and t.requires_grad for t in tensors)
+
     def forward(self, x, pre_act=None, pre_slope=0.0, post_act=None, post_slope=0.0, add1=None, add2=None,
-                out_mul=1.0, out_div=1.0, out=None):
+                out_mul=1.0, out_div=1.0):
         """Fused ``post((conv(pre(x)) + bias + add1 + add2) * out_mul / out_div)``."""
-        b, _, t_in = x.shape
-        desc = self.make_desc(b, t_in, pre_act=pre_act, pre_slope=pre_slope, post_act=post_act,
-                              post_slope=post_slope, out_mul=out_mul, out_div=out_div)
-        return ops.conv1d_forward(desc, x.contiguous(), self.packed_weight(),
-                                  None if self.bias is None else self.bias.detach(), add1, add2, out)
+        fused = dict(pre_act=pre_act, pre_slope=pre_slope, post_act=post_act, post_slope=post_slope,
+                     out_mul=out_mul, out_div=out_div)
+        if self._needs_grad(x, add1, add2):
+            geom = self.geom()
+            if self.width_mode:
+                geom["width"] = x.shape[-1]
+            return Fn.FusedConvFn.apply(x, self.weight_tensor(), self.bias, add1, add2, geom, fused, None)
+        with torch.no_grad():
+            b = x.shape[0]
+            if self.width_mode:
+                h, width = x.shape[2], x.shape[3]
+                desc = self.make_desc(b, h, width=width, **fused)
+                y = ops.conv1d_forward(desc, x.reshape(b, x.shape[1], -1).contiguous(), self.packed_weight(),
+                                       None if self.bias is None else self.bias.detach(),
+                                       None if add1 is None else add1.reshape(b, self.out_channels, -1),
+                                       None if add2 is None else add2.reshape(b, self.out_channels, -1))
+                return y.reshape(b, self.out_channels, desc.t_out, width)
+            desc = self.make_desc(b, x.shape[-1], **fused)
+            return ops.conv1d_forward(desc, x.contiguous(), self.packed_weight(),
+                                      None if self.bias is None else self.bias.detach(), add1, add2)
 
     def extra_repr(self):
+        norm = "weight_norm" if self.has_weight_norm else ("spectral_norm" if self.has_spectral_norm else "none")
         return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, "
-                f"padding={self.padding}, dilation={self.dilation}, groups={self.groups}, "
-                f"weight_norm={self.has_weight_norm}")
+                f"padding={self.padding}, dilation={self.dilation}, groups={self.groups}, norm={norm}")
 
 
 class Conv1d(_ConvNd):
@@ -142,10 +245,38 @@ class Conv1d(_ConvNd):
     def out_length(self, t_in):
         return ops.conv_out_length(t_in, self.kernel_size, self.stride, self.dilation, self.padding, self.padding)
 
-    def make_desc(self, batch, t_in, **fused):
+    def make_desc(self, batch, t_in, width=1, **fused):
         return ops.make_conv_desc(batch, self.in_channels, self.out_channels, t_in, self.out_length(t_in),
                                   self.kernel_size, self.stride, self.dilation, self.padding, self.groups,
-                                  transposed=False, pad_mode=self.pad_mode, **fused)
+                                  transposed=False, width=width, pad_mode=self.pad_mode, **fused)
+
+
+class Conv2d(Conv1d):
+    """Drop-in for ``torch.nn.Conv2d`` restricted to ``(k, 1)`` kernels, ``(s, 1)`` strides and
+    ``(p, 0)`` padding -- the only 2-D convolutions on the hot path (period discriminator,
+    /root/reference/parallel_wavegan/models/hifigan.py:314-341).  Input (B, C, H, W); the
+    weight keeps torch's (C_out, C_in, k, 1) shape."""
+
+    width_mode = True
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True):
+        def _first(v, name):
+            if isinstance(v, (tuple, list)):
+                if len(v) != 2 or (name == "kernel_size" and v[1] != 1) or (name == "stride" and v[1] != 1) or (
+                        name == "padding" and v[1] != 0):
+                    raise NotImplementedError(f"Conv2d: only (k,1) kernels / (s,1) strides / (p,0) padding, got {name}={v}")
+                return v[0]
+            if name == "stride":
+                if v != 1:
+                    raise NotImplementedError("Conv2d: an int stride > 1 would also stride the width axis")
+                return 1
+            raise NotImplementedError(f"Conv2d: {name} must be given as a (k, 1)-style tuple")
+
+        super().__init__(in_channels, out_channels, _first(kernel_size, "kernel_size"), _first(stride, "stride"),
+                         _first(padding, "padding"), bias=bias)
+
+    def _weight_shape(self):
+        return (self.out_channels, self.in_channels // self.groups, self.kernel_size, 1)
 
 
 class ConvTranspose1d(_ConvNd):
@@ -156,7 +287,7 @@ class ConvTranspose1d(_ConvNd):
     def out_length(self, t_in):
         return ops.conv_transpose_out_length(t_in, self.kernel_size, self.stride, self.padding, self.output_padding)
 
-    def make_desc(self, batch, t_in, **fused):
+    def make_desc(self, batch, t_in, width=1, **fused):
         return ops.make_conv_desc(batch, self.in_channels, self.out_channels, t_in, self.out_length(t_in),
                                   self.kernel_size, self.stride, 1, self.padding, self.groups, transposed=True,
-                                  **fused)
+                                  width=width, **fused)

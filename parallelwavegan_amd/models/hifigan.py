@@ -4,13 +4,16 @@ Drop-in for ``parallel_wavegan.models.hifigan`` (constructor kwargs, method
 names and state-dict keys follow /root/reference/parallel_wavegan/models/hifigan.py);
 the arithmetic is hand-written HIP behind ``parallelwavegan_amd.ops``.
 """
+import copy
 import logging
 
 import numpy as np
 import torch
 
+from .. import functional as Fn
 from ..layers.activation import FusedActivation
-from ..layers.conv import Conv1d, ConvTranspose1d
+from ..layers.conv import Conv1d, Conv2d, ConvTranspose1d
+from ..layers.pooling import get_pooling
 from ..layers.residual_block import HiFiGANResidualBlock as ResidualBlock
 
 
@@ -135,3 +138,242 @@ class HiFiGANGenerator(torch.nn.Module):
             c = (c - self.mean) / self.scale
         c = self.forward(c.transpose(1, 0).unsqueeze(0).contiguous())
         return c.squeeze(0).transpose(1, 0)
+
+
+class HiFiGANPeriodDiscriminator(torch.nn.Module):
+    """HiFi-GAN period discriminator (reference: models/hifigan.py:270-402).
+
+    The waveform is reflect-padded to a multiple of ``period`` and viewed as (B, 1, T/p, p);
+    every layer is a ``(k, 1)`` Conv2d, executed by the 1-D MFMA kernel with the period as the
+    row width (no transposition, no copy), LeakyReLU fused into the producing kernel's epilogue.
+    Returns the list of the 5 activated feature maps plus the flattened logits.
+    """
+
+    def __init__(self, in_channels=1, out_channels=1, period=3, kernel_sizes=[5, 3], channels=32,
+                 downsample_scales=[3, 3, 3, 3, 1], max_downsample_channels=1024, bias=True,
+                 nonlinear_activation="LeakyReLU", nonlinear_activation_params={"negative_slope": 0.1},
+                 use_weight_norm=True, use_spectral_norm=False):
+        super().__init__()
+        assert len(kernel_sizes) == 2
+        assert kernel_sizes[0] % 2 == 1, "Kernel size must be odd number."
+        assert kernel_sizes[1] % 2 == 1, "Kernel size must be odd number."
+        self.period = period
+        self.convs = torch.nn.ModuleList()
+        in_chs, out_chs = in_channels, channels
+        for scale in downsample_scales:
+            self.convs.append(torch.nn.Sequential(
+                Conv2d(in_chs, out_chs, (kernel_sizes[0], 1), (scale, 1), padding=((kernel_sizes[0] - 1) // 2, 0),
+                       bias=bias),
+                FusedActivation(nonlinear_activation, **nonlinear_activation_params),
+            ))
+            in_chs = out_chs
+            out_chs = min(out_chs * 4, max_downsample_channels)
+        self.output_conv = Conv2d(out_chs, out_channels, (kernel_sizes[1] - 1, 1), (1, 1),
+                                  padding=((kernel_sizes[1] - 1) // 2, 0), bias=bias)
+        if use_weight_norm and use_spectral_norm:
+            raise ValueError("Either use use_weight_norm or use_spectral_norm.")
+        if use_weight_norm:
+            self.apply_weight_norm()
+        if use_spectral_norm:
+            self.apply_spectral_norm()
+
+    def forward(self, x):
+        """x: (B, in_channels, T) -> list of tensors (5 feature maps (B,C,H,p) + logits (B, H'*p))."""
+        b, c, t = x.shape
+        if t % self.period != 0:
+            n_pad = self.period - (t % self.period)
+            x = Fn.pad1d(x, 0, n_pad, "reflect")
+            t += n_pad
+        x = x.reshape(b, c, t // self.period, self.period)
+        outs = []
+        for layer in self.convs:
+            conv, act = layer[0], layer[1]
+            x = conv(x, post_act=act.kind, post_slope=act.slope)
+            outs.append(x)
+        x = self.output_conv(x)
+        outs.append(torch.flatten(x, 1, -1))
+        return outs
+
+    def apply_weight_norm(self):
+        for m in self.modules():
+            if isinstance(m, Conv2d):
+                m.apply_weight_norm()
+                logging.debug(f"Weight norm is applied to {m}.")
+
+    def apply_spectral_norm(self):
+        for m in self.modules():
+            if isinstance(m, Conv2d):
+                m.apply_spectral_norm()
+                logging.debug(f"Spectral norm is applied to {m}.")
+
+
+class HiFiGANMultiPeriodDiscriminator(torch.nn.Module):
+    """HiFi-GAN multi-period discriminator (reference: models/hifigan.py:404-453)."""
+
+    def __init__(self, periods=[2, 3, 5, 7, 11],
+                 discriminator_params={"in_channels": 1, "out_channels": 1, "kernel_sizes": [5, 3], "channels": 32,
+                                       "downsample_scales": [3, 3, 3, 3, 1], "max_downsample_channels": 1024,
+                                       "bias": True, "nonlinear_activation": "LeakyReLU",
+                                       "nonlinear_activation_params": {"negative_slope": 0.1},
+                                       "use_weight_norm": True, "use_spectral_norm": False}):
+        super().__init__()
+        self.discriminators = torch.nn.ModuleList()
+        for period in periods:
+            params = copy.deepcopy(discriminator_params)
+            params["period"] = period
+            self.discriminators.append(HiFiGANPeriodDiscriminator(**params))
+
+    def forward(self, x):
+        return [d(x) for d in self.discriminators]
+
+
+class HiFiGANScaleDiscriminator(torch.nn.Module):
+    """HiFi-GAN scale discriminator (reference: models/hifigan.py:456-702): conv k15, grouped
+    strided convs k41, conv k5, conv k3; LeakyReLU fused into each producing kernel."""
+
+    def __init__(self, in_channels=1, out_channels=1, kernel_sizes=[15, 41, 5, 3], channels=128,
+                 max_downsample_channels=1024, max_groups=16, bias=True, downsample_scales=[2, 2, 4, 4, 1],
+                 nonlinear_activation="LeakyReLU", nonlinear_activation_params={"negative_slope": 0.1},
+                 use_weight_norm=True, use_spectral_norm=False):
+        super().__init__()
+        self.layers = torch.nn.ModuleList()
+        assert len(kernel_sizes) == 4
+        for ks in kernel_sizes:
+            assert ks % 2 == 1
+
+        def act():
+            return FusedActivation(nonlinear_activation, **nonlinear_activation_params)
+
+        self.layers.append(torch.nn.Sequential(
+            Conv1d(in_channels, channels, kernel_sizes[0], bias=bias, padding=(kernel_sizes[0] - 1) // 2), act()))
+        in_chs, out_chs, groups = channels, channels, 4
+        for scale in downsample_scales:
+            self.layers.append(torch.nn.Sequential(
+                Conv1d(in_chs, out_chs, kernel_size=kernel_sizes[1], stride=scale, padding=(kernel_sizes[1] - 1) // 2,
+                       groups=groups, bias=bias), act()))
+            in_chs = out_chs
+            out_chs = min(in_chs * 2, max_downsample_channels)
+            groups = min(groups * 4, max_groups)
+        out_chs = min(in_chs * 2, max_downsample_channels)
+        self.layers.append(torch.nn.Sequential(
+            Conv1d(in_chs, out_chs, kernel_size=kernel_sizes[2], stride=1, padding=(kernel_sizes[2] - 1) // 2,
+                   bias=bias), act()))
+        self.layers.append(Conv1d(out_chs, out_channels, kernel_size=kernel_sizes[3], stride=1,
+                                  padding=(kernel_sizes[3] - 1) // 2, bias=bias))
+        if use_weight_norm and use_spectral_norm:
+            raise ValueError("Either use use_weight_norm or use_spectral_norm.")
+        self.use_weight_norm = use_weight_norm
+        if use_weight_norm:
+            self.apply_weight_norm()
+        self.use_spectral_norm = use_spectral_norm
+        if use_spectral_norm:
+            self.apply_spectral_norm()
+        self._register_load_state_dict_pre_hook(self._load_state_dict_pre_hook)
+
+    def forward(self, x):
+        outs = []
+        for f in self.layers:
+            if isinstance(f, torch.nn.Sequential):
+                conv, act = f[0], f[1]
+                x = conv(x, post_act=act.kind, post_slope=act.slope)
+            else:
+                x = f(x)
+            outs.append(x)
+        return outs
+
+    def _convs(self):
+        return [m for m in self.modules() if isinstance(m, Conv1d)]
+
+    def apply_weight_norm(self):
+        for m in self._convs():
+            m.apply_weight_norm()
+
+    def apply_spectral_norm(self):
+        for m in self._convs():
+            m.apply_spectral_norm()
+
+    def remove_weight_norm(self):
+        for m in self._convs():
+            if m.has_weight_norm:
+                m.remove_weight_norm()
+
+    def remove_spectral_norm(self):
+        for m in self._convs():
+            if m.has_spectral_norm:
+                m.remove_spectral_norm()
+
+    def _load_state_dict_pre_hook(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                  error_msgs):
+        """Checkpoint compatibility (reference: models/hifigan.py:647-702): some published models
+        were trained with a config that asks for weight/spectral norm although none was applied;
+        when the incoming keys show that, drop the norm from this module so the keys match."""
+        keys = [k for k in state_dict.keys() if k.startswith(prefix)]
+        if self.use_weight_norm and not any("weight_g" in k for k in keys):
+            logging.warning("The checkpoint has no weight-norm parameters for the scale discriminator although the "
+                            "config enables it; removing weight norm from the current model to stay compatible "
+                            "(set discriminator_params.follow_official_norm / use_weight_norm to false to silence).")
+            self.remove_weight_norm()
+            self.use_weight_norm = False
+        if self.use_spectral_norm and not any("weight_u" in k for k in keys):
+            logging.warning("The checkpoint has no spectral-norm buffers for the scale discriminator although the "
+                            "config enables it; removing spectral norm from the current model to stay compatible.")
+            self.remove_spectral_norm()
+            self.use_spectral_norm = False
+
+
+class HiFiGANMultiScaleDiscriminator(torch.nn.Module):
+    """HiFi-GAN multi-scale discriminator (reference: models/hifigan.py:705-777)."""
+
+    def __init__(self, scales=3, downsample_pooling="AvgPool1d",
+                 downsample_pooling_params={"kernel_size": 4, "stride": 2, "padding": 2},
+                 discriminator_params={"in_channels": 1, "out_channels": 1, "kernel_sizes": [15, 41, 5, 3],
+                                       "channels": 128, "max_downsample_channels": 1024, "max_groups": 16,
+                                       "bias": True, "downsample_scales": [2, 2, 4, 4, 1],
+                                       "nonlinear_activation": "LeakyReLU",
+                                       "nonlinear_activation_params": {"negative_slope": 0.1}},
+                 follow_official_norm=False):
+        super().__init__()
+        self.discriminators = torch.nn.ModuleList()
+        for i in range(scales):
+            params = copy.deepcopy(discriminator_params)
+            if follow_official_norm:
+                # first scale: spectral norm; the others: weight norm (official implementation)
+                params["use_weight_norm"] = i != 0
+                params["use_spectral_norm"] = i == 0
+            self.discriminators.append(HiFiGANScaleDiscriminator(**params))
+        self.pooling = get_pooling(downsample_pooling, **downsample_pooling_params)
+
+    def forward(self, x):
+        outs = []
+        for f in self.discriminators:
+            outs.append(f(x))
+            x = self.pooling(x)
+        return outs
+
+
+class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
+    """MSD + MPD (reference: models/hifigan.py:780-864); returns msd_outs + mpd_outs."""
+
+    def __init__(self, scales=3, scale_downsample_pooling="AvgPool1d",
+                 scale_downsample_pooling_params={"kernel_size": 4, "stride": 2, "padding": 2},
+                 scale_discriminator_params={"in_channels": 1, "out_channels": 1, "kernel_sizes": [15, 41, 5, 3],
+                                             "channels": 128, "max_downsample_channels": 1024, "max_groups": 16,
+                                             "bias": True, "downsample_scales": [2, 2, 4, 4, 1],
+                                             "nonlinear_activation": "LeakyReLU",
+                                             "nonlinear_activation_params": {"negative_slope": 0.1}},
+                 follow_official_norm=True, periods=[2, 3, 5, 7, 11],
+                 period_discriminator_params={"in_channels": 1, "out_channels": 1, "kernel_sizes": [5, 3],
+                                              "channels": 32, "downsample_scales": [3, 3, 3, 3, 1],
+                                              "max_downsample_channels": 1024, "bias": True,
+                                              "nonlinear_activation": "LeakyReLU",
+                                              "nonlinear_activation_params": {"negative_slope": 0.1},
+                                              "use_weight_norm": True, "use_spectral_norm": False}):
+        super().__init__()
+        self.msd = HiFiGANMultiScaleDiscriminator(
+            scales=scales, downsample_pooling=scale_downsample_pooling,
+            downsample_pooling_params=scale_downsample_pooling_params,
+            discriminator_params=scale_discriminator_params, follow_official_norm=follow_official_norm)
+        self.mpd = HiFiGANMultiPeriodDiscriminator(periods=periods, discriminator_params=period_discriminator_params)
+
+    def forward(self, x):
+        return self.msd(x) + self.mpd(x)

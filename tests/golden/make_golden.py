@@ -62,10 +62,152 @@ def hifigan_generator(name, cfg, batch, frames, seed):
     print(name, "y", tuple(y.shape), "std %.4f max %.4f pre-tanh std %.3f" % (y.std().item(), y.abs().max().item(), pre[0].std().item()))
 
 
+def _load_yaml(name):
+    import yaml
+
+    with open(os.path.join(ref_shim.REF_ROOT, "egs", "ljspeech", "voc1", "conf", name)) as f:
+        return yaml.safe_load(f)
+
+
+def hifigan_discriminator(name, seed):
+    """MSD+MPD outputs in eval mode and after two training-mode calls (spectral-norm state)."""
+    import parallel_wavegan.models as RM
+
+    cfg = _load_yaml("hifigan.v1.yaml")
+    d = RM.HiFiGANMultiScaleMultiPeriodDiscriminator(**cfg["discriminator_params"])
+    d.load_state_dict(synth.synth_state_dict(d.state_dict(), seed=seed, g_scale=1.0))
+    x = 0.5 * synth.synth_input("wave", (2, 1, 8192), seed=seed)
+    out = {}
+    with torch.no_grad():
+        d.eval()
+        o = d(x)
+        out["eval_logits"] = np.concatenate([t[-1].reshape(-1).numpy() for t in o])
+        out["eval_feat_stats"] = np.stack([_stats(f) for t in o for f in t])
+        d.train()
+        d(x)
+        o = d(x)
+        out["train2_logits"] = np.concatenate([t[-1].reshape(-1).numpy() for t in o])
+        out["train2_feat_stats"] = np.stack([_stats(f) for t in o for f in t])
+        out["train2_u0"] = d.msd.discriminators[0].layers[1][0].weight_u.numpy()
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), meta=np.array([2, 8192, seed]), **out)
+    print(name, "logits", out["eval_logits"].shape, float(np.abs(out["eval_logits"]).max()))
+
+
+def losses(name, seed):
+    """Spectral / adversarial / feature-matching losses and their input gradients."""
+    import parallel_wavegan.losses as RL
+
+    cfg = _load_yaml("hifigan.v1.yaml")
+    out = {}
+    y = 0.5 * synth.synth_input("y", (2, 1, 8192), seed=seed)
+    yh = (0.5 * synth.synth_input("yh", (2, 1, 8192), seed=seed)).requires_grad_()
+    mel = RL.MelSpectrogramLoss(**cfg["mel_loss_params"])
+    l = mel(yh, y)
+    l.backward()
+    out["mel_loss"], out["mel_grad"] = l.item(), yh.grad.numpy().copy()
+    out["mel_spec"] = mel.mel_spectrogram(y).detach().numpy()
+    # LibriTTS mel loss (n_fft 2048, hop 300, win 1200)
+    mel2 = RL.MelSpectrogramLoss(fs=24000, fft_size=2048, hop_size=300, win_length=1200, window="hann", num_mels=80,
+                                 fmin=0, fmax=12000, log_base=None)
+    yh.grad = None
+    t84 = slice(0, 8100)
+    l = mel2(yh[..., t84], y[..., t84])
+    l.backward()
+    out["mel2_loss"], out["mel2_grad"] = l.item(), yh.grad.numpy().copy()
+    # full-band multi-resolution STFT loss (PWG / MB-MelGAN) and the sub-band variant
+    for tag, kw, shape in [("stft", dict(), (2, 6000)),
+                           ("substft", dict(fft_sizes=[384, 683, 171], hop_sizes=[30, 60, 10],
+                                            win_lengths=[150, 300, 60]), (2, 4, 1500))]:
+        st = RL.MultiResolutionSTFTLoss(**kw)
+        a = (0.5 * synth.synth_input(tag + "x", shape, seed=seed)).requires_grad_()
+        b = 0.5 * synth.synth_input(tag + "y", shape, seed=seed)
+        sc, mag = st(a, b)
+        (sc + mag).backward()
+        out[tag + "_sc"], out[tag + "_mag"], out[tag + "_grad"] = sc.item(), mag.item(), a.grad.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), meta=np.array([seed]), **out)
+    print(name, {k: (v if np.isscalar(v) else v.shape) for k, v in out.items()})
+
+
+def hifigan_train_steps(name, seed, batch=2, n_steps=2):
+    """Two full ``Trainer._train_step`` calls of the reference (HiFi-GAN V1 YAML, G+D active)."""
+    import tempfile
+
+    import parallel_wavegan.losses as RL
+    import parallel_wavegan.models as RM
+    from parallel_wavegan.bin.train import Trainer
+
+    cfg = _load_yaml("hifigan.v1.yaml")
+    g = RM.HiFiGANGenerator(**cfg["generator_params"])
+    d = RM.HiFiGANMultiScaleMultiPeriodDiscriminator(**cfg["discriminator_params"])
+    g.load_state_dict(synth.synth_state_dict(g.state_dict(), seed=seed, g_scale=G_SCALE))
+    d.load_state_dict(synth.synth_state_dict(d.state_dict(), seed=seed + 1, g_scale=1.0))
+    model = {"generator": g, "discriminator": d}
+    criterion = {
+        "gen_adv": RL.GeneratorAdversarialLoss(**cfg["generator_adv_loss_params"]),
+        "dis_adv": RL.DiscriminatorAdversarialLoss(**cfg["discriminator_adv_loss_params"]),
+        "mel": RL.MelSpectrogramLoss(**cfg["mel_loss_params"]),
+        "feat_match": RL.FeatureMatchLoss(**cfg["feat_match_loss_params"]),
+    }
+    optimizer = {
+        "generator": torch.optim.Adam(g.parameters(), **cfg["generator_optimizer_params"]),
+        "discriminator": torch.optim.Adam(d.parameters(), **cfg["discriminator_optimizer_params"]),
+    }
+    scheduler = {
+        k: torch.optim.lr_scheduler.MultiStepLR(optimizer[k], **cfg[f"{k}_scheduler_params"])
+        for k in ("generator", "discriminator")
+    }
+    c = synth.synth_input("c", (batch, 80, 32), seed=seed)
+    y = 0.5 * synth.synth_input("y", (batch, 1, 8192), seed=seed)
+    batches = [((c,), y)] * n_steps
+    cfg.update(distributed=False, rank=0, outdir=tempfile.mkdtemp(), train_max_steps=2 + n_steps,
+               save_interval_steps=10 ** 9, eval_interval_steps=10 ** 9, log_interval_steps=10 ** 9,
+               use_stft_loss=False, use_subband_stft_loss=False)
+    tr = Trainer(steps=2, epochs=0, data_loader={"train": batches, "dev": batches},
+                 sampler={"train": None, "dev": None}, model=model, criterion=criterion, optimizer=optimizer,
+                 scheduler=scheduler, config=cfg, device=torch.device("cpu"))
+    out = {}
+    from tqdm import tqdm
+
+    tr.tqdm = tqdm(disable=True)
+    prev = {}
+    for i in range(n_steps):
+        tr._train_step(batches[i])
+        cur = dict(tr.total_train_loss)
+        for k, v in cur.items():
+            out[f"step{i}/{k}"] = v - prev.get(k, 0.0)
+        prev = cur
+        if i == 0:
+            # first moments after step 1 = (1 - beta1) * gradient: pins every parameter gradient
+            for key in ("generator", "discriminator"):
+                st = optimizer[key].state
+                names = {p: n for n, p in model[key].named_parameters()}
+                norms = {names[p]: float(s["exp_avg"].double().norm()) for p, s in st.items()}
+                out[f"gradnorm_names/{key}"] = np.array(sorted(norms))
+                out[f"gradnorm/{key}"] = np.array([norms[k] for k in sorted(norms)])
+            out["grad/g/output_conv.1.weight_v"] = optimizer["generator"].state[g.output_conv[1].weight_v]["exp_avg"].numpy().copy()
+            out["grad/g/input_conv.bias"] = optimizer["generator"].state[g.input_conv.bias]["exp_avg"].numpy().copy()
+            out["grad/d/msd.discriminators.0.layers.0.0.weight_orig"] = optimizer["discriminator"].state[
+                d.msd.discriminators[0].layers[0][0].weight_orig]["exp_avg"].numpy().copy()
+            out["grad/d/mpd.discriminators.4.convs.0.0.weight_v"] = optimizer["discriminator"].state[
+                d.mpd.discriminators[4].convs[0][0].weight_v]["exp_avg"].numpy().copy()
+    for key, m in (("g", g), ("d", d)):
+        sd = m.state_dict()
+        names = sorted(sd)
+        out[f"final_names/{key}"] = np.array(names)
+        out[f"final_sum/{key}"] = np.array([float(sd[n].double().sum()) for n in names])
+    out["final/g/output_conv.1.weight_v"] = g.output_conv[1].weight_v.detach().numpy().copy()
+    out["final/g/input_conv.bias"] = g.input_conv.bias.detach().numpy().copy()
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), meta=np.array([batch, n_steps, seed]), g_scale=np.float64(G_SCALE), **out)
+    print(name, {k: round(float(v), 6) for k, v in out.items() if k.startswith("step")})
+
+
 JOBS = {
     "hifigan_v1_g": lambda: hifigan_generator("hifigan_v1_g", synth.HIFIGAN_V1, 2, 32, 11),
     "hifigan_v1_libritts_g": lambda: hifigan_generator("hifigan_v1_libritts_g", synth.HIFIGAN_V1_LIBRITTS, 1, 28, 12),
     "hifigan_tiny_g": lambda: hifigan_generator("hifigan_tiny_g", synth.HIFIGAN_TINY, 3, 21, 13),
+    "hifigan_v1_d": lambda: hifigan_discriminator("hifigan_v1_d", 21),
+    "losses": lambda: losses("losses", 31),
+    "hifigan_v1_train": lambda: hifigan_train_steps("hifigan_v1_train", 41),
 }
 
 if __name__ == "__main__":

@@ -23,8 +23,13 @@ def synth_tensor(name, shape, seed=0, g_scale=1.0):
     leaf = name.rsplit(".", 1)[-1]
     if leaf == "weight_g":
         a = g_scale * (1.0 + 0.1 * r.standard_normal(shape))
+    elif leaf == "weight_v" and len(shape) == 1:  # spectral-norm right singular vector estimate
+        a = r.standard_normal(shape)
+        a = a / np.linalg.norm(a)
     elif leaf in ("weight_v", "weight_orig"):
         a = r.standard_normal(shape)
+        if leaf == "weight_orig":
+            a = g_scale * a / np.sqrt(max(int(np.prod(shape[1:])), 1))
     elif leaf == "weight":
         fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else 1
         a = g_scale * r.standard_normal(shape) / np.sqrt(max(fan_in, 1))
@@ -50,6 +55,20 @@ def synth_state_dict(shapes, seed=0, g_scale=1.0, skip=()):
             continue
         shp = tuple(shp.shape) if hasattr(shp, "shape") else tuple(shp)
         out[name] = synth_tensor(name, shp, seed, g_scale)
+    # spectral-norm triplets: make (u, v) a converged singular-vector estimate of weight_orig, as a
+    # trained checkpoint would hold (a random u, v gives an arbitrary sigma = u^T W v in eval mode)
+    for name in [n for n in out if n.endswith(".weight_orig")]:
+        base = name[: -len("weight_orig")]
+        if base + "weight_u" in out and base + "weight_v" in out:
+            w = out[name].double().numpy().reshape(out[name].shape[0], -1)
+            u = out[base + "weight_u"].double().numpy()
+            for _ in range(30):
+                v = w.T @ u
+                v /= np.linalg.norm(v)
+                u = w @ v
+                u /= np.linalg.norm(u)
+            out[base + "weight_u"] = torch.from_numpy(u.astype(np.float32))
+            out[base + "weight_v"] = torch.from_numpy(v.astype(np.float32))
     return out
 
 

@@ -1,0 +1,91 @@
+"""GPU parity: HiFi-GAN MSD+MPD forward vs the reference's golden vectors and the oracle."""
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from oracle import torch_cpu
+from parallelwavegan_amd.models import HiFiGANMultiScaleMultiPeriodDiscriminator
+from tests.golden import synth
+from tests.util import load_golden, max_abs
+
+pytestmark = pytest.mark.gpu
+
+D_PARAMS = yaml.safe_load("""
+scales: 3
+scale_downsample_pooling: "AvgPool1d"
+scale_downsample_pooling_params: {kernel_size: 4, stride: 2, padding: 2}
+scale_discriminator_params:
+    in_channels: 1
+    out_channels: 1
+    kernel_sizes: [15, 41, 5, 3]
+    channels: 128
+    max_downsample_channels: 1024
+    max_groups: 16
+    bias: true
+    downsample_scales: [4, 4, 4, 4, 1]
+    nonlinear_activation: "LeakyReLU"
+    nonlinear_activation_params: {negative_slope: 0.1}
+follow_official_norm: true
+periods: [2, 3, 5, 7, 11]
+period_discriminator_params:
+    in_channels: 1
+    out_channels: 1
+    kernel_sizes: [5, 3]
+    channels: 32
+    downsample_scales: [3, 3, 3, 3, 1]
+    max_downsample_channels: 1024
+    bias: true
+    nonlinear_activation: "LeakyReLU"
+    nonlinear_activation_params: {negative_slope: 0.1}
+    use_weight_norm: true
+    use_spectral_norm: false
+""")
+
+
+def _stats(t):
+    t = t.detach().cpu().double()
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()])
+
+
+def test_msmpd_matches_reference_golden(device):
+    gold = load_golden("hifigan_v1_d")
+    _, t, seed = (int(v) for v in gold["meta"])
+    d = HiFiGANMultiScaleMultiPeriodDiscriminator(**D_PARAMS)
+    d.load_state_dict(synth.synth_state_dict(d.state_dict(), seed=seed, g_scale=1.0))
+    d = d.to(device)
+    x = (0.5 * synth.synth_input("wave", (2, 1, t), seed=seed)).to(device)
+    with torch.no_grad():
+        d.eval()
+        o = d(x)
+        logits = np.concatenate([t_[-1].reshape(-1).cpu().numpy() for t_ in o])
+        scale = np.abs(gold["eval_logits"]).max()
+        assert np.abs(logits - gold["eval_logits"]).max() <= 2e-5 * max(scale, 1.0)
+        st = np.stack([_stats(f) for t_ in o for f in t_])
+        np.testing.assert_allclose(st[:, 1:], gold["eval_feat_stats"][:, 1:], rtol=2e-5)
+        # two training-mode calls: spectral-norm power iterations update u, v like the hook does
+        d.train()
+        d(x)
+        o = d(x)
+        logits = np.concatenate([t_[-1].reshape(-1).cpu().numpy() for t_ in o])
+        assert np.abs(logits - gold["train2_logits"]).max() <= 2e-5 * max(scale, 1.0)
+        u0 = d.msd.discriminators[0].layers[1][0].weight_u.cpu().numpy()
+        assert np.abs(u0 - gold["train2_u0"]).max() <= 1e-5
+
+
+@pytest.mark.parametrize("t,batch", [(8192, 2), (2051, 1), (4097, 3)])
+def test_msmpd_matches_oracle_feature_maps(t, batch, device):
+    d = HiFiGANMultiScaleMultiPeriodDiscriminator(**D_PARAMS)
+    sd = synth.synth_state_dict(d.state_dict(), seed=7, g_scale=1.0)
+    d.load_state_dict(sd)
+    d = d.to(device).eval()
+    x = 0.5 * synth.synth_input("wave", (batch, 1, t), seed=t)
+    with torch.no_grad():
+        mine = d(x.to(device))
+        ref = torch_cpu.hifigan_msmpd(dict(sd), x, training=False, **D_PARAMS)
+    assert len(mine) == len(ref) == 8
+    for dm, dr in zip(mine, ref):
+        assert len(dm) == len(dr)
+        for a, b in zip(dm, dr):
+            assert tuple(a.shape) == tuple(b.shape)
+            assert max_abs(a, b) <= 3e-5 * max(1.0, b.abs().max().item())

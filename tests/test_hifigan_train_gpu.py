@@ -1,0 +1,115 @@
+"""GPU parity of the full HiFi-GAN V1 training step (G + D phases, losses, Adam updates)
+against two steps of the reference's own Trainer (tests/golden/hifigan_v1_train.npz)."""
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from parallelwavegan_amd import losses, optimizers
+from parallelwavegan_amd.bin.train import Trainer
+from parallelwavegan_amd.models import HiFiGANGenerator, HiFiGANMultiScaleMultiPeriodDiscriminator
+from tests.golden import synth
+from tests.test_discriminator_gpu import D_PARAMS
+from tests.test_losses_gpu import MEL_PARAMS
+from tests.util import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def build_trainer(device, seed, g_scale, batch, n_steps, distributed=False):
+    g = HiFiGANGenerator(**synth.HIFIGAN_V1)
+    d = HiFiGANMultiScaleMultiPeriodDiscriminator(**D_PARAMS)
+    g.load_state_dict(synth.synth_state_dict(g.state_dict(), seed=seed, g_scale=g_scale))
+    d.load_state_dict(synth.synth_state_dict(d.state_dict(), seed=seed + 1, g_scale=1.0))
+    model = {"generator": g.to(device), "discriminator": d.to(device)}
+    criterion = {
+        "gen_adv": losses.GeneratorAdversarialLoss(average_by_discriminators=False),
+        "dis_adv": losses.DiscriminatorAdversarialLoss(average_by_discriminators=False),
+        "mel": losses.MelSpectrogramLoss(**MEL_PARAMS).to(device),
+        "feat_match": losses.FeatureMatchLoss(average_by_discriminators=False, average_by_layers=False,
+                                              include_final_outputs=False),
+    }
+    opt = {k: optimizers.Adam(model[k].parameters(), lr=2.0e-4, betas=(0.5, 0.9), weight_decay=0.0)
+           for k in ("generator", "discriminator")}
+    sched = {k: optimizers.lr_scheduler.MultiStepLR(opt[k], gamma=0.5, milestones=[200000, 400000, 600000, 800000])
+             for k in ("generator", "discriminator")}
+    config = dict(generator_type="HiFiGANGenerator", generator_params=synth.HIFIGAN_V1, use_stft_loss=False,
+                  use_subband_stft_loss=False, use_mel_loss=True, use_feat_match_loss=True, lambda_aux=45.0,
+                  lambda_adv=1.0, lambda_feat_match=2.0, generator_grad_norm=-1, discriminator_grad_norm=-1,
+                  generator_train_start_steps=1, discriminator_train_start_steps=0, train_max_steps=2 + n_steps,
+                  save_interval_steps=10 ** 9, eval_interval_steps=10 ** 9, log_interval_steps=10 ** 9,
+                  distributed=distributed, rank=0, outdir=tempfile.mkdtemp(), progress=False)
+    c = synth.synth_input("c", (batch, 80, 32), seed=seed)
+    y = 0.5 * synth.synth_input("y", (batch, 1, 8192), seed=seed)
+    batches = [((c,), y)] * n_steps
+    tr = Trainer(steps=2, epochs=0, data_loader={"train": batches, "dev": batches},
+                 sampler={"train": None, "dev": None}, model=model, criterion=criterion, optimizer=opt,
+                 scheduler=sched, config=config, device=device)
+    return tr, batches, model, opt
+
+
+def test_two_train_steps_match_reference_trainer(device):
+    gold = load_golden("hifigan_v1_train")
+    batch, n_steps, seed = (int(v) for v in gold["meta"])
+    tr, batches, model, opt = build_trainer(device, seed, float(gold["g_scale"]), batch, n_steps)
+    tr.tqdm = None
+    prev = {}
+    for i in range(n_steps):
+        tr._train_step(batches[i])
+        tr._flush_pending()
+        cur = dict(tr.total_train_loss)
+        for k, v in cur.items():
+            want = float(gold[f"step{i}/{k}"])
+            got = v - prev.get(k, 0.0)
+            tol = (1e-4 if i == 0 else 2e-3) * max(abs(want), 1e-3)
+            assert abs(got - want) <= tol, (i, k, got, want)
+        prev = cur
+        if i == 0:
+            # exp_avg after the first step = (1 - beta1) * grad  -> every parameter gradient is pinned
+            for key, tag in (("generator", "g"), ("discriminator", "d")):
+                names = {p: n for n, p in model[key].named_parameters()}
+                norms = {names[p]: float(s["exp_avg"].double().norm()) for p, s in opt[key].state.items()}
+                gnames = [str(n) for n in gold[f"gradnorm_names/{key}"]]
+                assert sorted(norms) == gnames
+                got = np.array([norms[n] for n in gnames])
+                want = gold[f"gradnorm/{key}"]
+                rel = np.abs(got - want) / (np.abs(want) + 1e-12 + 1e-6 * np.abs(want).max())
+                assert rel.max() <= 2e-3, (key, gnames[int(rel.argmax())], rel.max())
+            g, d = model["generator"], model["discriminator"]
+            checks = {
+                "grad/g/output_conv.1.weight_v": opt["generator"].state[g.output_conv[1].weight_v]["exp_avg"],
+                "grad/g/input_conv.bias": opt["generator"].state[g.input_conv.bias]["exp_avg"],
+                "grad/d/msd.discriminators.0.layers.0.0.weight_orig":
+                    opt["discriminator"].state[d.msd.discriminators[0].layers[0][0].weight_orig]["exp_avg"],
+                "grad/d/mpd.discriminators.4.convs.0.0.weight_v":
+                    opt["discriminator"].state[d.mpd.discriminators[4].convs[0][0].weight_v]["exp_avg"],
+            }
+            for k, t in checks.items():
+                want = gold[k]
+                err = np.abs(t.cpu().numpy() - want).max() / (np.abs(want).max() + 1e-30)
+                assert err <= 2e-3, (k, err)
+    # parameters after two Adam steps
+    for key, tag in (("generator", "g"), ("discriminator", "d")):
+        sd = model[key].state_dict()
+        names = [str(n) for n in gold[f"final_names/{tag}"]]
+        assert sorted(sd) == names
+    g = model["generator"]
+    assert np.abs(g.input_conv.bias.detach().cpu().numpy() - gold["final/g/input_conv.bias"]).max() <= 5e-5
+
+
+def test_checkpoint_round_trip(device, tmp_path):
+    tr, batches, model, opt = build_trainer(device, 5, 1.25, 1, 1)
+    tr.tqdm = None
+    tr._train_step(batches[0])
+    path = str(tmp_path / "checkpoint-3steps.pkl")
+    tr.save_checkpoint(path)
+    ck = torch.load(path, map_location="cpu")
+    assert set(ck) == {"optimizer", "scheduler", "steps", "epochs", "model"}
+    assert set(ck["model"]) == {"generator", "discriminator"} and ck["steps"] == 3
+    tr2, _, model2, _ = build_trainer(device, 6, 1.0, 1, 1)
+    tr2.load_checkpoint(path)
+    assert tr2.steps == 3
+    for k in ("generator", "discriminator"):
+        for (n1, p1), (n2, p2) in zip(model[k].state_dict().items(), model2[k].state_dict().items()):
+            assert n1 == n2 and torch.equal(p1.cpu(), p2.cpu())

@@ -1,0 +1,83 @@
+"""GPU parity of the loss modules (values AND input gradients) vs the reference's golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_cpu
+from parallelwavegan_amd import losses
+from tests.golden import synth
+from tests.util import load_golden, max_abs
+
+pytestmark = pytest.mark.gpu
+
+MEL_PARAMS = dict(fs=22050, fft_size=1024, hop_size=256, win_length=None, window="hann", num_mels=80, fmin=0,
+                  fmax=11025, log_base=None)
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+
+
+def test_mel_loss_matches_reference_golden(device):
+    gold = load_golden("losses")
+    seed = int(gold["meta"][0])
+    y = (0.5 * synth.synth_input("y", (2, 1, 8192), seed=seed)).to(device)
+    yh = (0.5 * synth.synth_input("yh", (2, 1, 8192), seed=seed)).to(device).requires_grad_()
+    crit = losses.MelSpectrogramLoss(**MEL_PARAMS).to(device)
+    loss = crit(yh, y)
+    loss.backward()
+    assert abs(loss.item() - float(gold["mel_loss"])) <= 2e-5 * float(gold["mel_loss"])
+    assert _rel(yh.grad.cpu().numpy(), gold["mel_grad"]) <= 2e-4
+    with torch.no_grad():
+        spec = crit.mel_spectrogram(y)
+    assert max_abs(spec, gold["mel_spec"]) <= 2e-4  # log-mel values are O(1..10)
+    # LibriTTS parameters: n_fft 2048, hop 300, window 1200 (window shorter than the FFT)
+    crit2 = losses.MelSpectrogramLoss(fs=24000, fft_size=2048, hop_size=300, win_length=1200, window="hann",
+                                      num_mels=80, fmin=0, fmax=12000, log_base=None).to(device)
+    yh.grad = None
+    loss2 = crit2(yh[..., :8100], y[..., :8100])
+    loss2.backward()
+    assert abs(loss2.item() - float(gold["mel2_loss"])) <= 2e-5 * float(gold["mel2_loss"])
+    assert _rel(yh.grad.cpu().numpy(), gold["mel2_grad"]) <= 2e-4
+
+
+@pytest.mark.parametrize("tag,kw,shape", [
+    ("stft", dict(), (2, 6000)),
+    ("substft", dict(fft_sizes=[384, 683, 171], hop_sizes=[30, 60, 10], win_lengths=[150, 300, 60]), (2, 4, 1500)),
+])
+def test_multi_resolution_stft_loss_matches_reference_golden(tag, kw, shape, device):
+    gold = load_golden("losses")
+    seed = int(gold["meta"][0])
+    a = (0.5 * synth.synth_input(tag + "x", shape, seed=seed)).to(device).requires_grad_()
+    b = (0.5 * synth.synth_input(tag + "y", shape, seed=seed)).to(device)
+    crit = losses.MultiResolutionSTFTLoss(**kw).to(device)
+    sc, mag = crit(a, b)
+    (sc + mag).backward()
+    assert abs(sc.item() - float(gold[tag + "_sc"])) <= 2e-5 * float(gold[tag + "_sc"])
+    assert abs(mag.item() - float(gold[tag + "_mag"])) <= 2e-5 * float(gold[tag + "_mag"])
+    assert _rel(a.grad.cpu().numpy(), gold[tag + "_grad"]) <= 3e-4
+
+
+def test_adversarial_and_feature_match_losses_vs_oracle(device):
+    g = torch.Generator().manual_seed(3)
+    feats_hat = [[torch.randn(2, 4, 50, generator=g), torch.randn(2, 8, 20, generator=g), torch.randn(2, 1, 9, generator=g)]
+                 for _ in range(3)]
+    feats = [[torch.randn_like(t) for t in fl] for fl in feats_hat]
+    fh_d = [[t.to(device).requires_grad_() for t in fl] for fl in feats_hat]
+    f_d = [[t.to(device) for t in fl] for fl in feats]
+    fh_c = [[t.clone().requires_grad_() for t in fl] for fl in feats_hat]
+    for avg in (True, False):
+        ga = losses.GeneratorAdversarialLoss(average_by_discriminators=avg)(fh_d)
+        da_real, da_fake = losses.DiscriminatorAdversarialLoss(average_by_discriminators=avg)(fh_d, f_d)
+        fm = losses.FeatureMatchLoss(average_by_layers=avg, average_by_discriminators=avg)(fh_d, f_d)
+        ga_r = torch_cpu.generator_adversarial_loss(fh_c, avg)
+        dr_r, df_r = torch_cpu.discriminator_adversarial_loss(fh_c, feats, avg)
+        fm_r = torch_cpu.feature_match_loss(fh_c, feats, avg, avg)
+        for mine, ref in ((ga, ga_r), (da_real, dr_r), (da_fake, df_r), (fm, fm_r)):
+            assert abs(mine.item() - ref.item()) <= 1e-5 * max(1.0, abs(ref.item()))
+    (ga + fm).backward()
+    (ga_r + fm_r).backward()
+    for a_l, b_l in zip(fh_d, fh_c):
+        for a, b in zip(a_l, b_l):
+            assert max_abs(a.grad, b.grad) <= 1e-6
