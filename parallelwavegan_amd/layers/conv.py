@@ -162,7 +162,7 @@ class _ConvNd(torch.nn.Module):
         ps = [self.raw_weight] + ([self.weight_g] if self.has_weight_norm else [])
         if self.has_spectral_norm:
             ps += [self.weight_u, self.weight_v]
-        return tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
+        return (ops.PARAM_EPOCH[0],) + tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
 
     def packed_weight(self):
         """Cached forward weight image (no-grad path)."""

@@ -59,7 +59,8 @@ class STFTMagnitude(torch.nn.Module):
         self._fused = dict(pre_act=None, pre_slope=0.0, post_act=None, post_slope=0.0, out_mul=1.0, out_div=1.0)
 
     def frames(self, t):
-        return 1 + t // self.hop_size
+        # torch.stft(center=True): the signal is padded by n_fft // 2 on both sides (odd n_fft loses one)
+        return 1 + (t + 2 * (self.fft_size // 2) - self.fft_size) // self.hop_size
 
     def spectrum(self, x):
         """x: (B, T) -> (B, 2*bins, frames) [real rows | imaginary rows]."""

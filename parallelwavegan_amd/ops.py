@@ -14,6 +14,15 @@ ACT = {None: _lib.PWG_ACT_NONE, "none": _lib.PWG_ACT_NONE, "leaky_relu": _lib.PW
 PAD = {"zero": _lib.PWG_PAD_ZERO, "reflect": _lib.PWG_PAD_REFLECT, "replicate": _lib.PWG_PAD_REPLICATE}
 
 
+# Parameters updated through raw pointers (fused optimizer kernels) do not bump torch's version
+# counters; every such update bumps this epoch instead, and the packed-weight caches key on it.
+PARAM_EPOCH = [0]
+
+
+def bump_param_epoch():
+    PARAM_EPOCH[0] += 1
+
+
 def _require_device(*tensors):
     for t in tensors:
         if t is None:

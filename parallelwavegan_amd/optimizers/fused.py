@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from .. import _lib
-from ..ops import _stream
+from ..ops import _stream, bump_param_epoch
 
 CHUNK = 65536
 
@@ -101,6 +101,7 @@ class Adam(_FusedBase):
                                              float(b2), float(group["eps"]), float(group["weight_decay"]), step,
                                              float(self.grad_scale), _stream()), "adam_step")
                 self._keep = table  # the launch is asynchronous: keep the table alive until the next step
+        bump_param_epoch()  # parameters changed behind torch's back: invalidate packed-weight caches
         return loss
 
 
@@ -136,6 +137,7 @@ class RAdam(_FusedBase):
                                               float(b2), float(group["eps"]), float(group["weight_decay"]), step,
                                               float(self.grad_scale), _stream()), "radam_step")
                 self._keep = table
+        bump_param_epoch()
         return loss
 
 

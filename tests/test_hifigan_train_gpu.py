@@ -62,7 +62,7 @@ def test_two_train_steps_match_reference_trainer(device):
         for k, v in cur.items():
             want = float(gold[f"step{i}/{k}"])
             got = v - prev.get(k, 0.0)
-            tol = (1e-4 if i == 0 else 2e-3) * max(abs(want), 1e-3)
+            tol = 1e-4 * max(abs(want), 1e-3)  # two CPU runs of the reference differ by ~5e-6
             assert abs(got - want) <= tol, (i, k, got, want)
         prev = cur
         if i == 0:
