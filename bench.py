@@ -94,6 +94,152 @@ def cpu_baseline(budget_s=12.0):
     }
 
 
+
+HIFIGAN_V1_D = dict(
+    scales=3, scale_downsample_pooling="AvgPool1d",
+    scale_downsample_pooling_params=dict(kernel_size=4, stride=2, padding=2),
+    scale_discriminator_params=dict(in_channels=1, out_channels=1, kernel_sizes=[15, 41, 5, 3], channels=128,
+                                    max_downsample_channels=1024, max_groups=16, bias=True,
+                                    downsample_scales=[4, 4, 4, 4, 1], nonlinear_activation="LeakyReLU",
+                                    nonlinear_activation_params=dict(negative_slope=0.1)),
+    follow_official_norm=True, periods=[2, 3, 5, 7, 11],
+    period_discriminator_params=dict(in_channels=1, out_channels=1, kernel_sizes=[5, 3], channels=32,
+                                     downsample_scales=[3, 3, 3, 3, 1], max_downsample_channels=1024, bias=True,
+                                     nonlinear_activation="LeakyReLU",
+                                     nonlinear_activation_params=dict(negative_slope=0.1), use_weight_norm=True,
+                                     use_spectral_norm=False),
+)
+MEL_LOSS = dict(fs=22050, fft_size=1024, hop_size=256, win_length=None, window="hann", num_mels=80, fmin=0,
+                fmax=11025, log_base=None)
+# fwd = 1x, bwd = 2x, incl. the second no-grad G pass and the no-grad D(real) pass:
+# per item 4 * G(32 frames) + 10 * D(8192 samples)
+TRAIN_GFLOP_PER_ITEM = 4 * 19.65 + 10 * 12.08
+
+
+def cpu_train_baseline(budget_steps=2):
+    """oracle.train_step (torch CPU restatement of Trainer._train_step) on a B=2 slice of the
+    same workload; reported as steps/s scaled to the full batch of 16."""
+    from oracle.train_step import HiFiGANTrainState
+    from parallelwavegan_amd.models import HiFiGANGenerator, HiFiGANMultiScaleMultiPeriodDiscriminator
+
+    cores = os.cpu_count() or 1
+    nthreads = min(cores, 32)
+    torch.set_num_threads(nthreads)
+    g = HiFiGANGenerator(**HIFIGAN_V1)
+    d = HiFiGANMultiScaleMultiPeriodDiscriminator(**HIFIGAN_V1_D)
+    st = HiFiGANTrainState({k: v.detach() for k, v in g.state_dict().items()},
+                           {k: v.detach() for k, v in d.state_dict().items()}, HIFIGAN_V1, HIFIGAN_V1_D, MEL_LOSS)
+    b = 2
+    c, y = torch.randn(b, 80, 32), 0.3 * torch.randn(b, 1, 8192)
+    st.step(c, y)  # warm-up
+    t0 = time.time()
+    for _ in range(budget_steps):
+        st.step(c, y)
+    dt = (time.time() - t0) / budget_steps
+    return {
+        "value": 1.0 / (dt * 16 / b),
+        "unit": "steps/s (B=16 x 8192, extrapolated linearly from B=2)",
+        "cores": nthreads,
+        "kind": "port",
+        "sample": f"oracle.train_step.HiFiGANTrainState.step, B={b} x 8192 samples, {budget_steps} timed steps "
+                  f"({dt:.2f} s each), {nthreads} of {cores} host threads",
+    }
+
+
+def bench_train(args, dev, rank, world, dist):
+    """HiFi-GAN V1 LJSpeech training step (configs[2] / C3): B=16 x 8192 samples per GPU, both the
+    generator and the discriminator phase active, mel loss + adversarial + feature matching, Adam."""
+    import tempfile
+
+    from parallelwavegan_amd import losses, ops, optimizers
+    from parallelwavegan_amd.bin.train import Trainer
+    from parallelwavegan_amd.models import HiFiGANGenerator, HiFiGANMultiScaleMultiPeriodDiscriminator
+
+    torch.manual_seed(4321)
+    model = {"generator": HiFiGANGenerator(**HIFIGAN_V1).to(dev),
+             "discriminator": HiFiGANMultiScaleMultiPeriodDiscriminator(**HIFIGAN_V1_D).to(dev)}
+    criterion = {
+        "gen_adv": losses.GeneratorAdversarialLoss(average_by_discriminators=False),
+        "dis_adv": losses.DiscriminatorAdversarialLoss(average_by_discriminators=False),
+        "mel": losses.MelSpectrogramLoss(**MEL_LOSS).to(dev),
+        "feat_match": losses.FeatureMatchLoss(average_by_discriminators=False, average_by_layers=False,
+                                              include_final_outputs=False),
+    }
+    opt = {k: optimizers.Adam(model[k].parameters(), lr=2.0e-4, betas=(0.5, 0.9), weight_decay=0.0)
+           for k in ("generator", "discriminator")}
+    sched = {k: optimizers.lr_scheduler.MultiStepLR(opt[k], gamma=0.5, milestones=[200000, 400000, 600000, 800000])
+             for k in ("generator", "discriminator")}
+    steps, warmup = args.train_steps, args.train_warmup
+    config = dict(generator_type="HiFiGANGenerator", generator_params=HIFIGAN_V1, use_stft_loss=False,
+                  use_subband_stft_loss=False, use_mel_loss=True, use_feat_match_loss=True, lambda_aux=45.0,
+                  lambda_adv=1.0, lambda_feat_match=2.0, generator_grad_norm=-1, discriminator_grad_norm=-1,
+                  generator_train_start_steps=0, discriminator_train_start_steps=0,
+                  train_max_steps=10 ** 9, save_interval_steps=10 ** 9, eval_interval_steps=10 ** 9,
+                  log_interval_steps=10 ** 9, distributed=world > 1, rank=rank, outdir=tempfile.mkdtemp(),
+                  progress=False)
+    gen = torch.Generator(device="cpu").manual_seed(200 + rank)
+    b, t = args.train_batch, 8192
+    c = torch.randn(b, 80, t // 256, generator=gen).to(dev)
+    y = (0.3 * torch.randn(b, 1, t, generator=gen)).to(dev)
+    batch = ((c,), y)
+    tr = Trainer(steps=1, epochs=0, data_loader={"train": [batch], "dev": [batch]},
+                 sampler={"train": None, "dev": None}, model=model, criterion=criterion, optimizer=opt,
+                 scheduler=sched, config=config, device=dev)
+    tr.tqdm = None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        tr._train_step(batch)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr._train_step(batch)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    tr._flush_pending()
+    finite = all(v == v and abs(v) != float("inf") for v in tr.total_train_loss.values())
+    out = None
+    if rank == 0:
+        with ops.profile() as prof:
+            tr._train_step(batch)
+        tot_ms = sum(v["ms"] for v in prof.results.values())
+        kern = {k: {"ms_per_step": round(v["ms"], 3), "launches": v["launches"],
+                    "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
+                    "GBps_algorithmic": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
+                for k, v in sorted(prof.results.items(), key=lambda kv: -kv[1]["ms"])}
+        flops_step = TRAIN_GFLOP_PER_ITEM * 1e9 * b
+        out = {
+            "metric": "HiFi-GAN V1 LJSpeech training steps/s (G+D phases, B=16 x 8192 per GPU)",
+            "value": steps / elapsed,
+            "unit": "steps/s",
+            "ms_per_step": elapsed / steps * 1e3,
+            "steps": steps,
+            "warmup": warmup,
+            "batch_per_gpu": b,
+            "global_batch": b * world,
+            "segments_per_s": b * world * steps / elapsed,
+            "scaling": "weak",
+            "parallelism": f"dp{world}" if world > 1 else "single",
+            "losses_finite": finite,
+            "algorithmic_TFLOP_per_step_per_gpu": flops_step / 1e12,
+            "achieved_TFLOPs_per_gpu": flops_step / (elapsed / steps) / 1e12,
+            "frac_of_fp32_matrix_peak": flops_step / (elapsed / steps) / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
+            "kernel_time_ms_per_step": round(tot_ms, 3),
+            "kernels": kern,
+        }
+    for r in (tr.reducers or {}).values():
+        r.remove()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,11 +248,16 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="utterances per step per GPU")
     ap.add_argument("--frames", type=int, default=800, help="mel frames per utterance (800 = 9.3 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step measurement")
+    ap.add_argument("--train-steps", type=int, default=8)
+    ap.add_argument("--train-warmup", type=int, default=2)
+    ap.add_argument("--train-batch", type=int, default=16)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
     if world > 1:
         import torch.distributed as dist
 
@@ -174,6 +325,10 @@ def main():
             "share_of_step_kernel_time": r["ms"] / sum(v["ms"] for v in prof.results.values()),
         }
 
+    del y
+    torch.cuda.empty_cache()
+    train = None if args.no_train else bench_train(args, dev, rank, world, dist)
+
     if rank == 0:
         value = samples_per_step * world * args.steps / elapsed
         out = {
@@ -201,8 +356,12 @@ def main():
             "rtf": 22050.0 / value,
             "roofline": roofline,
         }
+        if train is not None:
+            out["train"] = train
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            if train is not None:
+                train["cpu_baseline"] = cpu_train_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -136,11 +136,13 @@ int pwg_conv1d_pack_weight_bwd(const pwg_conv1d_desc* d, const float* w, const f
  * may alias dx.                                                                 */
 int pwg_conv1d_backward_data(const pwg_conv1d_desc* d, const float* dy, const float* w_packed_bwd,
                              const float* x, const float* accum, float* dx, void* stream);
-/* dw (torch layout, same shape as the forward weight) += sum_{b,t} dy * pre_act(x) taps;
- * db[c] = sum dy.  dw must be ZEROED by the caller (partial sums are combined with fp32
- * atomics).  Either of dw/db may be NULL.                                       */
+/* dw (torch layout, same shape as the forward weight) = sum_{b,t} dy * pre_act(x) taps;
+ * db[c] = sum dy.  The (batch, time) reduction is cut into slices that each write a private
+ * slab of `workspace`; a second kernel sums the slabs (deterministic, no atomics).  Query the
+ * workspace size (floats, may be 0) first.  Either of dw/db may be NULL.          */
+size_t pwg_conv1d_backward_weight_workspace_floats(const pwg_conv1d_desc* d);
 int pwg_conv1d_backward_weight(const pwg_conv1d_desc* d, const float* x, const float* dy, float* dw,
-                               float* db, void* stream);
+                               float* db, float* workspace, size_t workspace_floats, void* stream);
 
 /* Tuning / diagnostics: the same operation with an explicit tile configuration
  * (0 <= tile_config < pwg_conv1d_num_tile_configs()) and staging path (use_dma:

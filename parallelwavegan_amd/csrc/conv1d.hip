@@ -598,8 +598,11 @@ struct TileCfg {
   X(12, 2, 1, 2, 2, 8)    \
   X(13, 1, 1, 1, 4, 8)    \
   X(14, 2, 4, 1, 4, 4)    \
-  X(15, 2, 2, 1, 4, 4)
-static const int kNumCfgs = 16;
+  X(15, 2, 2, 1, 4, 4)    \
+  X(16, 1, 2, 2, 2, 8)    \
+  X(17, 1, 1, 2, 2, 8)    \
+  X(18, 1, 1, 4, 1, 8)
+static const int kNumCfgs = 19;
 
 static TileCfg cfg_info(int id) {
   switch (id) {
@@ -635,47 +638,56 @@ static int launch_cfg(int id, bool dma, const ConvArgs& a, const Geometry& g, in
   return PWG_ERR_UNSUPPORTED;
 }
 
-// Heuristic from the tools/bench_conv.py sweep on MI355X (HiFi-GAN V1 problem set, B=16 x 800
-// frames): the kernel is latency- rather than reuse-bound, so few taps want SMALL tiles (more
-// resident workgroups per CU), many taps want a short ci-chunk (CK=4) under a 128x128 / 64x256
-// tile.  Every candidate list ends in a configuration that fits the 160 KB LDS for any k.
+// Heuristic from the tools/bench_conv.py sweep on MI355X (HiFi-GAN V1 problem set): the kernel is
+// latency- rather than reuse-bound, so few taps want SMALL tiles (more resident workgroups per
+// CU) and many taps a short ci-chunk (CK=4) under a 128x128 / 64x256 tile.  Training shapes add
+// launches with few columns per item (T = 9..256): every candidate is scored by
+//   (chip fill: workgroups up to 2 per CU) x (useful fraction of its column tiles) x (measured
+//   relative speed of the tile shape)
+// and the best one that fits the LDS wins.
+struct Cand {
+  int id;
+  float speed;
+};
 static int choose_cfg(const Geometry& g, int W, int batch, int groups, bool dma) {
   const int m = g.m_g;
   const int k = g.k_phase;
-  static const int big_fewtaps[] = {12, 0, 2};   // 128x64x8, 128x128x8, 128x128x4
-  static const int big_manytaps[] = {2, 12};     // 128x128x4, 128x64x8
-  static const int mid_fewtaps[] = {13, 15};     // 32x128x8, 64x256x4
-  static const int mid_manytaps[] = {15, 13};    // 64x256x4, 32x128x8
-  static const int small_any[] = {13};           // 32x128x8
-  const int* cand;
+  static const Cand big_few[] = {{12, 0.95f}, {0, 0.85f}, {16, 0.85f}, {17, 0.75f}, {18, 0.6f}, {2, 0.8f}};
+  static const Cand big_many[] = {{2, 1.0f}, {12, 0.9f}, {16, 0.85f}, {17, 0.75f}, {18, 0.6f}};
+  static const Cand mid_few[] = {{13, 1.0f}, {15, 0.8f}, {17, 0.8f}};
+  static const Cand mid_many[] = {{15, 1.0f}, {13, 0.9f}, {17, 0.8f}};
+  static const Cand small_any[] = {{13, 1.0f}};
+  const Cand* cand;
   int ncand;
   if (m > 64) {
-    if (k <= 4) {
-      cand = big_fewtaps;
-      ncand = 3;
-    } else {
-      cand = big_manytaps;
-      ncand = 2;
-    }
+    cand = k <= 4 ? big_few : big_many;
+    ncand = k <= 4 ? 6 : 5;
   } else if (m > 32) {
-    if (k <= 8) {
-      cand = mid_fewtaps;
-      ncand = 2;
-    } else {
-      cand = mid_manytaps;
-      ncand = 2;
-    }
+    cand = k <= 8 ? mid_few : mid_many;
+    ncand = 3;
   } else {
     cand = small_any;
     ncand = 1;
   }
-  (void)batch;
-  (void)groups;
-  for (int i = 0; i < ncand; ++i)
-    if (cfg_lds(cand[i], g, W, dma) <= 80 * 1024) return cand[i];
-  for (int i = 0; i < ncand; ++i)
-    if (cfg_lds(cand[i], g, W, dma) <= 160 * 1024) return cand[i];
-  return 13;
+  int best = -1;
+  float best_score = -1.f;
+  for (int pass = 0; pass < 2 && best < 0; ++pass) {
+    const size_t cap = pass == 0 ? 80 * 1024 : 160 * 1024;  // first try to keep >= 2 workgroups per CU
+    for (int i = 0; i < ncand; ++i) {
+      if (cfg_lds(cand[i].id, g, W, dma) > cap) continue;
+      const TileCfg c = cfg_info(cand[i].id);
+      const long ntiles = ceil_div(g.n_cols, c.bn);
+      const long blocks = ntiles * ceil_div(m, c.bm) * groups * batch;
+      const float fill = blocks >= 512 ? 1.f : (float)blocks / 512.f;
+      const float useful = (float)g.n_cols / (float)(ntiles * c.bn) * (float)m / (float)(ceil_div(m, c.bm) * c.bm);
+      const float score = fill * useful * cand[i].speed;
+      if (score > best_score) {
+        best_score = score;
+        best = cand[i].id;
+      }
+    }
+  }
+  return best >= 0 ? best : 13;
 }
 
 static int fill_args(const pwg_conv1d_desc* d, const Geometry& g, const float* x, const float* w_packed,

@@ -29,6 +29,7 @@ struct WgArgs {
   int batch;
   int chunks_per_item, chunks_total, chunks_per_block;
   int xs_stride;    // odd
+  long slab_elems;  // elements of one gradient slab (= the whole dW)
   float slope_g, slope_x;  // branch-free pre-activation slopes (1 = none)
   unsigned g_bytes, x_bytes;
 };
@@ -61,7 +62,6 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgArgs a) {
 
   const int c_begin = blockIdx.x * a.chunks_per_block;
   const int c_end = min(c_begin + a.chunks_per_block, a.chunks_total);
-  if (c_begin >= c_end) return;
 
   __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.g, 0, a.g_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgArgs a) {
     }
   };
 
-  issue(c_begin, smem);
+  if (c_begin < c_end) issue(c_begin, smem);
   for (int c = c_begin; c < c_end; ++c) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -146,7 +146,10 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgArgs a) {
     }
   }
 
-  // ---- epilogue: D layout col = lane&31 (-> i), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (-> o)
+  // ---- epilogue: D layout col = lane&31 (-> i), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (-> o).
+  // Every reduction slice owns a private slab (torch weight layout) that it fully overwrites with
+  // plain stores; slabs are summed by reduce_slabs_kernel (no atomics, deterministic).
+  float* slab = a.dw + (long)blockIdx.x * a.slab_elems;
   const int i = i0 + wave_i * 32 + l31;
   if (i < a.ci_g) {
 #pragma unroll
@@ -155,11 +158,19 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int o = o0 + wave_o * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          if (o < a.co_g)
-            atomicAdd(a.dw + (((long)(grp * a.co_g + o)) * a.ci_g + i) * a.k + k0 + t, acc[t][r]);
+          if (o < a.co_g) slab[(((long)(grp * a.co_g + o)) * a.ci_g + i) * a.k + k0 + t] = acc[t][r];
         }
       }
     }
+  }
+}
+
+// dw[e] = sum_s slabs[s][e]
+__global__ void reduce_slabs_kernel(const float* slabs, float* dw, long elems, int nslabs) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < elems; e += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int j = 0; j < nslabs; ++j) s += slabs[(long)j * elems + e];
+    dw[e] = s;
   }
 }
 
@@ -178,8 +189,25 @@ __global__ void bias_grad_kernel(const float* dy, float* db, int batch, int chan
   if (threadIdx.x == 0) db[c] = red[0] + red[1] + red[2] + red[3];
 }
 
+static int wgrad_splits(int tiles, int tap_groups, int chunks_total) {
+  // ~3 workgroups per CU, but at least 8 chunks (256 columns) of reduction per workgroup
+  int splits = ceil_div(768, tiles * tap_groups);
+  if (splits > chunks_total / 8) splits = chunks_total / 8;
+  if (splits < 1) splits = 1;
+  const int per_block = ceil_div(chunks_total, splits);
+  return ceil_div(chunks_total, per_block);
+}
+
+static int tg_for(int k) {
+  if (k <= 4) return 4;
+  if (k <= 6 || k == 11 || k == 12) return 6;
+  if (k == 7 || k == 41 || k == 42 || k == 14) return 7;
+  return 8;
+}
+
 template <int TG>
-static int launch_wgrad(WgArgs a, int tap_groups, hipStream_t stream, double flops, double bytes) {
+static int launch_wgrad(WgArgs a, int tap_groups, float* dw_out, float* workspace, size_t ws_floats,
+                        hipStream_t stream, double flops, double bytes) {
   a.k0_step = TG;
   const int rows = (a.width == 1) ? WG_TT : ((WG_TT - 1) / a.width + 2);
   int xs_len = ((rows - 1) * a.stride + (TG - 1) * a.dil + 1) * a.width;
@@ -194,16 +222,31 @@ static int launch_wgrad(WgArgs a, int tap_groups, hipStream_t stream, double flo
                 hipGetErrorString(e));
   }
   const int tiles = ceil_div(a.co_g, 64) * ceil_div(a.ci_g, 64) * a.groups;
-  // enough reduction slices to fill the chip (~4 workgroups per CU), at least 4 chunks each
-  int splits = ceil_div(1024, tiles * tap_groups);
-  if (splits > ceil_div(a.chunks_total, 4)) splits = ceil_div(a.chunks_total, 4);
-  if (splits < 1) splits = 1;
+  const int splits = wgrad_splits(tiles, tap_groups, a.chunks_total);
   a.chunks_per_block = ceil_div(a.chunks_total, splits);
-  splits = ceil_div(a.chunks_total, a.chunks_per_block);
+  a.slab_elems = (long)a.co_g * a.groups * a.ci_g * a.k;
+  if (splits == 1) {
+    a.dw = dw_out;  // single slice: write the gradient directly
+  } else {
+    PWG_REQUIRE(workspace && ws_floats >= (size_t)splits * a.slab_elems, PWG_ERR_WORKSPACE,
+                "conv1d_backward_weight: workspace of %zu floats needed, %zu given", (size_t)splits * a.slab_elems,
+                ws_floats);
+    a.dw = workspace;
+  }
   dim3 grid(splits, tiles, tap_groups);
-  ProfScope prof(stream, "conv1d_wgrad_kernel", flops, bytes);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+  {
+    ProfScope prof(stream, "conv1d_wgrad_kernel", flops, bytes);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+  }
   PWG_CHECK_LAUNCH("conv1d_backward_weight");
+  if (splits > 1) {
+    long blocks = (a.slab_elems + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    ProfScope prof(stream, "reduce_slabs_kernel", 0, 4.0 * a.slab_elems * (splits + 1));
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((int)blocks), dim3(256), 0, stream, workspace, dw_out, a.slab_elems,
+                       splits);
+    PWG_CHECK_LAUNCH("reduce_slabs");
+  }
   return PWG_OK;
 }
 
@@ -211,8 +254,32 @@ static int launch_wgrad(WgArgs a, int tap_groups, hipStream_t stream, double flo
 
 using namespace pwg;
 
+static void wgrad_roles(const pwg_conv1d_desc* d, int* co_g, int* ci_g, int* n_cols) {
+  if (!d->transposed) {
+    *co_g = d->c_out / d->groups;
+    *ci_g = d->c_in / d->groups;
+    *n_cols = d->t_out * d->width;
+  } else {
+    *co_g = d->c_in / d->groups;
+    *ci_g = d->c_out / d->groups;
+    *n_cols = d->t_in * d->width;
+  }
+}
+
+extern "C" size_t pwg_conv1d_backward_weight_workspace_floats(const pwg_conv1d_desc* d) {
+  if (!d || d->groups <= 0 || d->c_in % d->groups || d->c_out % d->groups) return 0;
+  int co_g, ci_g, n_cols;
+  wgrad_roles(d, &co_g, &ci_g, &n_cols);
+  const int tg = tg_for(d->kernel);
+  const int tiles = ceil_div(co_g, 64) * ceil_div(ci_g, 64) * d->groups;
+  const int chunks_total = ceil_div(n_cols, WG_TT) * d->batch;
+  const int splits = wgrad_splits(tiles, ceil_div(d->kernel, tg), chunks_total);
+  return splits > 1 ? (size_t)splits * co_g * d->groups * ci_g * d->kernel : 0;
+}
+
 extern "C" int pwg_conv1d_backward_weight(const pwg_conv1d_desc* d, const float* x, const float* dy,
-                                          float* dw, float* db, void* stream_) {
+                                          float* dw, float* db, float* workspace, size_t workspace_floats,
+                                          void* stream_) {
   PWG_REQUIRE(d && x && dy, PWG_ERR_NULL, "conv1d_backward_weight: NULL pointer");
   PWG_REQUIRE(d->c_in % d->groups == 0 && d->c_out % d->groups == 0 && d->groups > 0, PWG_ERR_BAD_SHAPE,
               "conv1d_backward_weight: bad groups");
@@ -256,7 +323,7 @@ extern "C" int pwg_conv1d_backward_weight(const pwg_conv1d_desc* d, const float*
     a.g_bytes = (unsigned)(x_elems * 4);
     a.x_bytes = (unsigned)(y_elems * 4);
   }
-  a.dw = dw;
+  a.dw = nullptr;
   a.groups = d->groups;
   a.k = d->kernel;
   a.stride = d->stride;
@@ -268,9 +335,12 @@ extern "C" int pwg_conv1d_backward_weight(const pwg_conv1d_desc* d, const float*
   a.chunks_total = a.chunks_per_item * d->batch;
   const double flops = 2.0 * d->batch * (double)a.n_cols * a.co_g * a.ci_g * d->groups * d->kernel;
   const double bytes = 4.0 * ((double)x_elems + (double)y_elems + (double)a.co_g * a.ci_g * d->groups * d->kernel);
-  const int k = d->kernel;
-  if (k <= 4) return launch_wgrad<4>(a, ceil_div(k, 4), stream, flops, bytes);
-  if (k <= 6 || k == 11 || k == 12) return launch_wgrad<6>(a, ceil_div(k, 6), stream, flops, bytes);
-  if (k == 7 || k == 41 || k == 42 || k == 14) return launch_wgrad<7>(a, ceil_div(k, 7), stream, flops, bytes);
-  return launch_wgrad<8>(a, ceil_div(k, 8), stream, flops, bytes);
+  const int tg = tg_for(d->kernel);
+  const int tgroups = ceil_div(d->kernel, tg);
+  switch (tg) {
+    case 4: return launch_wgrad<4>(a, tgroups, dw, workspace, workspace_floats, stream, flops, bytes);
+    case 6: return launch_wgrad<6>(a, tgroups, dw, workspace, workspace_floats, stream, flops, bytes);
+    case 7: return launch_wgrad<7>(a, tgroups, dw, workspace, workspace_floats, stream, flops, bytes);
+    default: return launch_wgrad<8>(a, tgroups, dw, workspace, workspace_floats, stream, flops, bytes);
+  }
 }

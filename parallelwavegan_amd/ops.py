@@ -112,12 +112,17 @@ def conv1d_backward_data(desc, dy, w_packed_bwd, x=None, accum=None, out=None):
 
 
 def conv1d_backward_weight(desc, x, dy, weight_shape, need_dw=True, need_db=True):
-    """(dw in torch layout, db); partial sums are combined with fp32 atomics."""
+    """(dw in torch layout, db); deterministic two-stage reduction over (batch, time) slices."""
     _require_device(x, dy)
-    dw = torch.zeros(weight_shape, device=x.device, dtype=torch.float32) if need_dw else None
+    dw = torch.empty(weight_shape, device=x.device, dtype=torch.float32) if need_dw else None
     db = torch.empty(desc.c_out, device=x.device, dtype=torch.float32) if need_db else None
+    ws, ws_n = None, 0
+    if need_dw:
+        ws_n = _lib.lib().pwg_conv1d_backward_weight_workspace_floats(ctypes.byref(desc))
+        if ws_n:
+            ws = torch.empty(ws_n, device=x.device, dtype=torch.float32)
     _lib.check(_lib.lib().pwg_conv1d_backward_weight(ctypes.byref(desc), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db),
-                                                     _stream()), "conv1d_backward_weight")
+                                                     _ptr(ws), ws_n, _stream()), "conv1d_backward_weight")
     return dw, db
 
 

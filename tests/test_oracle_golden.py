@@ -28,3 +28,24 @@ def test_hifigan_generator_oracle_matches_reference_golden(name, cfg):
     # reduction order, MKL-DNN blocking): measured 3e-6 at these gains
     assert max_abs(y, gold["y"]) < 1e-5
     assert max_abs(y_inf, gold["y_inference"]) < 1e-5
+
+
+def test_oracle_train_step_matches_reference_trainer():
+    """Two optimisation steps of oracle.train_step vs the reference Trainer's logged losses."""
+    from oracle.train_step import HiFiGANTrainState
+    from parallelwavegan_amd.models import HiFiGANMultiScaleMultiPeriodDiscriminator
+    from tests.test_discriminator_gpu import D_PARAMS
+    from tests.test_losses_gpu import MEL_PARAMS
+
+    gold = load_golden("hifigan_v1_train")
+    batch, n_steps, seed = (int(v) for v in gold["meta"])
+    sd_g = synth_for(HiFiGANGenerator(**synth.HIFIGAN_V1), seed, float(gold["g_scale"]))
+    sd_d = synth_for(HiFiGANMultiScaleMultiPeriodDiscriminator(**D_PARAMS), seed + 1, 1.0)
+    st = HiFiGANTrainState(sd_g, sd_d, synth.HIFIGAN_V1, D_PARAMS, MEL_PARAMS)
+    c = synth.synth_input("c", (batch, 80, 32), seed=seed)
+    y = 0.5 * synth.synth_input("y", (batch, 1, 8192), seed=seed)
+    for i in range(n_steps):
+        log = st.step(c, y)
+        for k, v in log.items():
+            want = float(gold[f"step{i}/{k}"])
+            assert abs(v - want) <= 5e-5 * max(abs(want), 1e-3), (i, k, v, want)
