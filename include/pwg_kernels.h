@@ -188,6 +188,22 @@ int pwg_spectral_norm_backward(const float* dw, const float* w_orig, const float
                                int32_t cols, void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* Parallel WaveGAN specific element-wise stages                               */
+/* ------------------------------------------------------------------------- */
+/* WaveNet gate: out = tanh(z[:, :C]) * sigmoid(z[:, C:]); z (B, 2C, T), out (B, C, T)
+ * (layers/residual_block.py:120-132).                                           */
+int pwg_gate_forward(const float* z, float* out, int32_t batch, int32_t channels, int64_t t, void* stream);
+int pwg_gate_backward(const float* z, const float* dout, float* dz, int32_t batch, int32_t channels,
+                      int64_t t, void* stream);
+/* One stage of the mel upsampler: F.interpolate(nearest, x scale) followed by the
+ * (1, 2*scale+1) single-channel Conv2d, fused (layers/upsample.py:43-45,97-103,121-127):
+ *   y[r][t] = sum_j w[j] * x[r][(t + j - scale) / scale],  rows = B * mel channels.  */
+int pwg_stretch_conv_forward(const float* x, const float* w, float* y, int64_t rows, int32_t t_in,
+                             int32_t scale, int32_t kernel, void* stream);
+int pwg_stretch_conv_backward(const float* dy, const float* x, const float* w, float* dx, float* dw,
+                              int64_t rows, int32_t t_in, int32_t scale, int32_t kernel, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* Pooling / explicit padding                                                  */
 /* ------------------------------------------------------------------------- */
 /* torch.nn.AvgPool1d over `rows` rows (models/hifigan.py:773-775: k4 s2 p2,

@@ -331,3 +331,160 @@ def feature_match_loss(feats_hat, feats, average_by_layers=True, average_by_disc
             part = part / (j + 1)
         total = total + part
     return total / (i + 1) if average_by_discriminators else total
+
+
+# ----------------------------------------------------------------------------
+# Parallel WaveGAN (models/parallel_wavegan.py:144-173,337-349; layers/upsample.py; residual_block.py:102-140)
+# ----------------------------------------------------------------------------
+def pwg_upsample(sd, c, upsample_scales=(4, 4, 4, 4), prefix="upsample_net"):
+    """``ConvInUpsampleNetwork.forward`` layers/upsample.py:178-194 (+ ``UpsampleNetwork`` :112-128)."""
+    c = F.conv1d(c, get_weight(sd, f"{prefix}.conv_in"))  # no padding: the input carries the context frames
+    c = c.unsqueeze(1)
+    for i, s in enumerate(upsample_scales):
+        c = F.interpolate(c, scale_factor=(1, s), mode="nearest")
+        c = F.conv2d(c, get_weight(sd, f"{prefix}.upsample.up_layers.{2 * i + 1}"), padding=(0, s))
+    return c.squeeze(1)
+
+
+def pwg_generator(sd, z, c, layers=30, stacks=3, kernel_size=3, upsample_params=None, **_unused):
+    """``ParallelWaveGANGenerator.forward`` models/parallel_wavegan.py:144-173 (dropout = 0)."""
+    scales = (upsample_params or {}).get("upsample_scales", (4, 4, 4, 4))
+    c = pwg_upsample(sd, c, scales)
+    assert c.size(-1) == z.size(-1)
+    x = F.conv1d(z, get_weight(sd, "first_conv"), get_bias(sd, "first_conv"))
+    skips = 0
+    per_stack = layers // stacks
+    for l in range(layers):
+        p = f"conv_layers.{l}"
+        d = 2 ** (l % per_stack)
+        residual = x
+        h = F.conv1d(x, get_weight(sd, p + ".conv"), get_bias(sd, p + ".conv"), dilation=d,
+                     padding=(kernel_size - 1) // 2 * d)
+        xa, xb = h.split(h.size(1) // 2, dim=1)
+        a = F.conv1d(c, get_weight(sd, p + ".conv1x1_aux"))
+        ca, cb = a.split(a.size(1) // 2, dim=1)
+        g = torch.tanh(xa + ca) * torch.sigmoid(xb + cb)
+        s = F.conv1d(g, get_weight(sd, p + ".conv1x1_skip"), get_bias(sd, p + ".conv1x1_skip"))
+        x = (F.conv1d(g, get_weight(sd, p + ".conv1x1_out"), get_bias(sd, p + ".conv1x1_out")) + residual) * math.sqrt(0.5)
+        skips = skips + s
+    skips = skips * math.sqrt(1.0 / layers)
+    x = F.conv1d(F.relu(skips), get_weight(sd, "last_conv_layers.1"), get_bias(sd, "last_conv_layers.1"))
+    return F.conv1d(F.relu(x), get_weight(sd, "last_conv_layers.3"), get_bias(sd, "last_conv_layers.3"))
+
+
+def pwg_discriminator(sd, x, layers=10, kernel_size=3, dilation_factor=1, slope=0.2, **_unused):
+    """``ParallelWaveGANDiscriminator.forward`` models/parallel_wavegan.py:337-349."""
+    for i in range(layers - 1):
+        d = 1 if i == 0 else (i if dilation_factor == 1 else dilation_factor ** i)
+        p = f"conv_layers.{2 * i}"
+        x = F.leaky_relu(F.conv1d(x, get_weight(sd, p), get_bias(sd, p), dilation=d,
+                                  padding=(kernel_size - 1) // 2 * d), slope)
+    p = f"conv_layers.{2 * (layers - 1)}"
+    return F.conv1d(x, get_weight(sd, p), get_bias(sd, p), padding=(kernel_size - 1) // 2)
+
+
+# ----------------------------------------------------------------------------
+# MelGAN / Multi-band MelGAN (models/melgan.py:168-178,364-379,478-493; layers/residual_stack.py:75-85)
+# ----------------------------------------------------------------------------
+def melgan_generator(sd, c, kernel_size=7, upsample_scales=(8, 8, 2, 2), stack_kernel_size=3, stacks=3, slope=0.2,
+                     use_final_nonlinear_activation=True, **_unused):
+    """``MelGANGenerator.forward`` models/melgan.py:168-178 (flat Sequential built at :67-156)."""
+    p = (kernel_size - 1) // 2
+    x = F.conv1d(F.pad(c, (p, p), mode="reflect"), get_weight(sd, "melgan.1"), get_bias(sd, "melgan.1"))
+    idx = 2
+    for s in upsample_scales:
+        x = F.conv_transpose1d(F.leaky_relu(x, slope), get_weight(sd, f"melgan.{idx + 1}"),
+                               get_bias(sd, f"melgan.{idx + 1}"), stride=s, padding=s // 2 + s % 2,
+                               output_padding=s % 2)
+        idx += 2
+        for j in range(stacks):
+            d = stack_kernel_size ** j
+            pre = f"melgan.{idx}"
+            pd = (stack_kernel_size - 1) // 2 * d
+            t = F.conv1d(F.pad(F.leaky_relu(x, slope), (pd, pd), mode="reflect"), get_weight(sd, pre + ".stack.2"),
+                         get_bias(sd, pre + ".stack.2"), dilation=d)
+            t = F.conv1d(F.leaky_relu(t, slope), get_weight(sd, pre + ".stack.4"), get_bias(sd, pre + ".stack.4"))
+            x = t + F.conv1d(x, get_weight(sd, pre + ".skip_layer"), get_bias(sd, pre + ".skip_layer"))
+            idx += 1
+    x = F.conv1d(F.pad(F.leaky_relu(x, slope), (p, p), mode="reflect"), get_weight(sd, f"melgan.{idx + 2}"),
+                 get_bias(sd, f"melgan.{idx + 2}"))
+    return torch.tanh(x) if use_final_nonlinear_activation else x
+
+
+def melgan_discriminator(sd, prefix, x, kernel_sizes=(5, 3), downsample_scales=(4, 4, 4, 4), slope=0.2):
+    """``MelGANDiscriminator.forward`` models/melgan.py:364-379 (layers :304-359)."""
+    outs = []
+    k0 = int(np.prod(kernel_sizes))
+    p = f"{prefix}.layers.0.1"
+    x = F.leaky_relu(F.conv1d(F.pad(x, ((k0 - 1) // 2, (k0 - 1) // 2), mode="reflect"), get_weight(sd, p),
+                              get_bias(sd, p)), slope)
+    outs.append(x)
+    n = 1
+    for s in downsample_scales:
+        p = f"{prefix}.layers.{n}.0"
+        x = F.leaky_relu(F.conv1d(x, get_weight(sd, p), get_bias(sd, p), stride=s, padding=s * 5,
+                                  groups=x.size(1) // 4), slope)
+        outs.append(x)
+        n += 1
+    p = f"{prefix}.layers.{n}.0"
+    x = F.leaky_relu(F.conv1d(x, get_weight(sd, p), get_bias(sd, p), padding=(kernel_sizes[0] - 1) // 2), slope)
+    outs.append(x)
+    p = f"{prefix}.layers.{n + 1}"
+    x = F.conv1d(x, get_weight(sd, p), get_bias(sd, p), padding=(kernel_sizes[1] - 1) // 2)
+    outs.append(x)
+    return outs
+
+
+def melgan_multi_scale_discriminator(sd, x, scales=3, downsample_pooling_params=None, kernel_sizes=(5, 3),
+                                     downsample_scales=(4, 4, 4, 4), nonlinear_activation_params=None, **_unused):
+    """``MelGANMultiScaleDiscriminator.forward`` models/melgan.py:478-493."""
+    pp = downsample_pooling_params or {"kernel_size": 4, "stride": 2, "padding": 1, "count_include_pad": False}
+    slope = (nonlinear_activation_params or {}).get("negative_slope", 0.2)
+    outs = []
+    for i in range(scales):
+        outs.append(melgan_discriminator(sd, f"discriminators.{i}", x, kernel_sizes, downsample_scales, slope))
+        x = F.avg_pool1d(x, pp["kernel_size"], pp["stride"], pp["padding"],
+                         count_include_pad=pp.get("count_include_pad", True))
+    return outs
+
+
+# ----------------------------------------------------------------------------
+# PQMF (layers/pqmf.py:14-48,61-149)
+# ----------------------------------------------------------------------------
+def pqmf_filters(subbands=4, taps=62, cutoff_ratio=0.142, beta=9.0):
+    """Analysis (K,1,taps+1) / synthesis (1,K,taps+1) filters, layers/pqmf.py:37-46,80-107."""
+    import scipy.signal.windows
+
+    n = np.arange(taps + 1) - 0.5 * taps
+    with np.errstate(invalid="ignore", divide="ignore"):
+        h_i = np.sin(np.pi * cutoff_ratio * n) / (np.pi * n)
+    h_i[taps // 2] = cutoff_ratio
+    h = h_i * scipy.signal.windows.kaiser(taps + 1, beta)
+    ha = np.zeros((subbands, taps + 1))
+    hs = np.zeros((subbands, taps + 1))
+    for k in range(subbands):
+        arg = (2 * k + 1) * (np.pi / (2 * subbands)) * n
+        ha[k] = 2 * h * np.cos(arg + (-1) ** k * np.pi / 4)
+        hs[k] = 2 * h * np.cos(arg - (-1) ** k * np.pi / 4)
+    return torch.from_numpy(ha).float().unsqueeze(1), torch.from_numpy(hs).float().unsqueeze(0)
+
+
+def _updown(subbands):
+    f = torch.zeros(subbands, subbands, subbands)
+    for k in range(subbands):
+        f[k, k, 0] = 1.0
+    return f
+
+
+def pqmf_analysis(x, subbands=4, taps=62, cutoff_ratio=0.142, beta=9.0):
+    """``PQMF.analysis`` layers/pqmf.py:120-131."""
+    ha, _ = pqmf_filters(subbands, taps, cutoff_ratio, beta)
+    x = F.conv1d(F.pad(x, (taps // 2, taps // 2)), ha)
+    return F.conv1d(x, _updown(subbands), stride=subbands)
+
+
+def pqmf_synthesis(x, subbands=4, taps=62, cutoff_ratio=0.142, beta=9.0):
+    """``PQMF.synthesis`` layers/pqmf.py:133-149."""
+    _, hs = pqmf_filters(subbands, taps, cutoff_ratio, beta)
+    x = F.conv_transpose1d(x, _updown(subbands) * subbands, stride=subbands)
+    return F.conv1d(F.pad(x, (taps // 2, taps // 2)), hs)

@@ -307,6 +307,88 @@ __global__ void div_scalar_kernel(const float* x, const float* s, float* y, long
   GRID_STRIDE(i, n) y[i] = x[i] / d;
 }
 
+
+// ---- WaveNet gate: out = tanh(z[:, :C]) * sigmoid(z[:, C:])   (layers/residual_block.py:120-132)
+__global__ void gate_fwd_kernel(const float* z, float* out, int batch, int c, long t) {
+  const long n = (long)batch * c * t;
+  const long plane = (long)c * t;
+  GRID_STRIDE(i, n) {
+    const long b = i / plane;
+    const long r = i - b * plane;
+    const float a = z[b * 2 * plane + r], g = z[b * 2 * plane + plane + r];
+    out[i] = tanhf(a) * (1.f / (1.f + expf(-g)));
+  }
+}
+__global__ void gate_bwd_kernel(const float* z, const float* dout, float* dz, int batch, int c, long t) {
+  const long n = (long)batch * c * t;
+  const long plane = (long)c * t;
+  GRID_STRIDE(i, n) {
+    const long b = i / plane;
+    const long r = i - b * plane;
+    const float a = z[b * 2 * plane + r], g = z[b * 2 * plane + plane + r];
+    const float th = tanhf(a), sg = 1.f / (1.f + expf(-g));
+    const float d = dout[i];
+    dz[b * 2 * plane + r] = d * sg * (1.f - th * th);
+    dz[b * 2 * plane + plane + r] = d * th * sg * (1.f - sg);
+  }
+}
+
+// ---- PWG mel upsampler stage: nearest stretch x s along time fused with the (1, 2s+1) smoothing
+// conv (layers/upsample.py:43-45,97-103):  y[r][t] = sum_j w[j] * x[r][(t + j - s) / s]   (zero pad)
+__global__ void stretch_conv_fwd_kernel(const float* x, const float* w, float* y, long rows, int t_in, int s, int k) {
+  const int t_out = t_in * s;
+  const int pad = (k - 1) / 2;
+  const long n = rows * t_out;
+  GRID_STRIDE(i, n) {
+    const long r = i / t_out;
+    const int t = (int)(i - r * t_out);
+    const float* xr = x + r * t_in;
+    float acc = 0.f;
+    for (int j = 0; j < k; ++j) {
+      const int u = t + j - pad;
+      if (u >= 0 && u < t_out) acc += w[j] * xr[u / s];
+    }
+    y[i] = acc;
+  }
+}
+__global__ void stretch_conv_bwd_data_kernel(const float* dy, const float* w, float* dx, long rows, int t_in, int s,
+                                             int k) {
+  const int t_out = t_in * s;
+  const int pad = (k - 1) / 2;
+  const long n = rows * t_in;
+  GRID_STRIDE(i, n) {
+    const long r = i / t_in;
+    const int q = (int)(i - r * t_in);
+    const float* g = dy + r * t_out;
+    float acc = 0.f;
+    for (int u = q * s; u < q * s + s; ++u)
+      for (int j = 0; j < k; ++j) {
+        const int t = u - j + pad;
+        if (t >= 0 && t < t_out) acc += w[j] * g[t];
+      }
+    dx[i] = acc;
+  }
+}
+// dw[j] = sum_{r,t} dy[r][t] * xs[r][t + j - pad];  dw must be zeroed (block partials + atomics, k <= 64)
+__global__ void stretch_conv_bwd_weight_kernel(const float* dy, const float* x, float* dw, long rows, int t_in, int s,
+                                               int k) {
+  __shared__ float red[4];
+  const int t_out = t_in * s;
+  const int pad = (k - 1) / 2;
+  const long n = rows * t_out;
+  for (int j = 0; j < k; ++j) {
+    float acc = 0.f;
+    GRID_STRIDE(i, n) {
+      const long r = i / t_out;
+      const int t = (int)(i - r * t_out);
+      const int u = t + j - pad;
+      if (u >= 0 && u < t_out) acc += dy[i] * x[r * t_in + u / s];
+    }
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) atomicAdd(dw + j, acc);
+  }
+}
+
 }  // namespace pwg
 
 using namespace pwg;
@@ -470,5 +552,54 @@ extern "C" int pwg_spectral_norm_backward(const float* dw, const float* w_orig, 
   hipLaunchKernelGGL(spectral_norm_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, dw, u, v, sigma, scratch,
                      dw_orig, rows, cols);
   PWG_CHECK_LAUNCH("spectral_norm_backward");
+  return PWG_OK;
+}
+
+extern "C" int pwg_gate_forward(const float* z, float* out, int32_t batch, int32_t channels, int64_t t, void* stream) {
+  PWG_REQUIRE(z && out, PWG_ERR_NULL, "gate_forward: NULL pointer");
+  PWG_REQUIRE(batch > 0 && channels > 0 && t > 0, PWG_ERR_BAD_SHAPE, "gate: bad shape");
+  const long n = (long)batch * channels * t;
+  ProfScope prof((hipStream_t)stream, "gate_fwd_kernel", 0, 12.0 * n);
+  LAUNCH1D(gate_fwd_kernel, n, stream, z, out, batch, channels, (long)t);
+  return PWG_OK;
+}
+
+extern "C" int pwg_gate_backward(const float* z, const float* dout, float* dz, int32_t batch, int32_t channels,
+                                 int64_t t, void* stream) {
+  PWG_REQUIRE(z && dout && dz, PWG_ERR_NULL, "gate_backward: NULL pointer");
+  PWG_REQUIRE(batch > 0 && channels > 0 && t > 0, PWG_ERR_BAD_SHAPE, "gate: bad shape");
+  const long n = (long)batch * channels * t;
+  LAUNCH1D(gate_bwd_kernel, n, stream, z, dout, dz, batch, channels, (long)t);
+  return PWG_OK;
+}
+
+extern "C" int pwg_stretch_conv_forward(const float* x, const float* w, float* y, int64_t rows, int32_t t_in,
+                                        int32_t scale, int32_t kernel, void* stream) {
+  PWG_REQUIRE(x && w && y, PWG_ERR_NULL, "stretch_conv_forward: NULL pointer");
+  PWG_REQUIRE(rows > 0 && t_in > 0 && scale > 0 && kernel > 0 && kernel % 2 == 1 && kernel <= 64, PWG_ERR_BAD_SHAPE,
+              "stretch_conv: bad geometry");
+  const long n = rows * (long)t_in * scale;
+  ProfScope prof((hipStream_t)stream, "stretch_conv_fwd_kernel", 2.0 * n * kernel, 4.0 * (rows * (double)t_in + n));
+  LAUNCH1D(stretch_conv_fwd_kernel, n, stream, x, w, y, (long)rows, t_in, scale, kernel);
+  return PWG_OK;
+}
+
+extern "C" int pwg_stretch_conv_backward(const float* dy, const float* x, const float* w, float* dx, float* dw,
+                                         int64_t rows, int32_t t_in, int32_t scale, int32_t kernel, void* stream) {
+  PWG_REQUIRE(dy && w && (dx || dw), PWG_ERR_NULL, "stretch_conv_backward: NULL pointer");
+  PWG_REQUIRE(rows > 0 && t_in > 0 && scale > 0 && kernel > 0 && kernel % 2 == 1 && kernel <= 64, PWG_ERR_BAD_SHAPE,
+              "stretch_conv: bad geometry");
+  if (dx) {
+    const long n = rows * (long)t_in;
+    LAUNCH1D(stretch_conv_bwd_data_kernel, n, stream, dy, w, dx, (long)rows, t_in, scale, kernel);
+  }
+  if (dw) {
+    PWG_REQUIRE(x, PWG_ERR_NULL, "stretch_conv_backward: x needed for dw");
+    (void)hipMemsetAsync(dw, 0, sizeof(float) * kernel, (hipStream_t)stream);
+    const long n = rows * (long)t_in * scale;
+    hipLaunchKernelGGL(stretch_conv_bwd_weight_kernel, dim3(grid_for(n, 256, 512)), dim3(256), 0, (hipStream_t)stream,
+                       dy, x, dw, (long)rows, t_in, scale, kernel);
+    PWG_CHECK_LAUNCH("stretch_conv_bwd_weight");
+  }
   return PWG_OK;
 }

@@ -208,6 +208,62 @@ class Pad1dFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------
+# Parallel WaveGAN element-wise stages
+# ---------------------------------------------------------------------------------------------
+class GateFn(torch.autograd.Function):
+    """(B, 2C, T) -> (B, C, T): tanh(first half) * sigmoid(second half)."""
+
+    @staticmethod
+    def forward(ctx, z):
+        z = _c(z)
+        _require_device(z)
+        b, c2, t = z.shape
+        out = torch.empty(b, c2 // 2, t, device=z.device, dtype=torch.float32)
+        _lib.check(_L().pwg_gate_forward(_ptr(z), _ptr(out), b, c2 // 2, t, _stream()), "gate_forward")
+        ctx.save_for_backward(z)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (z,) = ctx.saved_tensors
+        dout = _c(dout)
+        b, c2, t = z.shape
+        dz = torch.empty_like(z)
+        _lib.check(_L().pwg_gate_backward(_ptr(z), _ptr(dout), _ptr(dz), b, c2 // 2, t, _stream()), "gate_backward")
+        return dz
+
+
+class StretchConvFn(torch.autograd.Function):
+    """Nearest stretch by ``scale`` along time + (1, 2*scale+1) smoothing conv; x (B, C, T), w (k,)."""
+
+    @staticmethod
+    def forward(ctx, x, w, scale):
+        x = _c(x)
+        w = _c(w.reshape(-1))
+        _require_device(x, w)
+        t_in = x.shape[-1]
+        rows = x.numel() // t_in
+        y = torch.empty(x.shape[:-1] + (t_in * scale,), device=x.device, dtype=torch.float32)
+        _lib.check(_L().pwg_stretch_conv_forward(_ptr(x), _ptr(w), _ptr(y), rows, t_in, scale, w.numel(), _stream()),
+                   "stretch_conv_forward")
+        ctx.save_for_backward(x, w)
+        ctx.scale = scale
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        t_in = x.shape[-1]
+        rows = x.numel() // t_in
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        _lib.check(_L().pwg_stretch_conv_backward(_ptr(dy), _ptr(x), _ptr(w), _ptr(dx), _ptr(dw), rows, t_in, ctx.scale,
+                                                  w.numel(), _stream()), "stretch_conv_backward")
+        return dx, dw, None
+
+
+# ---------------------------------------------------------------------------------------------
 # spectral-loss pieces
 # ---------------------------------------------------------------------------------------------
 class FrameFoldFn(torch.autograd.Function):

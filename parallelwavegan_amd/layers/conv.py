@@ -216,6 +216,11 @@ class _ConvNd(torch.nn.Module):
             geom = self.geom()
             if self.width_mode:
                 geom["width"] = x.shape[-1]
+            if self.pad_mode != "zero" and self.padding > 0:
+                # the backward kernels implement zero padding: pad explicitly (HIP kernel with its own
+                # backward); pad and the element-wise pre-activation commute
+                x = Fn.pad1d(x, self.padding, self.padding, self.pad_mode)
+                geom["padding"], geom["pad_mode"] = 0, "zero"
             return Fn.FusedConvFn.apply(x, self.weight_tensor(), self.bias, add1, add2, geom, fused, None)
         with torch.no_grad():
             b = x.shape[0]

@@ -1,8 +1,63 @@
 """Residual blocks (drop-in names for parallel_wavegan.layers.residual_block)."""
+import math
+
 import torch
 
+from .. import functional as Fn
 from .activation import FusedActivation
-from .conv import Conv1d
+from .conv import Conv1d as _Conv1d
+
+
+class Conv1d(_Conv1d):
+    """Conv1d with the reference's customised initialisation (kaiming normal for ReLU, zero bias;
+    layers/residual_block.py:19-30)."""
+
+    def reset_parameters(self):
+        w = self.raw_weight
+        fan_in = int(w[0].numel())
+        with torch.no_grad():
+            w.normal_(0.0, math.sqrt(2.0 / fan_in))  # kaiming_normal_(nonlinearity="relu"), fan_in mode
+            if self.bias is not None:
+                self.bias.zero_()
+
+
+class Conv1d1x1(Conv1d):
+    def __init__(self, in_channels, out_channels, bias):
+        super().__init__(in_channels, out_channels, kernel_size=1, padding=0, dilation=1, bias=bias)
+
+
+class WaveNetResidualBlock(torch.nn.Module):
+    """Gated residual block of the PWG generator (layers/residual_block.py:43-140): dilated conv ->
+    + aux 1x1 -> tanh * sigmoid -> skip 1x1 and out 1x1 (+ residual) * sqrt(0.5).  Five launches:
+    aux conv, dilated conv (+aux fused as addend), gate, skip conv (+running skip sum fused), out conv
+    (+residual and the sqrt(0.5) scale fused)."""
+
+    def __init__(self, kernel_size=3, residual_channels=64, gate_channels=128, skip_channels=64, aux_channels=80,
+                 dropout=0.0, dilation=1, bias=True, use_causal_conv=False):
+        super().__init__()
+        if use_causal_conv:
+            raise NotImplementedError("use_causal_conv=True is outside the accelerated path")
+        assert (kernel_size - 1) % 2 == 0, "Not support even number kernel size."
+        self.dropout = dropout
+        self.use_causal_conv = use_causal_conv
+        self.conv = Conv1d(residual_channels, gate_channels, kernel_size, padding=(kernel_size - 1) // 2 * dilation,
+                           dilation=dilation, bias=bias)
+        self.conv1x1_aux = Conv1d1x1(aux_channels, gate_channels, bias=False) if aux_channels > 0 else None
+        gate_out_channels = gate_channels // 2
+        self.conv1x1_out = Conv1d1x1(gate_out_channels, residual_channels, bias=bias)
+        self.conv1x1_skip = Conv1d1x1(gate_out_channels, skip_channels, bias=bias)
+
+    def forward(self, x, c, skips=None, skip_scale=1.0):
+        """Returns (x_out, skips + s) -- the running skip sum is an addend of the skip conv's epilogue
+        (``skip_scale`` is the final ``sqrt(1/layers)`` of the generator, applied by the last block)."""
+        if self.dropout > 0.0 and self.training:
+            raise NotImplementedError("dropout > 0 in training has no gfx950 kernel (the YAML configs use 0.0)")
+        aux = self.conv1x1_aux(c) if (c is not None and self.conv1x1_aux is not None) else None
+        z = self.conv(x, add1=aux)
+        g = Fn.GateFn.apply(z)
+        s = self.conv1x1_skip(g, add1=skips, out_mul=skip_scale)
+        x = self.conv1x1_out(g, add1=x, out_mul=math.sqrt(0.5))
+        return x, s
 
 
 class HiFiGANResidualBlock(torch.nn.Module):

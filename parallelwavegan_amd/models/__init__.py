@@ -1,1 +1,3 @@
 from .hifigan import *  # noqa: F401,F403
+from .melgan import *  # noqa: F401,F403
+from .parallel_wavegan import *  # noqa: F401,F403

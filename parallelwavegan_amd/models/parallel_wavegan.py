@@ -1,0 +1,169 @@
+"""Parallel WaveGAN modules on the gfx950 kernel library (drop-in for
+``parallel_wavegan.models.parallel_wavegan``; reference: models/parallel_wavegan.py)."""
+import logging
+import math
+
+import numpy as np
+import torch
+
+from .. import functional as Fn
+from ..layers import upsample
+from ..layers.activation import FusedActivation
+from ..layers.residual_block import Conv1d, Conv1d1x1
+from ..layers.residual_block import WaveNetResidualBlock as ResidualBlock
+from ..layers.upsample import Conv2d as UpsampleConv2d
+
+
+def _norm_modules(module):
+    for m in module.modules():
+        if isinstance(m, (Conv1d, UpsampleConv2d)):
+            yield m
+
+
+class _WeightNormMixin:
+    def remove_weight_norm(self):
+        for m in _norm_modules(self):
+            if m.has_weight_norm:
+                m.remove_weight_norm()
+                logging.debug(f"Weight norm is removed from {m}.")
+
+    def apply_weight_norm(self):
+        for m in _norm_modules(self):
+            m.apply_weight_norm()
+            logging.debug(f"Weight norm is applied to {m}.")
+
+
+class ParallelWaveGANGenerator(torch.nn.Module, _WeightNormMixin):
+    """Non-autoregressive WaveNet generator (reference: models/parallel_wavegan.py:21-261)."""
+
+    def __init__(self, in_channels=1, out_channels=1, kernel_size=3, layers=30, stacks=3, residual_channels=64,
+                 gate_channels=128, skip_channels=64, aux_channels=80, aux_context_window=2, dropout=0.0, bias=True,
+                 use_weight_norm=True, use_causal_conv=False, upsample_conditional_features=True,
+                 upsample_net="ConvInUpsampleNetwork", upsample_params={"upsample_scales": [4, 4, 4, 4]}):
+        super().__init__()
+        if use_causal_conv:
+            raise NotImplementedError("use_causal_conv=True is outside the accelerated path (SURVEY.md s8f-3)")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.aux_channels, self.aux_context_window = aux_channels, aux_context_window
+        self.layers, self.stacks, self.kernel_size = layers, stacks, kernel_size
+        assert layers % stacks == 0
+        layers_per_stack = layers // stacks
+        self.first_conv = Conv1d1x1(in_channels, residual_channels, bias=True)
+        if upsample_conditional_features:
+            upsample_params = dict(upsample_params)
+            upsample_params.update({"use_causal_conv": use_causal_conv})
+            if upsample_net == "MelGANGenerator":
+                raise NotImplementedError("upsample_net=MelGANGenerator is not used by configs C1-C5")
+            if upsample_net == "ConvInUpsampleNetwork":
+                upsample_params.update({"aux_channels": aux_channels, "aux_context_window": aux_context_window})
+            self.upsample_net = getattr(upsample, upsample_net)(**upsample_params)
+            self.upsample_factor = int(np.prod(upsample_params["upsample_scales"]))
+        else:
+            self.upsample_net = None
+            self.upsample_factor = 1
+        self.conv_layers = torch.nn.ModuleList()
+        for layer in range(layers):
+            self.conv_layers.append(ResidualBlock(
+                kernel_size=kernel_size, residual_channels=residual_channels, gate_channels=gate_channels,
+                skip_channels=skip_channels, aux_channels=aux_channels, dilation=2 ** (layer % layers_per_stack),
+                dropout=dropout, bias=bias, use_causal_conv=use_causal_conv))
+        self.last_conv_layers = torch.nn.ModuleList([
+            FusedActivation("ReLU"),
+            Conv1d1x1(skip_channels, skip_channels, bias=True),
+            FusedActivation("ReLU"),
+            Conv1d1x1(skip_channels, out_channels, bias=True),
+        ])
+        if use_weight_norm:
+            self.apply_weight_norm()
+
+    def forward(self, z, c):
+        """z: noise (B, 1, T), c: mel (B, C, T' + 2*aux_context_window) -> (B, out_channels, T)."""
+        if c is not None and self.upsample_net is not None:
+            c = self.upsample_net(c)
+            assert c.size(-1) == z.size(-1)
+        x = self.first_conv(z)
+        skips = None
+        n = len(self.conv_layers)
+        for i, f in enumerate(self.conv_layers):
+            # `skips += h` and the final `skips *= sqrt(1/n)` ride on the skip conv's epilogue
+            x, skips = f(x, c, skips=skips, skip_scale=math.sqrt(1.0 / n) if i == n - 1 else 1.0)
+        x = self.last_conv_layers[1](skips, pre_act="relu")
+        return self.last_conv_layers[3](x, pre_act="relu")
+
+    @staticmethod
+    def _get_receptive_field_size(layers, stacks, kernel_size, dilation=lambda x: 2 ** x):
+        assert layers % stacks == 0
+        per_cycle = layers // stacks
+        return (kernel_size - 1) * sum(dilation(i % per_cycle) for i in range(layers)) + 1
+
+    @property
+    def receptive_field_size(self):
+        return self._get_receptive_field_size(self.layers, self.stacks, self.kernel_size)
+
+    def register_stats(self, stats):
+        from ..utils import load_stats
+
+        mean, scale = load_stats(stats)
+        self.register_buffer("mean", torch.from_numpy(mean).float())
+        self.register_buffer("scale", torch.from_numpy(scale).float())
+        logging.info("Successfully registered stats as buffer.")
+
+    def inference(self, c=None, x=None, normalize_before=False):
+        """c: (T', C) mel, x: (T, 1) noise (drawn here if omitted) -> (T, out_channels)."""
+        dev = next(self.parameters()).device
+        if x is not None:
+            if not isinstance(x, torch.Tensor):
+                x = torch.tensor(x, dtype=torch.float).to(dev)
+            x = x.transpose(1, 0).unsqueeze(0).contiguous()
+        else:
+            assert c is not None
+            x = torch.randn(1, 1, len(c) * self.upsample_factor).to(dev)
+        if c is not None:
+            if not isinstance(c, torch.Tensor):
+                c = torch.tensor(c, dtype=torch.float).to(dev)
+            if normalize_before:
+                c = (c - self.mean) / self.scale
+            c = c.transpose(1, 0).unsqueeze(0).contiguous()
+            c = Fn.pad1d(c, self.aux_context_window, self.aux_context_window, "replicate")
+        return self.forward(x, c).squeeze(0).transpose(1, 0)
+
+
+class ParallelWaveGANDiscriminator(torch.nn.Module, _WeightNormMixin):
+    """Dilated conv stack discriminator (reference: models/parallel_wavegan.py:264-371)."""
+
+    def __init__(self, in_channels=1, out_channels=1, kernel_size=3, layers=10, conv_channels=64, dilation_factor=1,
+                 nonlinear_activation="LeakyReLU", nonlinear_activation_params={"negative_slope": 0.2}, bias=True,
+                 use_weight_norm=True):
+        super().__init__()
+        assert (kernel_size - 1) % 2 == 0, "Not support even number kernel size."
+        assert dilation_factor > 0, "Dilation factor must be > 0."
+        self.conv_layers = torch.nn.ModuleList()
+        conv_in_channels = in_channels
+        for i in range(layers - 1):
+            if i == 0:
+                dilation = 1
+            else:
+                dilation = i if dilation_factor == 1 else dilation_factor ** i
+                conv_in_channels = conv_channels
+            self.conv_layers.append(Conv1d(conv_in_channels, conv_channels, kernel_size=kernel_size,
+                                           padding=(kernel_size - 1) // 2 * dilation, dilation=dilation, bias=bias))
+            self.conv_layers.append(FusedActivation(nonlinear_activation, **nonlinear_activation_params))
+        self.conv_layers.append(Conv1d(conv_in_channels, out_channels, kernel_size=kernel_size,
+                                       padding=(kernel_size - 1) // 2, bias=bias))
+        if use_weight_norm:
+            self.apply_weight_norm()
+
+    def forward(self, x):
+        """(B, 1, T) -> (B, 1, T)."""
+        mods = list(self.conv_layers)
+        i = 0
+        while i < len(mods):
+            conv = mods[i]
+            if i + 1 < len(mods) and isinstance(mods[i + 1], FusedActivation):
+                act = mods[i + 1]
+                x = conv(x, post_act=act.kind, post_slope=act.slope)
+                i += 2
+            else:
+                x = conv(x)
+                i += 1
+        return x

@@ -201,10 +201,67 @@ def hifigan_train_steps(name, seed, batch=2, n_steps=2):
     print(name, {k: round(float(v), 6) for k, v in out.items() if k.startswith("step")})
 
 
+def pwg(name, seed):
+    """PWG.v1 generator (config C1: 80 x 100 mel, + 2 context frames each side) and discriminator."""
+    import parallel_wavegan.models as RM
+
+    cfg = _load_yaml("parallel_wavegan.v1.yaml")
+    out = {}
+    g = RM.ParallelWaveGANGenerator(**cfg["generator_params"]).eval()
+    g.load_state_dict(synth.synth_state_dict(g.state_dict(), seed=seed, g_scale=synth.PWG_G_SCALE))
+    frames = 100
+    c = synth.synth_input("c", (1, 80, frames + 4), seed=seed)
+    z = synth.synth_input("z", (1, 1, frames * 256), seed=seed)
+    with torch.no_grad():
+        y = g(z, c)
+        # inference API: (T', C) mel without context (ReplicationPad inside), explicit noise x
+        y_inf = g.inference(c=c[0, :, 2:-2].transpose(0, 1).numpy(), x=z[0].transpose(0, 1).numpy())
+    out["g_y"], out["g_y_inference"] = y.numpy(), y_inf.numpy()
+    d = RM.ParallelWaveGANDiscriminator(**cfg["discriminator_params"]).eval()
+    d.load_state_dict(synth.synth_state_dict(d.state_dict(), seed=seed + 1, g_scale=1.4))
+    x = 0.5 * synth.synth_input("wave", (2, 1, 6000), seed=seed)
+    with torch.no_grad():
+        out["d_y"] = d(x).numpy()
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), meta=np.array([frames, seed]), **out)
+    print(name, "G std %.4f max %.4f | D std %.4f" % (y.std().item(), y.abs().max().item(), out["d_y"].std()))
+
+
+def mb_melgan(name, seed):
+    """Multi-band MelGAN.v2 generator (+PQMF synthesis), MelGAN multi-scale discriminator, PQMF."""
+    import parallel_wavegan.layers as RLy
+    import parallel_wavegan.models as RM
+
+    cfg = _load_yaml("multi_band_melgan.v2.yaml")
+    out = {}
+    g = RM.MelGANGenerator(**cfg["generator_params"]).eval()
+    g.load_state_dict(synth.synth_state_dict(g.state_dict(), seed=seed, g_scale=synth.MELGAN_G_SCALE))
+    c = synth.synth_input("c", (2, 80, 24), seed=seed)
+    pqmf = RLy.PQMF()
+    with torch.no_grad():
+        y_mb = g(c)
+        out["g_y_mb"] = y_mb.numpy()
+        out["g_y_full"] = pqmf.synthesis(y_mb).numpy()
+        g.pqmf = pqmf
+        out["g_y_inference"] = g.inference(c[0].transpose(0, 1).numpy()).numpy()
+        w = 0.5 * synth.synth_input("wave", (2, 1, 4096), seed=seed)
+        out["pqmf_analysis"] = pqmf.analysis(w).numpy()
+        out["pqmf_round_trip"] = pqmf.synthesis(pqmf.analysis(w)).numpy()
+    d = RM.MelGANMultiScaleDiscriminator(**cfg["discriminator_params"]).eval()
+    d.load_state_dict(synth.synth_state_dict(d.state_dict(), seed=seed + 1, g_scale=1.2))
+    with torch.no_grad():
+        o = d(w)
+    out["d_logits"] = np.concatenate([t[-1].reshape(-1).numpy() for t in o])
+    out["d_feat_stats"] = np.stack([_stats(f) for t in o for f in t])
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), meta=np.array([seed]), **out)
+    print(name, "G mb std %.4f max %.4f | D logits std %.4f" % (y_mb.std().item(), y_mb.abs().max().item(), out["d_logits"].std()))
+
+
 JOBS = {
     "hifigan_v1_g": lambda: hifigan_generator("hifigan_v1_g", synth.HIFIGAN_V1, 2, 32, 11),
     "hifigan_v1_libritts_g": lambda: hifigan_generator("hifigan_v1_libritts_g", synth.HIFIGAN_V1_LIBRITTS, 1, 28, 12),
     "hifigan_tiny_g": lambda: hifigan_generator("hifigan_tiny_g", synth.HIFIGAN_TINY, 3, 21, 13),
+    "pwg_v1": lambda: pwg("pwg_v1", 51),
+    "mb_melgan_v2": lambda: mb_melgan("mb_melgan_v2", 61),
     "hifigan_v1_d": lambda: hifigan_discriminator("hifigan_v1_d", 21),
     "losses": lambda: losses("losses", 31),
     "hifigan_v1_train": lambda: hifigan_train_steps("hifigan_v1_train", 41),

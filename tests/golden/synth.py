@@ -23,6 +23,8 @@ def synth_tensor(name, shape, seed=0, g_scale=1.0):
     leaf = name.rsplit(".", 1)[-1]
     if leaf == "weight_g":
         a = g_scale * (1.0 + 0.1 * r.standard_normal(shape))
+        if int(np.prod(shape)) == 1:  # single-row weights (PWG's 1x(2s+1) smoothing Conv2d): keep ~unit DC gain
+            a = np.abs(a)
     elif leaf == "weight_v" and len(shape) == 1:  # spectral-norm right singular vector estimate
         a = r.standard_normal(shape)
         a = a / np.linalg.norm(a)
@@ -76,6 +78,9 @@ def synth_input(name, shape, seed=0):
     r = _rng(seed, "input:" + name)
     return torch.from_numpy(r.standard_normal(tuple(shape)).astype(np.float32))
 
+
+PWG_G_SCALE = 1.0
+MELGAN_G_SCALE = 0.95
 
 # ---------------------------------------------------------------------------
 # Configurations exercised by the golden fixtures (subset of the reference's
