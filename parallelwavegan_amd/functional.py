@@ -239,6 +239,7 @@ class StretchConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, scale):
         x = _c(x)
+        ctx.w_shape = tuple(w.shape)
         w = _c(w.reshape(-1))
         _require_device(x, w)
         t_in = x.shape[-1]
@@ -260,7 +261,7 @@ class StretchConvFn(torch.autograd.Function):
         dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
         _lib.check(_L().pwg_stretch_conv_backward(_ptr(dy), _ptr(x), _ptr(w), _ptr(dx), _ptr(dw), rows, t_in, ctx.scale,
                                                   w.numel(), _stream()), "stretch_conv_backward")
-        return dx, dw, None
+        return dx, (None if dw is None else dw.reshape(ctx.w_shape)), None
 
 
 # ---------------------------------------------------------------------------------------------

@@ -79,17 +79,22 @@ def test_multi_band_melgan_and_pqmf_match_reference_golden(device):
     np.testing.assert_allclose(st, gold["d_feat_stats"][:, 1:], rtol=3e-5)
 
 
-def _grads_match(loss_dev, params_dev, loss_ref, params_ref, rtol=2e-3):
+def _grads_match(loss_dev, params_dev, loss_ref, params_ref, rtol=2e-3, names=None):
     gd = torch.autograd.grad(loss_dev, params_dev, allow_unused=True)
     gr = torch.autograd.grad(loss_ref, params_ref, allow_unused=True)
-    worst = 0.0
-    for a, b in zip(gd, gr):
+    bad = []
+    # gradients that are analytically zero (weight_v of 1-element rows, bias under a zero-sum
+    # cotangent) are pure rounding noise on both sides: floor the scale by the global gradient scale
+    floor = 1e-3 * max(b.abs().max().item() for b in gr if b is not None)
+    for i, (a, b) in enumerate(zip(gd, gr)):
         assert (a is None) == (b is None)
         if a is None:
             continue
-        denom = b.abs().max().item() + 1e-12
-        worst = max(worst, (a.cpu() - b).abs().max().item() / denom)
-    assert worst <= rtol, worst
+        denom = max(b.abs().max().item(), floor)
+        err = (a.cpu() - b).abs().max().item() / denom
+        if err > rtol:
+            bad.append((names[i] if names and i < len(names) else i, tuple(b.shape), round(err, 5)))
+    assert not bad, bad[:12]
 
 
 def test_pwg_training_gradients_match_oracle(device):
@@ -106,9 +111,9 @@ def test_pwg_training_gradients_match_oracle(device):
     sd_ref = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     y_ref = torch_cpu.pwg_generator(sd_ref, z, c, **cfg)
     assert max_abs(y, y_ref) <= WAVE_TOL
-    w = torch.linspace(-1, 1, y_ref.numel()).reshape(y_ref.shape)
+    w = torch.linspace(-0.5, 1, y_ref.numel()).reshape(y_ref.shape)
     _grads_match((y * w.to(device)).sum(), [p for _, p in g.named_parameters()], (y_ref * w).sum(),
-                 [sd_ref[n] for n in names])
+                 [sd_ref[n] for n in names], names=names)
     d = models.ParallelWaveGANDiscriminator(**PWG_D)
     sdd = synth.synth_state_dict(d.state_dict(), seed=10, g_scale=1.4)
     d.load_state_dict(sdd)
@@ -136,7 +141,7 @@ def test_melgan_training_gradients_match_oracle(device):
     sd_ref = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     y_ref = torch_cpu.pqmf_synthesis(torch_cpu.melgan_generator(sd_ref, c, **cfg))
     assert max_abs(y, y_ref) <= WAVE_TOL
-    w = torch.linspace(-1, 1, y_ref.numel()).reshape(y_ref.shape)
+    w = torch.linspace(-0.5, 1, y_ref.numel()).reshape(y_ref.shape)
     _grads_match((y * w.to(device)).sum(), [p for _, p in g.named_parameters()], (y_ref * w).sum(),
                  [sd_ref[n] for n in names])
     d = models.MelGANMultiScaleDiscriminator(**MB_D)
