@@ -256,12 +256,108 @@ def mb_melgan(name, seed):
     print(name, "G mb std %.4f max %.4f | D logits std %.4f" % (y_mb.std().item(), y_mb.abs().max().item(), out["d_logits"].std()))
 
 
+def _run_reference_trainer(cfg, model, criterion, optimizer, scheduler, batches, start_step):
+    import tempfile
+
+    from parallel_wavegan.bin.train import Trainer
+    from tqdm import tqdm
+
+    cfg.update(distributed=False, rank=0, outdir=tempfile.mkdtemp(), train_max_steps=start_step + len(batches),
+               save_interval_steps=10 ** 9, eval_interval_steps=10 ** 9, log_interval_steps=10 ** 9)
+    tr = Trainer(steps=start_step, epochs=0, data_loader={"train": batches, "dev": batches},
+                 sampler={"train": None, "dev": None}, model=model, criterion=criterion, optimizer=optimizer,
+                 scheduler=scheduler, config=cfg, device=torch.device("cpu"))
+    tr.tqdm = tqdm(disable=True)
+    out, prev = {}, {}
+    for i, b in enumerate(batches):
+        tr._train_step(b)
+        cur = dict(tr.total_train_loss)
+        for k, v in cur.items():
+            out[f"step{i}/{k}"] = v - prev.get(k, 0.0)
+        prev = cur
+        if i == 0:
+            for key in ("generator", "discriminator"):
+                names = {p: n for n, p in model[key].named_parameters()}
+                norms = {names[p]: float(s["exp_avg"].double().norm()) for p, s in optimizer[key].state.items()}
+                out[f"momnorm_names/{key}"] = np.array(sorted(norms))
+                out[f"momnorm/{key}"] = np.array([norms[k] for k in sorted(norms)])
+    for key, tag in (("generator", "g"), ("discriminator", "d")):
+        sd = model[key].state_dict()
+        names = sorted(sd)
+        out[f"final_names/{tag}"] = np.array(names)
+        out[f"final_sum/{tag}"] = np.array([float(sd[n].double().sum()) for n in names])
+        out[f"final_abs/{tag}"] = np.array([float(sd[n].double().abs().sum()) for n in names])
+    return out
+
+
+def pwg_train_steps(name, seed, n_steps=2):
+    """Two ``Trainer._train_step`` calls of the reference with parallel_wavegan.v1.yaml (RAdam, StepLR,
+    grad clipping 10 / 1, multi-resolution STFT loss, D active from the first step)."""
+    import parallel_wavegan.losses as RL
+    import parallel_wavegan.models as RM
+    from parallel_wavegan.optimizers import RAdam
+
+    cfg = _load_yaml("parallel_wavegan.v1.yaml")
+    cfg["discriminator_train_start_steps"] = 0
+    g = RM.ParallelWaveGANGenerator(**cfg["generator_params"])
+    d = RM.ParallelWaveGANDiscriminator(**cfg["discriminator_params"])
+    g.load_state_dict(synth.synth_state_dict(g.state_dict(), seed=seed, g_scale=synth.PWG_G_SCALE))
+    d.load_state_dict(synth.synth_state_dict(d.state_dict(), seed=seed + 1, g_scale=1.4))
+    model = {"generator": g, "discriminator": d}
+    criterion = {"gen_adv": RL.GeneratorAdversarialLoss(), "dis_adv": RL.DiscriminatorAdversarialLoss(),
+                 "stft": RL.MultiResolutionSTFTLoss(**cfg["stft_loss_params"])}
+    optimizer = {"generator": RAdam(g.parameters(), **cfg["generator_optimizer_params"]),
+                 "discriminator": RAdam(d.parameters(), **cfg["discriminator_optimizer_params"])}
+    scheduler = {k: torch.optim.lr_scheduler.StepLR(optimizer[k], **cfg[f"{k}_scheduler_params"])
+                 for k in ("generator", "discriminator")}
+    frames = 10
+    c = synth.synth_input("c", (2, 80, frames + 4), seed=seed)
+    z = synth.synth_input("z", (2, 1, frames * 256), seed=seed)
+    y = 0.5 * synth.synth_input("y", (2, 1, frames * 256), seed=seed)
+    cfg.update(use_stft_loss=True, use_subband_stft_loss=False, use_mel_loss=False, use_feat_match_loss=False)
+    out = _run_reference_trainer(cfg, model, criterion, optimizer, scheduler, [((z, c), y)] * n_steps, 1)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), meta=np.array([frames, n_steps, seed]), **out)
+    print(name, {k: round(float(v), 6) for k, v in out.items() if k.startswith("step")})
+
+
+def mb_melgan_train_steps(name, seed, n_steps=2):
+    """Two reference Trainer steps with multi_band_melgan.v2.yaml (Adam amsgrad eps 1e-7, full-band +
+    sub-band STFT losses through PQMF, MelGAN MSD active from the first step)."""
+    import parallel_wavegan.layers as RLy
+    import parallel_wavegan.losses as RL
+    import parallel_wavegan.models as RM
+
+    cfg = _load_yaml("multi_band_melgan.v2.yaml")
+    cfg["discriminator_train_start_steps"] = 0
+    g = RM.MelGANGenerator(**cfg["generator_params"])
+    d = RM.MelGANMultiScaleDiscriminator(**cfg["discriminator_params"])
+    g.load_state_dict(synth.synth_state_dict(g.state_dict(), seed=seed, g_scale=synth.MELGAN_G_SCALE))
+    d.load_state_dict(synth.synth_state_dict(d.state_dict(), seed=seed + 1, g_scale=1.2))
+    model = {"generator": g, "discriminator": d}
+    criterion = {"gen_adv": RL.GeneratorAdversarialLoss(), "dis_adv": RL.DiscriminatorAdversarialLoss(),
+                 "stft": RL.MultiResolutionSTFTLoss(**cfg["stft_loss_params"]),
+                 "sub_stft": RL.MultiResolutionSTFTLoss(**cfg["subband_stft_loss_params"]),
+                 "pqmf": RLy.PQMF(subbands=cfg["generator_params"]["out_channels"])}
+    optimizer = {k: torch.optim.Adam(model[k].parameters(), **cfg[f"{k}_optimizer_params"])
+                 for k in ("generator", "discriminator")}
+    scheduler = {k: torch.optim.lr_scheduler.MultiStepLR(optimizer[k], **cfg[f"{k}_scheduler_params"])
+                 for k in ("generator", "discriminator")}
+    c = synth.synth_input("c", (2, 80, 16), seed=seed)
+    y = 0.5 * synth.synth_input("y", (2, 1, 4096), seed=seed)
+    cfg.update(use_stft_loss=True, use_mel_loss=False)
+    out = _run_reference_trainer(cfg, model, criterion, optimizer, scheduler, [((c,), y)] * n_steps, 1)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), meta=np.array([16, n_steps, seed]), **out)
+    print(name, {k: round(float(v), 6) for k, v in out.items() if k.startswith("step")})
+
+
 JOBS = {
     "hifigan_v1_g": lambda: hifigan_generator("hifigan_v1_g", synth.HIFIGAN_V1, 2, 32, 11),
     "hifigan_v1_libritts_g": lambda: hifigan_generator("hifigan_v1_libritts_g", synth.HIFIGAN_V1_LIBRITTS, 1, 28, 12),
     "hifigan_tiny_g": lambda: hifigan_generator("hifigan_tiny_g", synth.HIFIGAN_TINY, 3, 21, 13),
     "pwg_v1": lambda: pwg("pwg_v1", 51),
     "mb_melgan_v2": lambda: mb_melgan("mb_melgan_v2", 61),
+    "pwg_v1_train": lambda: pwg_train_steps("pwg_v1_train", 71),
+    "mb_melgan_v2_train": lambda: mb_melgan_train_steps("mb_melgan_v2_train", 81),
     "hifigan_v1_d": lambda: hifigan_discriminator("hifigan_v1_d", 21),
     "losses": lambda: losses("losses", 31),
     "hifigan_v1_train": lambda: hifigan_train_steps("hifigan_v1_train", 41),

@@ -1,0 +1,77 @@
+"""CPU, world_size 2 (gloo): the data-parallel gradient reducer averages exactly like single-process
+training on the concatenated batch (the semantics apex DDP gives the reference)."""
+import os
+import socket
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from parallelwavegan_amd.distributed import GradReducer
+
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 3))
+    if rank == 1:  # ranks start different: broadcast must make them equal
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    params = list(model.parameters())
+    red = GradReducer(params, bucket_bytes=100)  # two small buckets
+    red.broadcast_parameters(params)
+    g = torch.Generator().manual_seed(123)
+    x_all = torch.randn(2, 5, 8, generator=g)  # per-rank shards of the global batch
+    y_all = torch.randn(2, 5, 3, generator=g)
+    red.prepare()
+    loss = torch.nn.functional.mse_loss(model(x_all[rank]), y_all[rank])
+    loss.backward()
+    scale = red.finish()
+    grads = [red.flat_grads[p] * scale for p in params]
+    # single-process reference on the concatenated batch (mean over both shards)
+    ref = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 3))
+    ref.load_state_dict(model.state_dict())
+    ref_loss = 0.5 * (torch.nn.functional.mse_loss(ref(x_all[0]), y_all[0]) +
+                      torch.nn.functional.mse_loss(ref(x_all[1]), y_all[1]))
+    ref_loss.backward()
+    err = max((a - b.grad).abs().max().item() for a, b in zip(grads, ref.parameters()))
+    none_left = all(p.grad is None for p in params)
+    # a second step where one parameter gets no gradient: its slot must come back as exactly zero
+    red.prepare()
+    params[-1].requires_grad_(False)
+    (model(x_all[rank]).sum() * 0 + params[0].sum()).backward()
+    red.finish()
+    zero_ok = float(red.flat_grads[params[-1]].abs().max()) == 0.0
+    out[rank] = (err, none_left, zero_ok, len(red.buckets))
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_world_size_2():
+    mp.set_start_method("spawn", force=True)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = _free_port()
+    procs = [mp.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for r in range(2):
+        err, none_left, zero_ok, nb = out[r]
+        assert err <= 1e-6, err
+        assert none_left and zero_ok and nb >= 2
