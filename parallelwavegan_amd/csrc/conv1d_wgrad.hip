@@ -36,11 +36,15 @@ struct WgArgs {
 
 constexpr int WG_TT = 32;  // reduction columns per chunk
 
-template <int TG>
+// WIN = false: one X tile per chunk shared by all taps (taps are shifted reads).
+// WIN = true : one 32-column window per tap (rotation-swizzled like the G tile); used when the taps
+//              are far apart ((taps-1)*dilation >> 32, e.g. PWG dilations up to 512) so that the
+//              shared tile would not fit the LDS.  Requires stride == 1 and width == 1.
+template <int TG, bool WIN>
 __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int XS = a.xs_stride;
-  const int buf_floats = 64 * WG_TT + 64 * XS;
+  const int buf_floats = 64 * WG_TT + (WIN ? TG * 64 * WG_TT : 64 * XS);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -89,6 +93,20 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgArgs a) {
         off = (unsigned)((((long)b * co_tot + grp * a.co_g + o) * a.n_cols + n) * 4);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(g_rs, (lds_ptr_t)(gs + j * 64), 4, off, 0, 0, 0);
     }
+    if (WIN) {
+      // ---- per-tap windows: element (i, n) of tap t at xs[t][i][(n + i) & 31]
+      for (int t = 0; t < ntaps; ++t)
+        for (int j = wave; j < 32; j += 4) {
+          const int row = 2 * j + lhi;
+          const int i = i0 + row;
+          const int f = n0 + ((l31 - row) & 31) + (k0 + t) * a.dil - a.pad;
+          unsigned off = OOB;
+          if (i < a.ci_g && f >= 0 && f < a.x_len)
+            off = (unsigned)((((long)b * ci_tot + grp * a.ci_g + i) * a.x_len + f) * 4);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr_t)(xs + t * (64 * WG_TT) + j * 64), 4, off, 0, 0, 0);
+        }
+      return;
+    }
     // ---- X tile: 64 rows, flat range [f0, f0 + L)
     const int h0 = n0 / W;
     int n_last = n0 + WG_TT - 1;
@@ -121,14 +139,17 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgArgs a) {
     const int h0 = n0 / W;
     const int orow = wave_o * 32 + l31;
     const float* grow = gs + orow * WG_TT;
-    const float* xrow = xs + (wave_i * 32 + l31) * XS;
+    const int irow = wave_i * 32 + l31;
+    const float* xrow = xs + irow * (WIN ? WG_TT : XS);
 #pragma unroll 4
     for (int step = 0; step < WG_TT / 2; ++step) {
       const int nl = 2 * step + lhi;
       float av = grow[(nl + orow) & 31];
       av = __builtin_fmaf(a.slope_g, __builtin_fminf(av, 0.f), __builtin_fmaxf(av, 0.f));
       int xo;
-      if (W == 1) {
+      if (WIN) {
+        xo = (nl + irow) & 31;
+      } else if (W == 1) {
         xo = nl * a.stride;
       } else {
         const int n = n0 + nl;
@@ -138,7 +159,7 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgArgs a) {
 #pragma unroll
       for (int t = 0; t < TG; ++t) {
         if (t < ntaps) {
-          float bv = xrow[xo + t * a.dil * W];
+          float bv = WIN ? xrow[xo + t * (64 * WG_TT)] : xrow[xo + t * a.dil * W];
           bv = __builtin_fmaf(a.slope_x, __builtin_fminf(bv, 0.f), __builtin_fmaxf(bv, 0.f));
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
         }
@@ -210,11 +231,15 @@ static int launch_wgrad(WgArgs a, int tap_groups, float* dw_out, float* workspac
                         hipStream_t stream, double flops, double bytes) {
   a.k0_step = TG;
   const int rows = (a.width == 1) ? WG_TT : ((WG_TT - 1) / a.width + 2);
-  int xs_len = ((rows - 1) * a.stride + (TG - 1) * a.dil + 1) * a.width;
+  const int ntaps_max = a.k < TG ? a.k : TG;
+  int xs_len = ((rows - 1) * a.stride + (ntaps_max - 1) * a.dil + 1) * a.width;
   a.xs_stride = round_up(xs_len, 64) + 1;  // whole DMA pieces per row + odd stride (bank spread)
-  const size_t lds = 2 * (size_t)(64 * WG_TT + 64 * a.xs_stride) * sizeof(float);
+  size_t lds = 2 * (size_t)(64 * WG_TT + 64 * a.xs_stride) * sizeof(float);
+  // taps far apart: per-tap windows instead of one shared tile
+  const bool win = a.stride == 1 && a.width == 1 && (ntaps_max - 1) * a.dil > 96;
+  if (win) lds = 2 * (size_t)(64 * WG_TT + TG * 64 * WG_TT) * sizeof(float);
   PWG_REQUIRE(lds <= 160 * 1024, PWG_ERR_UNSUPPORTED, "conv1d_backward_weight: tile needs %zu B of LDS", lds);
-  auto kern = conv1d_wgrad_kernel<TG>;
+  void (*kern)(WgArgs) = win ? conv1d_wgrad_kernel<TG, true> : conv1d_wgrad_kernel<TG, false>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -167,3 +167,21 @@ def test_all_tile_configs_agree(device):
         for dma in (True, False):
             y = ops.conv1d_forward_cfg(desc, x, wp, tile_config=cfg, use_dma=dma)
             _close(y, ref, f"cfg {cfg} dma={dma}")
+
+
+@pytest.mark.parametrize("dil", [64, 128, 512])
+def test_large_dilation_weight_gradient(dil, device):
+    """PWG dilations up to 512: the weight-gradient kernel switches to per-tap windows."""
+    g = torch.Generator().manual_seed(dil)
+    x = torch.randn(2, 64, 1500, generator=g, requires_grad=True)
+    w = (torch.randn(128, 64, 3, generator=g) / 14).requires_grad_()
+    b = torch.randn(128, generator=g, requires_grad=True)
+    y_ref = F.conv1d(x, w, b, padding=dil, dilation=dil)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    desc = ops.make_conv_desc(2, 64, 128, 1500, 1500, 3, 1, dil, dil, 1)
+    xd, wd, bd, dyd = (t.detach().to(device).contiguous() for t in (x, w, b, dy))
+    _close(ops.conv1d_forward(desc, xd, ops.pack_weight(desc, wd), bd), y_ref, "forward")
+    _close(ops.conv1d_backward_data(desc, dyd, ops.pack_weight_bwd(desc, wd)), x.grad, "backward_data")
+    dw, db = ops.conv1d_backward_weight(desc, xd, dyd, tuple(w.shape))
+    _close(dw, w.grad, "backward_weight")
