@@ -58,7 +58,7 @@ for name, d, e0, e1 in recs:
 tot = sum(v[1] for v in agg.values())
 print(f"total conv-launch time {tot:.1f} ms over {len(recs)} launches")
 print("kind              B  Cin  Cout   Tin  Tout  W   K  s  d   g  T |  n     ms   ms/launch  TFLOP/s")
-for (name, d), (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+for (name, d), (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     B, ci, co, ti, to, w, k, s, dil, g, tr_ = d
     fl = 2.0 * B * co * (ci // g) * k * (ti if tr_ else to) * w
     print(f"{name[7:]:16s} {B:2d} {ci:4d} {co:5d} {ti:5d} {to:5d} {w:2d} {k:3d} {s:2d} {dil:2d} {g:3d} {tr_:1d} | {n:2d} {ms:7.2f} {ms/n:8.3f}  {fl*n/ms/1e9:7.1f}")
