@@ -118,7 +118,7 @@ size_t pwg_conv1d_packed_weight_floats(const pwg_conv1d_desc* d);
 int pwg_conv1d_pack_weight(const pwg_conv1d_desc* d, const float* w, const float* scale,
                            float* w_packed, void* stream);
 
-/* y = fused conv forward (see above).  bias/add1/add2 may be NULL.
+/* y = fused conv forward (see above).  bias/add1/add2 may be NULL; y must not alias any input.
  * x: (batch, c_in, t_in*width)  y/add1/add2: (batch, c_out, t_out*width)     */
 int pwg_conv1d_forward(const pwg_conv1d_desc* d, const float* x, const float* w_packed,
                        const float* bias, const float* add1, const float* add2, float* y,
@@ -132,8 +132,8 @@ int pwg_conv1d_pack_weight_bwd(const pwg_conv1d_desc* d, const float* w, const f
 /* dx = d(pre_act)/dx(x) * conv_data_grad(dy) + accum.  `d` is the FORWARD descriptor
  * (its post_act/out_mul/out_div are NOT differentiated here: the caller passes the gradient
  * w.r.t. the pre-post_act, pre-scale result).  x: forward input (may be NULL when
- * pre_act == NONE); accum: optional tensor added to the result (gradient accumulation),
- * may alias dx.                                                                 */
+ * pre_act == NONE); accum: optional tensor added to the result (gradient accumulation);
+ * it must NOT alias dx (the kernels treat outputs as restrict).                                                                 */
 int pwg_conv1d_backward_data(const pwg_conv1d_desc* d, const float* dy, const float* w_packed_bwd,
                              const float* x, const float* accum, float* dx, void* stream);
 /* dw (torch layout, same shape as the forward weight) = sum_{b,t} dy * pre_act(x) taps;

@@ -12,6 +12,10 @@ PKG = os.path.dirname(HERE)
 LIB = os.path.join(PKG, "libpwgkernels.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# the MFMA kernels never produce or consume NaNs on purpose; without IEEE-mode sNaN quieting the
+# in-loop LeakyReLU is v_mul + v_max instead of three instructions (see csrc/conv1d.hip, ACT == 1)
+EXTRA = {"conv1d.hip": ["-fno-honor-nans", "-mno-amdgpu-ieee"],
+         "conv1d_wgrad.hip": ["-fno-honor-nans", "-mno-amdgpu-ieee"]}
 
 
 def sources():
@@ -41,7 +45,7 @@ def build(force=False, verbose=True):
         if (not force and os.path.exists(obj)
                 and os.path.getmtime(obj) > max(os.path.getmtime(p) for p in [src] + hdrs)):
             continue
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + EXTRA.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))

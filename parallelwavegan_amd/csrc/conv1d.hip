@@ -24,6 +24,8 @@
 //       half-wave -> coalesced 128-B stores; bias/residual/scale/tanh fused.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace pwg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -59,7 +61,8 @@ struct ConvArgs {
   float pre_slope, post_slope, out_mul, out_div;
   // backward-data only: multiply by d(pre_act)/dx evaluated at the forward input
   const float* mask_src;
-  float mask_slope;  // derivative for mask_src <= 0 (LeakyReLU slope, 0 for ReLU)
+  float mask_slope;
+  int dbg;  // timing experiments only (PWG_DBG env): 1 = no DMA after chunk 0, 2 = no barriers, 4 = no epilogue  // derivative for mask_src <= 0 (LeakyReLU slope, 0 for ReLU)
 };
 
 template <int WM, int WN, int WAVES_M, int WAVES_N, int CK>
@@ -238,7 +241,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv1d_mfma_kernel(Con
 // ---------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, int CK>
+// FAST = true: stride 1, width 1, halo (k-1)*dil <= 64.  The x-tile row stride is the compile-time
+//   constant BN + 64, so every LDS operand address is (one VGPR base per tap) + immediate and the
+//   two column sub-tiles of a wave come from one ds_read2_b32; the pre-activation is
+//   ACT = 0 none / 1 LeakyReLU with 0 < slope < 1 as max(v, slope*v) (2 VALU) / 2 generic (3 VALU).
+// FAST = false: any geometry (runtime row stride, per-lane column offsets), generic activation.
+template <int WM, int WN, int WAVES_M, int WAVES_N, int CK, bool FAST, int ACT>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv1d_mfma_dma_kernel(ConvArgs a) {
   constexpr int BM = 32 * WM * WAVES_M;
   constexpr int BN = 32 * WN * WAVES_N;
@@ -248,7 +256,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv1d_mfma_dma_kernel
   constexpr int KS = CK / 2;                // MFMA k-steps per tap
   static_assert((CK % ROWS_PER_PIECE) == 0, "CK must cover whole DMA pieces");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int XS = a.xs_stride;
+  const int XS = FAST ? BN + 64 : a.xs_stride;
   const int buf_floats = CK * XS + a.k * CK * BM;
 
   const int tid = threadIdx.x;
@@ -273,7 +281,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv1d_mfma_dma_kernel
   const int f0 = (h0 * a.stride - a.pad) * W;
   const int L = ((h1 - h0) * a.stride + (a.k - 1) * a.dil + 1) * W;
   const int tap_step = a.dil * W;
-  const int in_bytes = a.t_in * W * 4;
 
   int coff[WN];
 #pragma unroll
@@ -298,16 +305,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv1d_mfma_dma_kernel
   const int w_row_in_piece = lane / L4;
   const int w_col = (lane % L4) * 4;
 
+  // ONE buffer descriptor per workgroup, built from kernel arguments and blockIdx only so that the
+  // compiler can prove it wave-uniform (a per-row descriptor made hipcc wrap every DMA in a
+  // readfirstlane "waterfall" loop, cdna_hip_programming.md T20).  Padding / channel tails are
+  // expressed per lane: an out-of-range lane gets the offset 0xFFFFFFFC, which is past num_records
+  // and lands as 0.0 in LDS.
+  __amdgpu_buffer_rsrc_t x_rs = uniform_buffer_rsrc(xb, (unsigned)(a.cin_g * a.x_cstride) * 4u);
   auto issue = [&](int ci0, float* buf) {
     float* xs = buf;
     float* ws = buf + CK * XS;
     for (int r = wave; r < CK; r += NWAVES) {
       const int ci = ci0 + r;
-      const float* xrow = xb + (long)ci * a.x_cstride;
-      const int nrec = ci < a.cin_g ? in_bytes : 0;
-      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xrow, 0, nrec, 0x00020000);
-      for (int i0 = 0; i0 < L; i0 += 64)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(xs + r * XS + i0), 4, (f0 + i0 + lane) * 4, 0, 0, 0);
+      const int rowoff = ci * a.x_cstride;
+      for (int i0 = 0; i0 < L; i0 += 64) {
+        const int f = f0 + i0 + lane;
+        unsigned off = 0xFFFFFFFCu;
+        if (ci < a.cin_g && f >= 0 && f < a.t_in * W) off = (unsigned)(rowoff + f) * 4u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr_t)(xs + r * XS + i0), 4, off, 0, 0, 0);
+      }
     }
     for (int p = wave; p < npieces; p += NWAVES) {
       const int rr = p * ROWS_PER_PIECE + w_row_in_piece;
@@ -323,12 +338,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv1d_mfma_dma_kernel
   issue(0, smem);
   for (int c = 0; c < nchunks; ++c) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (!(a.dbg & 2)) __syncthreads();
     float* buf = smem + (c & 1) * buf_floats;
-    if (c + 1 < nchunks) issue((c + 1) * CK, smem + ((c + 1) & 1) * buf_floats);
+    if (c + 1 < nchunks && !(a.dbg & 1)) issue((c + 1) * CK, smem + ((c + 1) & 1) * buf_floats);
     const float* xs = buf;
     const float* wl = buf + CK * XS + wave_m * (WM * 32) + l31 + lhi * BM;  // + tap*CK*BM + 2*kk*BM + mi*32
-    const float* xl = xs + lhi * XS;                                          // + tap*tap_step + 2*kk*XS + coff
+    const float* xl = xs + lhi * XS + (FAST ? wave_n * (WN * 32) + l31 : 0);  // + tap*tap_step + 2*kk*XS + coff
     // operands of one tap live in registers; the next tap's LDS reads are issued before this
     // tap's MFMAs so that LDS latency hides under the 64-cycle matrix instructions
     auto load_ops = [&](int tap, float(&av)[KS][WM], float(&bv)[KS][WN]) {
@@ -339,7 +354,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv1d_mfma_dma_kernel
 #pragma unroll
         for (int mi = 0; mi < WM; ++mi) av[kk][mi] = wt[2 * kk * BM + mi * 32];
 #pragma unroll
-        for (int ni = 0; ni < WN; ++ni) bv[kk][ni] = xt[2 * kk * XS + coff[ni]];
+        for (int ni = 0; ni < WN; ++ni) bv[kk][ni] = FAST ? xt[2 * kk * XS + ni * 32] : xt[2 * kk * XS + coff[ni]];
       }
     };
     auto mma = [&](float(&av)[KS][WM], float(&bv)[KS][WN]) {
@@ -351,7 +366,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv1d_mfma_dma_kernel
           // branch-free pre-activation: v>0 ? v : v*slope  ==  max(v,0) + slope*min(v,0)  (exact:
           // one of the two terms is always 0); slope_eff = 1 (none) / slope (LeakyReLU) / 0 (ReLU)
           const float v = bv[kk][ni];
-          bact[ni] = __builtin_fmaf(slope_eff, __builtin_fminf(v, 0.f), __builtin_fmaxf(v, 0.f));
+          if (ACT == 0)
+            bact[ni] = v;
+          else if (ACT == 1)
+            bact[ni] = __builtin_fmaxf(v, v * slope_eff);  // LeakyReLU for 0 < slope < 1, exact
+          else
+            bact[ni] = __builtin_fmaf(slope_eff, __builtin_fminf(v, 0.f), __builtin_fmaxf(v, 0.f));
         }
 #pragma unroll
         for (int mi = 0; mi < WM; ++mi)
@@ -372,34 +392,59 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv1d_mfma_dma_kernel
     if (tap < a.k) mma(a0, b0);
   }
 
+  if (a.dbg & 4) {
+    if (acc[0][0][0] == 12345.678f) a.y[0] = 1.f;
+    return;
+  }
+  // ---- epilogue: D layout col = lane&31 (time), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (channel).
+  // Per 32x32 accumulator tile: first ALL addend loads of the lane's 16 outputs are issued (they are
+  // independent: y never aliases bias/add1/add2), then the arithmetic, then 16 stores -- memory
+  // latency is paid once per tile instead of once per element.
+  const float* __restrict__ bias_p = a.bias;
+  const float* __restrict__ add1_p = a.add1;
+  const float* __restrict__ add2_p = a.add2;
+  const float* __restrict__ mask_p = a.mask_src;
+  float* __restrict__ y_p = a.y;
   const long ybase = (long)b * a.y_bstride;
+  const bool single_phase = a.m_g == a.cout_g;
 #pragma unroll
   for (int ni = 0; ni < WN; ++ni) {
     const int n = n0 + (wave_n * WN + ni) * 32 + l31;
-    if (n >= a.n_cols) continue;
+    const bool n_ok = n < a.n_cols;
     const int q = n / W;
     const int wcol = n - q * W;
 #pragma unroll
     for (int mi = 0; mi < WM; ++mi) {
+      long off[16];
+      bool ok[16];
+      float bsv[16], a1[16], a2[16], mk[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + (wave_m * WM + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        if (m >= a.m_g) continue;
-        const int phase = m / a.cout_g;
-        const int co = m - phase * a.cout_g;
+        int phase = 0, co = m;
+        if (!single_phase) {
+          phase = m / a.cout_g;
+          co = m - phase * a.cout_g;
+        }
         const int u = q * a.out_stride + phase - a.out_off;
-        if (u < 0 || u >= a.t_out) continue;
         const int cglob = g * a.cout_g + co;
-        const long o = ybase + (long)cglob * a.y_cstride + (long)u * W + wcol;
-        float v = acc[mi][ni][r];
-        if (a.bias) v += a.bias[cglob];
-        if (a.mask_src) v *= (a.mask_src[o] > 0.f ? 1.f : a.mask_slope);
-        if (a.add1) v += a.add1[o];
-        if (a.add2) v += a.add2[o];
+        ok[r] = n_ok && m < a.m_g && u >= 0 && u < a.t_out;
+        off[r] = ybase + (long)cglob * a.y_cstride + (long)u * W + wcol;
+        bsv[r] = (bias_p && ok[r]) ? bias_p[cglob] : 0.f;
+        a1[r] = (add1_p && ok[r]) ? add1_p[off[r]] : 0.f;
+        a2[r] = (add2_p && ok[r]) ? add2_p[off[r]] : 0.f;
+        mk[r] = (mask_p && ok[r]) ? mask_p[off[r]] : 1.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[mi][ni][r] + bsv[r];
+        if (mask_p) v *= (mk[r] > 0.f ? 1.f : a.mask_slope);
+        v += a1[r];
+        v += a2[r];
         if (a.out_mul != 1.0f) v *= a.out_mul;
         if (a.out_div != 1.0f) v = v / a.out_div;
         v = apply_act(v, a.post_act, a.post_slope);
-        a.y[o] = v;
+        if (ok[r]) y_p[off[r]] = v;
       }
     }
   }
@@ -537,6 +582,29 @@ static int make_geometry(const pwg_conv1d_desc* d, Geometry* g) {
   return PWG_OK;
 }
 
+// configurations that also have FAST instantiations (the ones the heuristic picks for the G stacks)
+template <int WM, int WN, int WAVES_M, int WAVES_N, int CK>
+struct HasFast {
+  static constexpr bool value = (WM == 2 && WN == 2 && WAVES_M == 2 && WAVES_N == 2 && CK == 4) ||   // 128x128x4
+                                (WM == 2 && WN == 1 && WAVES_M == 2 && WAVES_N == 2 && CK == 8) ||   // 128x64x8
+                                (WM == 1 && WN == 1 && WAVES_M == 1 && WAVES_N == 4 && CK == 8) ||   // 32x128x8
+                                (WM == 2 && WN == 2 && WAVES_M == 1 && WAVES_N == 4 && CK == 4) ||   // 64x256x4
+                                (WM == 1 && WN == 2 && WAVES_M == 2 && WAVES_N == 2 && CK == 8) ||   // 64x128x8
+                                (WM == 1 && WN == 1 && WAVES_M == 2 && WAVES_N == 2 && CK == 8);     // 64x64x8
+};
+
+template <int WM, int WN, int WAVES_M, int WAVES_N, int CK>
+static void (*pick_dma_kernel(bool fast, int act))(ConvArgs) {
+  if constexpr (HasFast<WM, WN, WAVES_M, WAVES_N, CK>::value) {
+    if (fast) {
+      if (act == 0) return conv1d_mfma_dma_kernel<WM, WN, WAVES_M, WAVES_N, CK, true, 0>;
+      if (act == 1) return conv1d_mfma_dma_kernel<WM, WN, WAVES_M, WAVES_N, CK, true, 1>;
+      return conv1d_mfma_dma_kernel<WM, WN, WAVES_M, WAVES_N, CK, true, 2>;
+    }
+  }
+  return conv1d_mfma_dma_kernel<WM, WN, WAVES_M, WAVES_N, CK, false, 2>;
+}
+
 template <int WM, int WN, int WAVES_M, int WAVES_N, int CK, bool DMA>
 static int launch_conv(const ConvArgs& a0, const Geometry& g, int batch, int groups, hipStream_t stream) {
   constexpr int BM = 32 * WM * WAVES_M;
@@ -547,13 +615,18 @@ static int launch_conv(const ConvArgs& a0, const Geometry& g, int batch, int gro
   const int xs_len = ((rows - 1) * g.stride + (g.k_phase - 1) * g.dil + 1) * W;
   // DMA variant: whole 64-lane pieces per row; register variant: 16-B aligned weight tile
   a.xs_stride = DMA ? round_up(xs_len, 64) : round_up(xs_len, 4);
+  const bool fast = DMA && HasFast<WM, WN, WAVES_M, WAVES_N, CK>::value && g.stride == 1 && W == 1 &&
+                    (g.k_phase - 1) * g.dil <= 64;
+  if (fast) a.xs_stride = BN + 64;
+  const int act = a.pre_act == PWG_ACT_NONE ? 0
+                  : (a.pre_act == PWG_ACT_LEAKY_RELU && a.pre_slope > 0.f && a.pre_slope < 1.f) ? 1 : 2;
   const size_t buf = ((size_t)CK * a.xs_stride + (size_t)g.k_phase * CK * BM) * sizeof(float);
   const size_t lds = DMA ? 2 * buf : buf;
   PWG_REQUIRE(lds <= 160 * 1024, PWG_ERR_UNSUPPORTED,
               "conv1d: tile needs %zu B of LDS (k=%d stride=%d dil=%d)", lds, g.k_phase, g.stride, g.dil);
   void (*kern)(ConvArgs);
   if (DMA)
-    kern = conv1d_mfma_dma_kernel<WM, WN, WAVES_M, WAVES_N, CK>;
+    kern = pick_dma_kernel<WM, WN, WAVES_M, WAVES_N, CK>(fast, act);
   else
     kern = conv1d_mfma_kernel<WM, WN, WAVES_M, WAVES_N, CK>;
   if (lds > 64 * 1024) {
@@ -619,7 +692,8 @@ static size_t cfg_lds(int id, const Geometry& g, int W, bool dma) {
   TileCfg c = cfg_info(id);
   const int rows = (W == 1) ? c.bn : ((c.bn - 1) / W + 2);
   const int xs_len = ((rows - 1) * g.stride + (g.k_phase - 1) * g.dil + 1) * W;
-  const int xs = dma ? round_up(xs_len, 64) : round_up(xs_len, 4);
+  int xs = dma ? round_up(xs_len, 64) : round_up(xs_len, 4);
+  if (dma && g.stride == 1 && W == 1 && (g.k_phase - 1) * g.dil <= 64) xs = c.bn + 64;  // FAST row stride (upper bound)
   const size_t buf = ((size_t)c.ck * xs + (size_t)g.k_phase * c.ck * c.bm) * sizeof(float);
   return dma ? 2 * buf : buf;
 }
@@ -731,6 +805,8 @@ static int fill_args(const pwg_conv1d_desc* d, const Geometry& g, const float* x
   a.out_div = d->out_div;
   a.mask_src = nullptr;
   a.mask_slope = 0.f;
+  static const int dbg = getenv("PWG_DBG") ? atoi(getenv("PWG_DBG")) : 0;
+  a.dbg = dbg;
   *out = a;
   return PWG_OK;
 }

@@ -75,8 +75,8 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgArgs a) {
   const int c_begin = blockIdx.x * a.chunks_per_block;
   const int c_end = min(c_begin + a.chunks_per_block, a.chunks_total);
 
-  __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.g, 0, a.g_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t g_rs = uniform_buffer_rsrc(a.g, a.g_bytes);
+  __amdgpu_buffer_rsrc_t x_rs = uniform_buffer_rsrc(a.x, a.x_bytes);
   const unsigned OOB = 0xFFFFFFFCu;
 
   f32x16 acc[TG];
