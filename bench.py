@@ -176,7 +176,7 @@ def bench_train(args, dev, rank, world, dist):
                   generator_train_start_steps=0, discriminator_train_start_steps=0,
                   train_max_steps=10 ** 9, save_interval_steps=10 ** 9, eval_interval_steps=10 ** 9,
                   log_interval_steps=10 ** 9, distributed=world > 1, rank=rank, outdir=tempfile.mkdtemp(),
-                  progress=False)
+                  progress=False, use_hip_graph=not args.no_graph, graph_warmup_steps=2)
     gen = torch.Generator(device="cpu").manual_seed(200 + rank)
     b, t = args.train_batch, 8192
     c = torch.randn(b, 80, t // 256, generator=gen).to(dev)
@@ -208,6 +208,7 @@ def bench_train(args, dev, rank, world, dist):
     finite = all(v == v and abs(v) != float("inf") for v in tr.total_train_loss.values())
     out = None
     if rank == 0:
+        tr.config["use_hip_graph"] = False  # per-kernel event timing needs eager launches
         with ops.profile() as prof:
             tr._train_step(batch)
         tot_ms = sum(v["ms"] for v in prof.results.values())
@@ -228,6 +229,7 @@ def bench_train(args, dev, rank, world, dist):
             "segments_per_s": b * world * steps / elapsed,
             "scaling": "weak",
             "parallelism": f"dp{world}" if world > 1 else "single",
+            "hip_graph": bool(tr._graphs),
             "losses_finite": finite,
             "algorithmic_TFLOP_per_step_per_gpu": flops_step / 1e12,
             "achieved_TFLOPs_per_gpu": flops_step / (elapsed / steps) / 1e12,
@@ -250,7 +252,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step measurement")
     ap.add_argument("--train-steps", type=int, default=8)
-    ap.add_argument("--train-warmup", type=int, default=2)
+    ap.add_argument("--train-warmup", type=int, default=4, help=">= 3 so that the hipGraph capture is not timed")
+    ap.add_argument("--no-graph", action="store_true", help="run the training step eagerly (no hipGraph replay)")
     ap.add_argument("--train-batch", type=int, default=16)
     args = ap.parse_args()
 

@@ -277,6 +277,12 @@ int pwg_adam_step(const void* chunks, int32_t n_chunks, float lr, float beta1, f
                   float weight_decay, int32_t step, float grad_scale, void* stream);
 int pwg_radam_step(const void* chunks, int32_t n_chunks, float lr, float beta1, float beta2, float eps,
                    float weight_decay, int32_t step, float grad_scale, void* stream);
+/* hipGraph-friendly variants: the scalars come from 8 floats in DEVICE memory
+ *   [lr, beta1, beta2, eps, weight_decay, step_size, aux, grad_scale]
+ * (Adam: step_size = lr/(1-beta1^t), aux = sqrt(1-beta2^t); RAdam: step_size per radam.py:63-86
+ * incl. lr, aux = 1 when rectified), refreshed by the host between graph replays.     */
+int pwg_adam_step_dev(const void* chunks, int32_t n_chunks, const float* hyper, void* stream);
+int pwg_radam_step_dev(const void* chunks, int32_t n_chunks, const float* hyper, void* stream);
 /* torch.nn.utils.clip_grad_norm_ (bin/train.py:289-293,329-333): out[0] = total L2 norm,
  * out[1] = applied coefficient; gradients are scaled in place.  workspace >= n_chunks floats. */
 int pwg_clip_grad_norm(const void* chunks, int32_t n_chunks, float max_norm, float* out, float* workspace,

@@ -89,6 +89,8 @@ SIGNATURES = {
     "pwg_reduce_backward": (ctypes.c_int, [_vp, _vp, _f32, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
     "pwg_adam_step": (ctypes.c_int, [_vp, _i32, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
     "pwg_radam_step": (ctypes.c_int, [_vp, _i32, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
+    "pwg_adam_step_dev": (ctypes.c_int, [_vp, _i32, _vp, _vp]),
+    "pwg_radam_step_dev": (ctypes.c_int, [_vp, _i32, _vp, _vp]),
     "pwg_clip_grad_norm": (ctypes.c_int, [_vp, _i32, _f32, _vp, _vp, _vp]),
     "pwg_weight_norm_scale": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "pwg_scale_rows": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),

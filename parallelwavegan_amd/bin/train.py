@@ -64,6 +64,8 @@ class Trainer(object):
         if "VQVAE" in gtype or "Duration" in gtype:
             raise NotImplementedError(f"{gtype} is outside the accelerated hot path (SURVEY.md s2)")
         self._pending = []  # (name, device scalar) of the current logging interval
+        self._capturing = False
+        self._graphs, self._graph_seen = {}, {}
         self.reducers = None
         if config.get("distributed", False):
             self.reducers = {k: GradReducer(list(self._module(k).parameters())) for k in ("generator", "discriminator")}
@@ -121,6 +123,12 @@ class Trainer(object):
         self._pending.append((name, value.detach()))
 
     def _flush_pending(self):
+        for entry in self._graphs.values():  # losses accumulated on the device by graph replays
+            if entry["accum"] is not None and entry["count"]:
+                for n, v in zip(entry["names"], entry["accum"].cpu().tolist()):
+                    self.total_train_loss[n] += v
+                entry["accum"].zero_()
+                entry["count"] = 0
         if not self._pending:
             return
         names = [n for n, _ in self._pending]
@@ -164,11 +172,87 @@ class Trainer(object):
                 opt.grad_scale = 1.0
             clip_grad_norm_(pairs, max_norm)
         opt.step()
-        self.scheduler[key].step()
+        if not self._capturing:
+            self.scheduler[key].step()
+
+    # ------------------------------------------------------------------ hipGraph mode
+    def _graph_ok(self):
+        cfg = self.config
+        return (cfg.get("use_hip_graph", False) and not cfg.get("distributed", False)
+                and cfg.get("generator_grad_norm", -1) <= 0 and cfg.get("discriminator_grad_norm", -1) <= 0)
+
+    def _phases(self):
+        cfg = self.config
+        return (self.steps > cfg.get("generator_train_start_steps", 0),
+                self.steps > cfg["discriminator_train_start_steps"])
+
+    def _train_step_graphed(self, batch):
+        """Replay the whole optimisation step (G forward/backward/update, D forward/backward/update,
+        ~1500 kernel launches) as ONE hipGraph launch.  The first ``graph_warmup_steps`` steps run
+        eagerly (they size every cache and the allocator), then the step is captured once per
+        (active phases, batch shapes) signature.  Per replay the host only copies the batch into the
+        static buffers, refreshes the optimizers' device scalars and steps the LR schedulers."""
+        x, y = self._parse_batch(batch)
+        key = (self._phases(), tuple(tuple(t.shape) for t in x if t is not None), tuple(y.shape))
+        entry = self._graphs.get(key)
+        if entry is None:
+            self._graph_seen[key] = self._graph_seen.get(key, 0) + 1
+            if self._graph_seen[key] <= self.config.get("graph_warmup_steps", 2):
+                return False  # run this step eagerly
+            torch.cuda.synchronize()
+            static_x = [None if t is None else t.clone() for t in x]
+            static_y = y.clone()
+            self._flush_pending()
+            graph = torch.cuda.CUDAGraph()
+            self._capturing = True
+            try:
+                with torch.cuda.graph(graph):
+                    self._device_step(static_x, static_y)
+                    names = [n for n, _ in self._pending]
+                    vals = torch.stack([v.reshape(()) for _, v in self._pending]) if self._pending else None
+            finally:
+                self._capturing = False
+            self._pending = []
+            accum = torch.zeros_like(vals) if vals is not None else None
+            entry = dict(graph=graph, x=static_x, y=static_y, names=names, vals=vals, accum=accum, count=0)
+            self._graphs[key] = entry
+        for s, t in zip(entry["x"], x):
+            if s is not None:
+                s.copy_(t, non_blocking=True)
+        entry["y"].copy_(y, non_blocking=True)
+        gen_on, disc_on = key[0]
+        if gen_on:
+            self.optimizer["generator"].grad_scale = 1.0
+            self.optimizer["generator"].prepare()
+        if disc_on:
+            self.optimizer["discriminator"].grad_scale = 1.0
+            self.optimizer["discriminator"].prepare()
+        entry["graph"].replay()
+        from ..ops import bump_param_epoch
+
+        bump_param_epoch()
+        if entry["accum"] is not None:
+            entry["accum"].add_(entry["vals"])
+            entry["count"] += 1
+        if gen_on:
+            self.scheduler["generator"].step()
+        if disc_on:
+            self.scheduler["discriminator"].step()
+        return True
 
     def _train_step(self, batch):
+        if self._graph_ok() and self._train_step_graphed(batch):
+            pass
+        else:
+            x, y = self._parse_batch(batch)
+            self._device_step(x, y)
+        self.steps += 1
+        if getattr(self, "tqdm", None) is not None:
+            self.tqdm.update(1)
+        self._check_train_finish()
+
+    def _device_step(self, x, y):
         cfg = self.config
-        x, y = self._parse_batch(batch)
         disc_on = self.steps > cfg["discriminator_train_start_steps"]
 
         # ---------------- generator ----------------
@@ -225,11 +309,6 @@ class Trainer(object):
             self._log("train/fake_loss", fake_loss)
             self._log("train/discriminator_loss", dis_loss)
             self._step_optimizer("discriminator", dis_loss)
-
-        self.steps += 1
-        if getattr(self, "tqdm", None) is not None:
-            self.tqdm.update(1)
-        self._check_train_finish()
 
     def _train_epoch(self):
         for train_steps_per_epoch, batch in enumerate(self.data_loader["train"], 1):

@@ -15,6 +15,20 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+static std::mutex g_lds_mu;
+static std::vector<std::pair<const void*, size_t>> g_lds_set;
+bool lds_limit_is_set(const void* kern, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_lds_mu);
+  for (auto& e : g_lds_set)
+    if (e.first == kern) {
+      if (e.second >= bytes) return true;
+      e.second = bytes;
+      return false;
+    }
+  g_lds_set.emplace_back(kern, bytes);
+  return false;
+}
+
 // ---- per-launch event timing ------------------------------------------------------------
 struct ProfRec {
   const char* kernel;

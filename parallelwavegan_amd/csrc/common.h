@@ -55,6 +55,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_buffer_rsrc(const void
   return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, n, 0x00020000);
 }
 
+// remembers the largest dynamic-LDS limit already configured per kernel (so that launches inside a
+// hipGraph capture never call hipFuncSetAttribute again)
+bool lds_limit_is_set(const void* kern, size_t bytes);
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 

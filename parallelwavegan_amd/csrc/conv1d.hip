@@ -629,7 +629,7 @@ static int launch_conv(const ConvArgs& a0, const Geometry& g, int batch, int gro
     kern = pick_dma_kernel<WM, WN, WAVES_M, WAVES_N, CK>(fast, act);
   else
     kern = conv1d_mfma_kernel<WM, WN, WAVES_M, WAVES_N, CK>;
-  if (lds > 64 * 1024) {
+  if (lds > 64 * 1024 && !lds_limit_is_set(reinterpret_cast<const void*>(kern), lds)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     PWG_REQUIRE(e == hipSuccess, PWG_ERR_LAUNCH, "conv1d: cannot raise LDS limit to %zu: %s", lds,

@@ -293,7 +293,7 @@ static int launch_wgrad(WgArgs a, const WgPlan& p, float* dw_out, float* workspa
   const size_t lds = p.lds;
   PWG_REQUIRE(lds <= 160 * 1024, PWG_ERR_UNSUPPORTED, "conv1d_backward_weight: tile needs %zu B of LDS", lds);
   void (*kern)(WgArgs) = p.win ? conv1d_wgrad_kernel<TG, true, SMALL, TT> : conv1d_wgrad_kernel<TG, false, SMALL, TT>;
-  if (lds > 64 * 1024) {
+  if (lds > 64 * 1024 && !lds_limit_is_set(reinterpret_cast<const void*>(kern), lds)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     PWG_REQUIRE(e == hipSuccess, PWG_ERR_LAUNCH, "conv1d_backward_weight: cannot raise LDS limit: %s",

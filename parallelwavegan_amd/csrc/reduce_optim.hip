@@ -126,6 +126,54 @@ __global__ void radam_multi_kernel(const OptChunk* chunks, float lr, float b1, f
   }
 }
 
+// Variants reading their scalars from DEVICE memory, so that the launch can live inside a captured
+// hipGraph while the host refreshes lr / bias corrections between replays:
+//   hyper = [lr, beta1, beta2, eps, weight_decay, step_size, aux, grad_scale]
+//   Adam : step_size = lr / (1 - beta1^t), aux = sqrt(1 - beta2^t)
+//   RAdam: step_size as radam.py:63-86 (includes lr), aux = 1 if rectified (N_sma >= 5) else 0
+__global__ void adam_multi_dev_kernel(const OptChunk* chunks, const float* hyper) {
+  const OptChunk c = chunks[blockIdx.x];
+  const float b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], step = hyper[5],
+              sqrt_bias_c2 = hyper[6], grad_scale = hyper[7];
+  for (int i = threadIdx.x; i < c.n; i += blockDim.x) {
+    float p = c.p[i];
+    float g = c.g[i] * grad_scale;
+    if (wd != 0.f) g += wd * p;
+    const float m = b1 * c.m[i] + (1.f - b1) * g;
+    const float v = b2 * c.v[i] + (1.f - b2) * g * g;
+    c.m[i] = m;
+    c.v[i] = v;
+    float vv = v;
+    if (c.vmax) {
+      vv = fmaxf(c.vmax[i], v);
+      c.vmax[i] = vv;
+    }
+    const float denom = sqrtf(vv) / sqrt_bias_c2 + eps;
+    c.p[i] = p - step * (m / denom);
+  }
+}
+
+__global__ void radam_multi_dev_kernel(const OptChunk* chunks, const float* hyper) {
+  const OptChunk c = chunks[blockIdx.x];
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], step_size = hyper[5],
+              grad_scale = hyper[7];
+  const bool rectified = hyper[6] != 0.f;
+  for (int i = threadIdx.x; i < c.n; i += blockDim.x) {
+    float p = c.p[i];
+    const float g = c.g[i] * grad_scale;
+    const float v = b2 * c.v[i] + (1.f - b2) * g * g;
+    const float m = b1 * c.m[i] + (1.f - b1) * g;
+    c.m[i] = m;
+    c.v[i] = v;
+    if (wd != 0.f) p += -wd * lr * p;
+    if (rectified)
+      p += -step_size * (m / (sqrtf(v) + eps));
+    else
+      p += -step_size * m;
+    c.p[i] = p;
+  }
+}
+
 // sum of squares of many tensors (grad-norm clipping): partial per chunk, then one block
 __global__ void sqsum_multi_kernel(const OptChunk* chunks, float* partial) {
   __shared__ float red[4];
@@ -240,5 +288,25 @@ extern "C" int pwg_clip_grad_norm(const void* chunks, int32_t n_chunks, float ma
   hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, stream, workspace, n_chunks, max_norm, out);
   hipLaunchKernelGGL(scale_grads_multi_kernel, dim3(n_chunks), dim3(256), 0, stream, (const OptChunk*)chunks, out);
   PWG_CHECK_LAUNCH("clip_grad_norm");
+  return PWG_OK;
+}
+
+// hyper: 8 floats in device memory (layout above the *_dev kernels); the host refreshes it per step
+extern "C" int pwg_adam_step_dev(const void* chunks, int32_t n_chunks, const float* hyper, void* stream) {
+  PWG_REQUIRE(chunks && hyper, PWG_ERR_NULL, "adam_step_dev: NULL pointer");
+  PWG_REQUIRE(n_chunks > 0, PWG_ERR_BAD_SHAPE, "adam_step_dev: bad arguments");
+  ProfScope prof((hipStream_t)stream, "adam_multi_kernel", 0, 28.0 * 65536.0 * n_chunks);
+  hipLaunchKernelGGL(adam_multi_dev_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream,
+                     (const OptChunk*)chunks, hyper);
+  PWG_CHECK_LAUNCH("adam_step_dev");
+  return PWG_OK;
+}
+
+extern "C" int pwg_radam_step_dev(const void* chunks, int32_t n_chunks, const float* hyper, void* stream) {
+  PWG_REQUIRE(chunks && hyper, PWG_ERR_NULL, "radam_step_dev: NULL pointer");
+  PWG_REQUIRE(n_chunks > 0, PWG_ERR_BAD_SHAPE, "radam_step_dev: bad arguments");
+  hipLaunchKernelGGL(radam_multi_dev_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream,
+                     (const OptChunk*)chunks, hyper);
+  PWG_CHECK_LAUNCH("radam_step_dev");
   return PWG_OK;
 }

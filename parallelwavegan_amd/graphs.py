@@ -1,0 +1,42 @@
+"""hipGraph capture helpers (torch.cuda.graphs drives hipStreamBeginCapture on ROCm; every kernel of
+libpwgkernels.so is launched on torch's current stream, so it is captured like any ATen kernel).
+
+A GAN-vocoder forward is ~80 dependent launches of a few tens of microseconds each at batch 1; an
+eager Python loop is host-bound there.  ``GraphedInference`` replays the whole generator forward
+as one graph launch per utterance shape.
+"""
+import torch
+
+
+class GraphedInference:
+    """Capture ``model.forward`` for fixed input shapes; ``__call__`` copies the new inputs into the
+    static buffers and replays.  One graph per distinct input shape (cached)."""
+
+    def __init__(self, model, warmup=2):
+        self.model = model
+        self.warmup = warmup
+        self._graphs = {}
+
+    def _capture(self, inputs):
+        static_in = [t.clone() for t in inputs]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(self.warmup):  # compiles nothing, but fills weight caches / sets kernel attributes
+                self.model(*static_in)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(g):
+            static_out = self.model(*static_in)
+        return g, static_in, static_out
+
+    @torch.no_grad()
+    def __call__(self, *inputs):
+        key = tuple((tuple(t.shape), t.dtype) for t in inputs)
+        if key not in self._graphs:
+            self._graphs[key] = self._capture(inputs)
+        g, static_in, static_out = self._graphs[key]
+        for s, t in zip(static_in, inputs):
+            s.copy_(t, non_blocking=True)
+        g.replay()
+        return static_out

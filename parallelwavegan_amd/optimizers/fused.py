@@ -1,12 +1,19 @@
-"""Fused multi-tensor optimizers on the HIP kernels (pwg_adam_step / pwg_radam_step).
+"""Fused multi-tensor optimizers on the HIP kernels (pwg_adam_step_dev / pwg_radam_step_dev).
 
 They subclass ``torch.optim.Optimizer`` only for parameter-group bookkeeping, LR schedulers and a
 ``state_dict`` layout interchangeable with ``torch.optim.Adam`` / the reference's
 ``parallel_wavegan/optimizers/radam.py``: per-parameter ``step``, ``exp_avg``, ``exp_avg_sq``
 (+ ``max_exp_avg_sq`` with amsgrad).  One kernel launch updates every parameter of a group:
 the launch reads a device table of 64 Ki-element chunks (pointer, length) built on the host.
+
+hipGraph friendliness: the scalars of an update (lr, bias corrections, rectification, gradient
+scale) live in 8 floats of device memory per group.  ``step()`` = ``prepare()`` (host: advance the
+step count, compute the scalars, stage them through pinned memory) + the kernel launch.  While a
+stream is being captured only the launch is recorded; the trainer calls ``prepare()`` before
+every replay.
 """
 import ctypes
+import math
 
 import numpy as np
 import torch
@@ -17,10 +24,21 @@ from ..ops import _stream, bump_param_epoch
 CHUNK = 65536
 
 
-class _FusedBase(torch.optim.Optimizer):
-    _kernel = None
-    _has_vmax = False
+def _capturing():
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
 
+
+class _FusedBase(torch.optim.Optimizer):
+    _entry = None  # name of the C entry point
+
+    def __init__(self, params, defaults):
+        super().__init__(params, defaults)
+        self.grad_scale = 1.0
+        self.flat_grads = None
+        self._dev = {}  # group index -> dict(hyper_dev, hyper_pin, table_pin, table_dev, n_chunks)
+        self._active = {}  # group index -> set of parameters that had a gradient at the last step()
+
+    # ---- per-parameter state (torch-compatible layout)
     def _state_for(self, p, amsgrad):
         st = self.state[p]
         if len(st) == 0:
@@ -35,24 +53,10 @@ class _FusedBase(torch.optim.Optimizer):
     def _as_int(step):
         return int(step.item()) if isinstance(step, torch.Tensor) else int(step)
 
-    def _build_table(self, entries, device):
-        """entries: list of (p, g, m, v, vmax_or_None) tensors -> device int64 table (n_chunks, 6)."""
-        rows = []
-        for p, g, m, v, vmax in entries:
-            n = p.numel()
-            pp, gp, mp, vp = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
-            xp = vmax.data_ptr() if vmax is not None else 0
-            for off in range(0, n, CHUNK):
-                cnt = min(CHUNK, n - off)
-                b = off * 4
-                rows.append((pp + b, gp + b, mp + b, vp + b, (xp + b) if xp else 0, cnt))
-        table = np.asarray(rows, dtype=np.int64)
-        return torch.from_numpy(table).to(device, non_blocking=True), len(rows)
-
-    def _grads(self, group):
+    def _pairs(self, group):
         """(param, grad) pairs; ``flat_grads`` (set by the DDP reducer) maps param -> reduced grad view."""
         out = []
-        override = getattr(self, "flat_grads", None)
+        override = self.flat_grads
         for p in group["params"]:
             g = override.get(p) if override is not None else None
             if g is None:
@@ -68,14 +72,64 @@ class _FusedBase(torch.optim.Optimizer):
             out.append((p, g))
         return out
 
+    def _slot(self, gi, device):
+        d = self._dev.get(gi)
+        if d is None:
+            d = dict(hyper_dev=torch.zeros(8, device=device, dtype=torch.float32),
+                     hyper_pin=torch.zeros(8, dtype=torch.float32).pin_memory(), table_pin=None, table_dev=None,
+                     n_chunks=0)
+            self._dev[gi] = d
+        return d
 
-class Adam(_FusedBase):
-    """``torch.optim.Adam`` semantics (L2 weight decay, optional amsgrad) in one launch per group."""
+    def _table(self, d, entries, device):
+        rows = []
+        for p, g, m, v, vmax in entries:
+            n = p.numel()
+            pp, gp, mp, vp = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
+            xp = vmax.data_ptr() if vmax is not None else 0
+            for off in range(0, n, CHUNK):
+                b = off * 4
+                rows.append((pp + b, gp + b, mp + b, vp + b, (xp + b) if xp else 0, min(CHUNK, n - off)))
+        arr = np.asarray(rows, dtype=np.int64)
+        if d["table_pin"] is None or d["table_pin"].shape[0] < arr.shape[0]:
+            if _capturing():
+                raise RuntimeError("the optimizer's chunk table must be sized before graph capture "
+                                   "(run one eager step first)")
+            d["table_pin"] = torch.zeros((arr.shape[0], 6), dtype=torch.int64).pin_memory()
+        d["table_pin"][: arr.shape[0]].copy_(torch.from_numpy(arr))
+        d["table_dev"] = d["table_pin"][: arr.shape[0]].to(device, non_blocking=True)
+        d["n_chunks"] = arr.shape[0]
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, **unused):
-        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=amsgrad)
-        super().__init__(params, defaults)
-        self.grad_scale = 1.0
+    # ---- to be provided by subclasses
+    def _hyper(self, group, t):
+        raise NotImplementedError
+
+    def _amsgrad(self, group):
+        return False
+
+    # ---- public
+    def prepare(self):
+        """Host half of a step: advance the step counts, refresh the device scalars.  Called by
+        ``step()`` in eager mode and by the trainer before each hipGraph replay.  Only parameters
+        that received a gradient at the last ``step()`` are advanced (torch.optim semantics)."""
+        for gi, group in enumerate(self.param_groups):
+            steps = set()
+            dev = None
+            active = self._active.get(gi)
+            for p in group["params"]:
+                if (active is None and p.requires_grad) or (active is not None and p in active):
+                    st = self._state_for(p, self._amsgrad(group))
+                    st["step"] = self._as_int(st["step"]) + 1
+                    steps.add(st["step"])
+                    dev = p.device
+            if not steps:
+                continue
+            if len(steps) != 1:
+                raise RuntimeError("fused optimizers need one common step count per parameter group")
+            d = self._slot(gi, dev)
+            h = self._hyper(group, steps.pop())
+            d["hyper_pin"].copy_(torch.tensor(h + [float(self.grad_scale)], dtype=torch.float32))
+            d["hyper_dev"].copy_(d["hyper_pin"], non_blocking=True)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -83,73 +137,80 @@ class Adam(_FusedBase):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        capturing = _capturing()
+        for gi, group in enumerate(self.param_groups):
+            self._active[gi] = {p for p, _ in self._pairs(group)}
+        if not capturing:
+            self.prepare()
         lib = _lib.lib()
-        for group in self.param_groups:
-            pairs = self._grads(group)
+        for gi, group in enumerate(self.param_groups):
+            pairs = self._pairs(group)
             if not pairs:
                 continue
-            by_step = {}
+            d = self._slot(gi, pairs[0][0].device)
+            entries = []
             for p, g in pairs:
-                st = self._state_for(p, group["amsgrad"])
-                step = self._as_int(st["step"]) + 1
-                st["step"] = step
-                by_step.setdefault(step, []).append((p, g, st["exp_avg"], st["exp_avg_sq"], st.get("max_exp_avg_sq")))
-            for step, entries in by_step.items():
-                table, n = self._build_table(entries, entries[0][0].device)
-                b1, b2 = group["betas"]
-                _lib.check(lib.pwg_adam_step(ctypes.c_void_p(table.data_ptr()), n, float(group["lr"]), float(b1),
-                                             float(b2), float(group["eps"]), float(group["weight_decay"]), step,
-                                             float(self.grad_scale), _stream()), "adam_step")
-                self._keep = table  # the launch is asynchronous: keep the table alive until the next step
+                st = self._state_for(p, self._amsgrad(group))
+                entries.append((p, g, st["exp_avg"], st["exp_avg_sq"], st.get("max_exp_avg_sq")))
+            self._table(d, entries, pairs[0][0].device)
+            fn = getattr(lib, self._entry)
+            _lib.check(fn(ctypes.c_void_p(d["table_dev"].data_ptr()), d["n_chunks"],
+                          ctypes.c_void_p(d["hyper_dev"].data_ptr()), _stream()), self._entry)
         bump_param_epoch()  # parameters changed behind torch's back: invalidate packed-weight caches
         return loss
+
+
+class Adam(_FusedBase):
+    """``torch.optim.Adam`` semantics (L2 weight decay, optional amsgrad) in one launch per group."""
+
+    _entry = "pwg_adam_step_dev"
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, **unused):
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=amsgrad))
+
+    def _amsgrad(self, group):
+        return bool(group["amsgrad"])
+
+    def _hyper(self, group, t):
+        b1, b2 = group["betas"]
+        lr = float(group["lr"])
+        return [lr, float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                lr / (1.0 - b1 ** t), math.sqrt(1.0 - b2 ** t)]
 
 
 class RAdam(_FusedBase):
     """Rectified Adam with the update rule of the reference's ``optimizers/radam.py:27-99``."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, **unused):
-        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
-        super().__init__(params, defaults)
-        self.grad_scale = 1.0
+    _entry = "pwg_radam_step_dev"
 
-    @torch.no_grad()
-    def step(self, closure=None):
-        loss = None
-        if closure is not None:
-            with torch.enable_grad():
-                loss = closure()
-        lib = _lib.lib()
-        for group in self.param_groups:
-            pairs = self._grads(group)
-            if not pairs:
-                continue
-            by_step = {}
-            for p, g in pairs:
-                st = self._state_for(p, False)
-                step = self._as_int(st["step"]) + 1
-                st["step"] = step
-                by_step.setdefault(step, []).append((p, g, st["exp_avg"], st["exp_avg_sq"], None))
-            for step, entries in by_step.items():
-                table, n = self._build_table(entries, entries[0][0].device)
-                b1, b2 = group["betas"]
-                _lib.check(lib.pwg_radam_step(ctypes.c_void_p(table.data_ptr()), n, float(group["lr"]), float(b1),
-                                              float(b2), float(group["eps"]), float(group["weight_decay"]), step,
-                                              float(self.grad_scale), _stream()), "radam_step")
-                self._keep = table
-        bump_param_epoch()
-        return loss
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, **unused):
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+
+    def _hyper(self, group, t):
+        b1, b2 = group["betas"]
+        lr = float(group["lr"])
+        beta2_t = b2 ** t
+        n_sma_max = 2.0 / (1.0 - b2) - 1.0
+        n_sma = n_sma_max - 2.0 * t * beta2_t / (1.0 - beta2_t)
+        if n_sma >= 5:
+            step_size = lr * math.sqrt((1 - beta2_t) * (n_sma - 4) / (n_sma_max - 4) * (n_sma - 2) / n_sma
+                                       * n_sma_max / (n_sma_max - 2)) / (1 - b1 ** t)
+            rect = 1.0
+        else:
+            step_size = lr / (1 - b1 ** t)
+            rect = 0.0
+        return [lr, float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), step_size, rect]
 
 
 def clip_grad_norm_(params_and_grads, max_norm):
     """``torch.nn.utils.clip_grad_norm_`` (L2) over (param, grad) pairs with three HIP launches;
     returns a device tensor [total_norm, applied_coefficient] (no host sync)."""
-    entries = [(g, g, g, g, None) for _, g in params_and_grads]
-    if not entries:
+    grads = [g for _, g in params_and_grads]
+    if not grads:
         return None
-    dev = entries[0][0].device
+    dev = grads[0].device
     rows = []
-    for g, *_ in entries:
+    for g in grads:
         n, gp = g.numel(), g.data_ptr()
         for off in range(0, n, CHUNK):
             rows.append((gp + off * 4, gp + off * 4, 0, 0, 0, min(CHUNK, n - off)))
