@@ -286,15 +286,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the forward is replayed as one hipGraph (the 3 MRF blocks of a stage are parallel branches)
+    from parallelwavegan_amd.graphs import GraphedInference
+
+    g.branch_streams = not args.no_graph
+    run = g if args.no_graph else GraphedInference(g)
     with torch.no_grad():
         for _ in range(args.warmup):
-            y = g(c)
+            y = run(c)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            y = g(c)
+            y = run(c)
         barrier()
         elapsed = time.perf_counter() - t0
+    g.branch_streams = False
     assert torch.isfinite(y).all()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -328,7 +334,28 @@ def main():
             "share_of_step_kernel_time": r["ms"] / sum(v["ms"] for v in prof.results.values()),
         }
 
-    del y
+    # single-utterance latency (bin/decode.py's regime: batch 1), same graph-replay path
+    latency = None
+    if rank == 0:
+        latency = {}
+        g.branch_streams = not args.no_graph
+        for frames in (100, 800):
+            c1 = torch.randn(1, 80, frames, generator=gen).to(dev)
+            run1 = g if args.no_graph else GraphedInference(g)
+            with torch.no_grad():
+                for _ in range(3):
+                    run1(c1)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(20):
+                    run1(c1)
+                torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / 20
+            latency[f"B1_F{frames}"] = {"ms": dt * 1e3, "samples_per_s": frames * g.upsample_factor / dt,
+                                        "rtf": dt / (frames * g.upsample_factor / 22050.0)}
+            del run1
+        g.branch_streams = False
+    del y, run
     torch.cuda.empty_cache()
     train = None if args.no_train else bench_train(args, dev, rank, world, dist)
 
@@ -357,6 +384,8 @@ def main():
                 "parallelism": f"replicas x{world}",
             },
             "rtf": 22050.0 / value,
+            "hip_graph": not args.no_graph,
+            "latency": latency,
             "roofline": roofline,
         }
         if train is not None:

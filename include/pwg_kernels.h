@@ -172,6 +172,9 @@ int pwg_scale_rows(const float* v, const float* scale, float* w, int32_t n0, int
  * nodes of torch.nn.Tanh / LeakyReLU at models/hifigan.py:150, :329 etc.        */
 int pwg_act_backward(const float* dy, const float* y, float* dx, int64_t n, int32_t act, float slope,
                      float scale, void* stream);
+/* y = ((a + b) + c) / div (c may be NULL): the MRF combine `cs += block(c); c = cs / num_blocks`
+ * (models/hifigan.py:186-190) when the residual blocks run as parallel graph branches.   */
+int pwg_add3_div(const float* a, const float* b, const float* c, float* y, int64_t n, float div, void* stream);
 /* Backward of old-style weight_norm (dim 0): given dw (torch layout) returns dv, dg. */
 int pwg_weight_norm_backward(const float* dw, const float* v, const float* g, float* dv, float* dg,
                              int32_t n0, int32_t inner, void* stream);

@@ -66,6 +66,10 @@ class Trainer(object):
         self._pending = []  # (name, device scalar) of the current logging interval
         self._capturing = False
         self._graphs, self._graph_seen = {}, {}
+        if config.get("use_hip_graph", False) and config.get("branch_streams", True):
+            for m in self.model.values():  # independent sub-networks become parallel graph branches
+                if hasattr(m, "branch_streams"):
+                    m.branch_streams = True
         self.reducers = None
         if config.get("distributed", False):
             self.reducers = {k: GradReducer(list(self._module(k).parameters())) for k in ("generator", "discriminator")}

@@ -389,6 +389,16 @@ __global__ void stretch_conv_bwd_weight_kernel(const float* dy, const float* x, 
   }
 }
 
+
+// y = ((a + b) + c) / div   (MRF: cs = b0 + b1 + b2; c = cs / num_blocks, models/hifigan.py:186-190)
+__global__ void add3_div_kernel(const float* a, const float* b, const float* c, float* y, long n, float div) {
+  GRID_STRIDE(i, n) {
+    float v = a[i] + b[i];
+    if (c) v += c[i];
+    y[i] = v / div;
+  }
+}
+
 }  // namespace pwg
 
 using namespace pwg;
@@ -601,5 +611,14 @@ extern "C" int pwg_stretch_conv_backward(const float* dy, const float* x, const 
                        dy, x, dw, (long)rows, t_in, scale, kernel);
     PWG_CHECK_LAUNCH("stretch_conv_bwd_weight");
   }
+  return PWG_OK;
+}
+
+extern "C" int pwg_add3_div(const float* a, const float* b, const float* c, float* y, int64_t n, float div,
+                            void* stream) {
+  PWG_REQUIRE(a && b && y, PWG_ERR_NULL, "add3_div: NULL pointer");
+  PWG_REQUIRE(n > 0 && div != 0.f, PWG_ERR_BAD_SHAPE, "add3_div: bad arguments");
+  ProfScope prof((hipStream_t)stream, "add3_div_kernel", 0, 16.0 * n);
+  LAUNCH1D(add3_div_kernel, n, stream, a, b, c, y, (long)n, div);
   return PWG_OK;
 }

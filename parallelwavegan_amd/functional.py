@@ -158,6 +158,29 @@ class FusedConvFn(torch.autograd.Function):
         return dx, dw, db, dadd1, dadd2, None, None, None
 
 
+class Add3DivFn(torch.autograd.Function):
+    """((a + b) + c) / div with c optional -- the MRF combine when blocks run as parallel branches."""
+
+    @staticmethod
+    def forward(ctx, a, b, c, div):
+        a, b = _c(a), _c(b)
+        c = None if c is None else _c(c)
+        _require_device(a, b, c)
+        y = torch.empty_like(a)
+        _lib.check(_L().pwg_add3_div(_ptr(a), _ptr(b), _ptr(c), _ptr(y), a.numel(), float(div), _stream()), "add3_div")
+        ctx.div = float(div)
+        ctx.has_c = c is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        g = torch.empty_like(dy)
+        _lib.check(_L().pwg_act_backward(_ptr(dy), None, _ptr(g), dy.numel(), 0, 0.0, 1.0 / ctx.div, _stream()),
+                   "act_backward")
+        return g, g, (g if ctx.has_c else None), None
+
+
 # ---------------------------------------------------------------------------------------------
 # pooling / padding
 # ---------------------------------------------------------------------------------------------

@@ -14,6 +14,7 @@ from .. import functional as Fn
 from ..layers.activation import FusedActivation
 from ..layers.conv import Conv1d, Conv2d, ConvTranspose1d
 from ..layers.pooling import get_pooling
+from ..streams import run_branches
 from ..layers.residual_block import HiFiGANResidualBlock as ResidualBlock
 
 
@@ -32,6 +33,8 @@ class HiFiGANGenerator(torch.nn.Module):
     ``/ num_blocks`` are folded into the last launch of each block, the final
     LeakyReLU(0.01) + conv + tanh is one launch.
     """
+
+    branch_streams = False  # True: run the MRF blocks of a stage on separate streams (graph branches)
 
     def __init__(self, in_channels=80, out_channels=1, channels=512, kernel_size=7, upsample_scales=(8, 8, 2, 2),
                  upsample_kernel_sizes=(16, 16, 4, 4), resblock_kernel_sizes=(3, 7, 11),
@@ -82,6 +85,12 @@ class HiFiGANGenerator(torch.nn.Module):
         for i in range(self.num_upsamples):
             act, up = self.upsamples[i][0], self.upsamples[i][1]
             c = up(c, pre_act=act.kind, pre_slope=act.slope)
+            if self.branch_streams and 2 <= nb <= 3:
+                # the MRF blocks as parallel branches; combined by one small kernel in the same order
+                # ((b0 + b1) + b2) / nb as the reference's running sum
+                outs = run_branches([(lambda j=j, c=c: self.blocks[i * nb + j](c)) for j in range(nb)], c.device, True)
+                c = Fn.Add3DivFn.apply(outs[0], outs[1], outs[2] if nb == 3 else None, float(nb))
+                continue
             cs = None
             for j in range(nb):
                 last = j == nb - 1
@@ -223,8 +232,10 @@ class HiFiGANMultiPeriodDiscriminator(torch.nn.Module):
             params["period"] = period
             self.discriminators.append(HiFiGANPeriodDiscriminator(**params))
 
+    branch_streams = False  # set True (e.g. by the trainer's hipGraph mode) to fork one stream per period
+
     def forward(self, x):
-        return [d(x) for d in self.discriminators]
+        return run_branches([(lambda d=d: d(x)) for d in self.discriminators], x.device, self.branch_streams)
 
 
 class HiFiGANScaleDiscriminator(torch.nn.Module):
@@ -343,12 +354,17 @@ class HiFiGANMultiScaleDiscriminator(torch.nn.Module):
             self.discriminators.append(HiFiGANScaleDiscriminator(**params))
         self.pooling = get_pooling(downsample_pooling, **downsample_pooling_params)
 
+    branch_streams = False
+
     def forward(self, x):
-        outs = []
-        for f in self.discriminators:
-            outs.append(f(x))
+        xs = []
+        for _ in self.discriminators:  # the pooled inputs first (cheap, sequential) ...
+            xs.append(x)
             x = self.pooling(x)
-        return outs
+        # ... then the scale discriminators as independent branches (the trailing pooling of the
+        # reference's loop, whose result is never used, is dropped)
+        return run_branches([(lambda f=f, xi=xi: f(xi)) for f, xi in zip(self.discriminators, xs[: len(self.discriminators)])],
+                            xs[0].device, self.branch_streams)
 
 
 class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
@@ -375,5 +391,23 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
             discriminator_params=scale_discriminator_params, follow_official_norm=follow_official_norm)
         self.mpd = HiFiGANMultiPeriodDiscriminator(periods=periods, discriminator_params=period_discriminator_params)
 
+    @property
+    def branch_streams(self):
+        return self.msd.branch_streams
+
+    @branch_streams.setter
+    def branch_streams(self, value):
+        self.msd.branch_streams = bool(value)
+        self.mpd.branch_streams = bool(value)
+
     def forward(self, x):
+        if self.msd.branch_streams:  # one fork over all 3 + 5 sub-discriminators
+            xs = []
+            xi = x
+            for _ in self.msd.discriminators:
+                xs.append(xi)
+                xi = self.msd.pooling(xi)
+            fns = [(lambda f=f, v=v: f(v)) for f, v in zip(self.msd.discriminators, xs)]
+            fns += [(lambda d=d: d(x)) for d in self.mpd.discriminators]
+            return run_branches(fns, x.device, True)
         return self.msd(x) + self.mpd(x)
