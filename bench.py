@@ -251,6 +251,7 @@ def main():
     ap.add_argument("--frames", type=int, default=800, help="mel frames per utterance (800 = 9.3 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step measurement")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-utterance latency runs")
     ap.add_argument("--train-steps", type=int, default=8)
     ap.add_argument("--train-warmup", type=int, default=4, help=">= 3 so that the hipGraph capture is not timed")
     ap.add_argument("--no-graph", action="store_true", help="run the training step eagerly (no hipGraph replay)")
@@ -317,6 +318,16 @@ def main():
                 g(c)
         name, r = max(prof.results.items(), key=lambda kv: kv[1]["ms"])
         achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
+        traffic, traffic_src = None, None
+        pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+        if os.path.exists(pmc_file) and args.batch == 16 and args.frames == 800:
+            # HBM bytes per launch of this kernel on THIS workload, from separate rocprofv3 --pmc passes
+            # (FETCH_SIZE, WRITE_SIZE; KiB units; read side calibrated on a known byte count) --
+            # counters cannot be read from inside the process, so the committed summary is cited
+            with open(pmc_file) as f:
+                pmc = json.load(f)
+            if pmc.get("kernel") == name:
+                traffic, traffic_src = pmc["hbm_bytes_per_launch"], "profiles/r01_pmc_hbm_traffic.json"
         roofline = {
             "kernel": name,
             "bound": "mfma",
@@ -324,7 +335,8 @@ def main():
             "peak": FP32_MATRIX_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / FP32_MATRIX_PEAK_TFLOPS,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": traffic_src,
             "launches_per_step": r["launches"] / prof_steps,
             "avg_launch_us": r["ms"] * 1e3 / r["launches"],
             "flops_per_launch": r["flops"] / r["launches"],
@@ -336,7 +348,7 @@ def main():
 
     # single-utterance latency (bin/decode.py's regime: batch 1), same graph-replay path
     latency = None
-    if rank == 0:
+    if rank == 0 and not args.no_latency:
         latency = {}
         g.branch_streams = not args.no_graph
         for frames in (100, 800):

@@ -1,0 +1,30 @@
+#!/bin/bash
+# rocprofv3 evidence for the round: kernel-trace stats of the default bench command, then separate
+# PMC passes (FETCH_SIZE / WRITE_SIZE cannot share a pass: TCC has 4 slots, MI355X_MICROARCH.md).
+TAG=${1:-r01}
+cd /tmp && export TMPDIR=/tmp
+R=/root/repo
+O=$R/gpurun_out/prof_$TAG
+mkdir -p $O
+if [ -z "$PMC_ONLY" ]; then
+rocprofv3 --kernel-trace --stats -d $O/trace -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-graph > $O/trace.log 2>&1
+fi
+[ -z "$PMC_ONLY" ] && python $R/tools/rocprof_summary.py $(ls $O/trace/*.db | head -1) $O/kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-graph (eager launches so that every kernel is a separate dispatch; inference B=16x800 frames: 2 warm-up + 5 timed + 3 event-profiled + 2 latency shapes; training B=16x8192: 4 warm-up + 8 timed + 1 event-profiled steps)"
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_$C -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-train --no-latency > $O/pmc_$C.log 2>&1
+done
+python - <<PY
+import csv, glob, collections, json
+out = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for f in glob.glob("$O/pmc_%s/**/*counter_collection.csv" % c, recursive=True):
+        for row in csv.DictReader(open(f)):
+            k = row["Kernel_Name"].split("(")[0]
+            k = "conv1d_mfma_dma_kernel" if "conv1d_mfma_dma_kernel" in k else k
+            agg[k][0] += 1; agg[k][1] += float(row["Counter_Value"])
+    out[c] = {k: {"dispatches": n, "sum": v, "avg_per_dispatch": v / n} for k, (n, v) in agg.items() if "pwg" in k or "conv1d" in k}
+json.dump(out, open("$O/pmc_hbm.json", "w"), indent=1)
+for c, d in out.items():
+    for k, v in d.items(): print(c, k, v)
+PY
