@@ -44,8 +44,11 @@ struct WgArgs {
 // SMALL = false: workgroup tile 64 o x 64 i, 2x2 waves, every wave runs all TG taps of the block.
 // SMALL = true : workgroup tile 32 o x 32 i (narrow layers: C = 32, grouped convs, 1-channel edge
 //              layers); the 4 waves share the tiles and split the block's 4*TG taps between them.
-template <int TG, bool WIN, bool SMALL, int TT>
-__global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgArgs a) {
+// MODE 0: width 1, stride 1, no pre-activation; 1: width 1, stride 1, leaky-ReLU/ReLU applied to the
+//      operands on the fly; 3: width 1, any stride; 2: width > 1 ((k,1) Conv2d of the period
+//      discriminators).  Modes 2/3 always evaluate the activation formula (slope 1 = identity).
+template <int TG, bool WIN, bool SMALL, int TT, int MODE>
+__global__ __launch_bounds__(256, (TG > 7 ? 1 : 2)) void conv1d_wgrad_kernel(WgArgs a) {
   constexpr int BT = SMALL ? 32 : 64;          // tile rows (o) and columns (i)
   constexpr int TAPS_BLOCK = SMALL ? 4 * TG : TG;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -85,35 +88,75 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  auto issue = [&](int c, float* buf) {
+  // Per-lane, chunk-invariant pieces of the rotated-tile DMA addresses: piece q of a wave covers tile
+  // rows (2j, 2j+1) of column block cb with jj = 4q + wave = cb * (BT/2) + j.
+  constexpr int NQ = (TT / 32) * (BT / 2) / 4;
+  int g_rel[NQ], x_rel[WIN ? NQ : 1];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int jj = 4 * q + wave;
+    const int cb = jj / (BT / 2), j = jj - cb * (BT / 2);
+    const int row = 2 * j + lhi;
+    const int nrel = cb * 32 + ((l31 - row) & 31);
+    g_rel[q] = row * a.n_cols + nrel;
+    if (WIN) x_rel[q] = row * a.x_len + nrel;
+  }
+  const bool o_full = o0 + BT <= a.co_g, i_full = i0 + BT <= a.ci_g;
+
+  // Stage chunk (b, n0) into buf.  Interior chunks (tile fully inside the tensors) take a path with
+  // one VALU op per DMA instruction; edge chunks go through the fully predicated one.
+  auto issue = [&](int b, int n0, float* buf) {
     float* gs = buf;
     float* xs = buf + BT * TT;
-    const int b = c / a.chunks_per_item;
-    const int n0 = (c - b * a.chunks_per_item) * TT;
     // ---- G tile: [TT/32 column blocks][BT rows][32]; element (o, n) at column (n + o) & 31 of its block
-    for (int jj = wave; jj < (TT / 32) * (BT / 2); jj += 4) {
-      const int cb = jj / (BT / 2), j = jj - cb * (BT / 2);
-      const int row = 2 * j + lhi;
-      const int n = n0 + cb * 32 + ((l31 - row) & 31);
-      const int o = o0 + row;
-      unsigned off = OOB;
-      if (o < a.co_g && n < a.n_cols)
-        off = (unsigned)((((long)b * co_tot + grp * a.co_g + o) * a.n_cols + n) * 4);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(g_rs, (lds_ptr_t)(gs + cb * (BT * 32) + j * 64), 4, off, 0, 0, 0);
+    // (tensors are below 4 GiB, checked by the host: 32-bit element indices)
+    const int g_base = (b * co_tot + grp * a.co_g + o0) * a.n_cols + n0;
+    if (o_full && n0 + TT <= a.n_cols) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int jj = 4 * q + wave;
+        const int cb = jj / (BT / 2), j = jj - cb * (BT / 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(g_rs, (lds_ptr_t)(gs + cb * (BT * 32) + j * 64), 4,
+                                                 (unsigned)(g_base + g_rel[q]) * 4u, 0, 0, 0);
+      }
+    } else {
+#pragma unroll 1
+      for (int jj = wave; jj < (TT / 32) * (BT / 2); jj += 4) {
+        const int cb = jj / (BT / 2), j = jj - cb * (BT / 2);
+        const int row = 2 * j + lhi;
+        const int nrel = cb * 32 + ((l31 - row) & 31);
+        const bool ok = o0 + row < a.co_g && n0 + nrel < a.n_cols;
+        const unsigned off = ok ? (unsigned)(g_base + row * a.n_cols + nrel) * 4u : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(g_rs, (lds_ptr_t)(gs + cb * (BT * 32) + j * 64), 4, off, 0, 0, 0);
+      }
     }
+    const int x_base = (b * ci_tot + grp * a.ci_g + i0) * a.x_len;
     if (WIN) {
       // ---- per-tap windows: [tap][column block][BT][32], element (i, n) at column (n + i) & 31
-      for (int t = 0; t < ntaps_block; ++t)
-        for (int jj = wave; jj < (TT / 32) * (BT / 2); jj += 4) {
-          const int cb = jj / (BT / 2), j = jj - cb * (BT / 2);
-          const int row = 2 * j + lhi;
-          const int i = i0 + row;
-          const int f = n0 + cb * 32 + ((l31 - row) & 31) + (k0 + t) * a.dil - a.pad;
-          unsigned off = OOB;
-          if (i < a.ci_g && f >= 0 && f < a.x_len)
-            off = (unsigned)((((long)b * ci_tot + grp * a.ci_g + i) * a.x_len + f) * 4);
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr_t)(xs + t * (BT * TT) + cb * (BT * 32) + j * 64), 4, off, 0, 0, 0);
+#pragma unroll 1
+      for (int t = 0; t < ntaps_block; ++t) {
+        const int fs = n0 + (k0 + t) * a.dil - a.pad;
+        float* xt = xs + t * (BT * TT);
+        if (i_full && fs >= 0 && fs + TT <= a.x_len) {
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            const int jj = 4 * q + wave;
+            const int cb = jj / (BT / 2), j = jj - cb * (BT / 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr_t)(xt + cb * (BT * 32) + j * 64), 4,
+                                                     (unsigned)(x_base + fs + x_rel[WIN ? q : 0]) * 4u, 0, 0, 0);
+          }
+        } else {
+#pragma unroll 1
+          for (int jj = wave; jj < (TT / 32) * (BT / 2); jj += 4) {
+            const int cb = jj / (BT / 2), j = jj - cb * (BT / 2);
+            const int row = 2 * j + lhi;
+            const int f = fs + cb * 32 + ((l31 - row) & 31);
+            const bool ok = i0 + row < a.ci_g && (unsigned)f < (unsigned)a.x_len;
+            const unsigned off = ok ? (unsigned)(x_base + row * a.x_len + f) * 4u : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr_t)(xt + cb * (BT * 32) + j * 64), 4, off, 0, 0, 0);
+          }
         }
+      }
       return;
     }
     // ---- X tile: BT rows, flat range [f0, f0 + L)
@@ -123,58 +166,126 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgArgs a) {
     const int h1 = n_last / W;
     const int f0 = (h0 * a.stride + k0 * a.dil - a.pad) * W;
     const int L = ((h1 - h0) * a.stride + (ntaps_block - 1) * a.dil + 1) * W;
-    for (int r = wave; r < BT; r += 4) {
-      const int i = i0 + r;
-      const long rowbase = ((long)b * ci_tot + grp * a.ci_g + i) * a.x_len;
+    const int Lr = (L + 63) & ~63;  // whole DMA pieces (the row stride XS covers them)
+    if (i_full && f0 >= 0 && f0 + Lr <= a.x_len) {
+#pragma unroll 1
+      for (int e0 = 0; e0 < Lr; e0 += 64) {
+        const int fl = f0 + e0 + lane;
+        int rowbase = x_base + wave * a.x_len;
+#pragma unroll 4
+        for (int r = wave; r < BT; r += 4) {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr_t)(xs + r * XS + e0), 4,
+                                                   (unsigned)(rowbase + fl) * 4u, 0, 0, 0);
+          rowbase += 4 * a.x_len;
+        }
+      }
+    } else {
+#pragma unroll 1
       for (int e0 = 0; e0 < L; e0 += 64) {
         const int f = f0 + e0 + lane;
-        unsigned off = OOB;
-        if (i < a.ci_g && f >= 0 && f < a.x_len && e0 + lane < L) off = (unsigned)((rowbase + f) * 4);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr_t)(xs + r * XS + e0), 4, off, 0, 0, 0);
+        const bool lane_ok = (unsigned)f < (unsigned)a.x_len && e0 + lane < L;
+#pragma unroll 1
+        for (int r = wave; r < BT; r += 4) {
+          const int rowbase = x_base + r * a.x_len;
+          const unsigned off = (lane_ok && i0 + r < a.ci_g) ? (unsigned)(rowbase + f) * 4u : OOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr_t)(xs + r * XS + e0), 4, off, 0, 0, 0);
+        }
       }
     }
   };
 
-  if (c_begin < c_end) issue(c_begin, smem);
+  // Every wave runs all TG accumulators unconditionally (a per-tap branch would put every MFMA in its
+  // own basic block and serialise it behind its LDS read); accumulators beyond the wave's tap count
+  // repeat its last tap and are dropped in the epilogue.
+  int toff[TG];
+#pragma unroll
+  for (int t = 0; t < TG; ++t) {
+    const int tc = min(t, max(ntaps - 1, 0));
+    toff[t] = tc * (WIN ? BT * TT : a.dil * W);
+  }
+  auto mac_chunk = [&](const float* grow, const float* xrow, int n0, int h0, int orow, int irow) {
+    constexpr bool ACT = MODE != 0;
+    constexpr bool S1 = MODE <= 1 && !WIN;  // stride 1, width 1: step offsets fold into the LDS instructions
+    constexpr int STEPS = TT / 2;
+    const int rot0 = (lhi + orow) & 31, roti = (lhi + irow) & 31;
+    const float* xt[TG];
+#pragma unroll
+    for (int t = 0; t < TG; ++t) xt[t] = xrow + toff[t] + (S1 ? lhi : 0);
+    // operands of one reduction step (2 columns): 1 G value + TG X values per lane
+    auto load_ops = [&](int step, float& av, float(&bv)[TG]) {
+      const int cb = step >> 4;  // 32-column block of columns (2*step, 2*step+1)
+      av = grow[cb * (BT * 32) + ((2 * step + rot0) & 31)];
+      int xo;
+      if (WIN) {
+        xo = cb * (BT * 32) + ((2 * step + roti) & 31);
+      } else if (S1) {
+        xo = 2 * step;
+      } else if (MODE == 3) {
+        xo = (2 * step + lhi) * a.stride;
+      } else {
+        const int n = n0 + 2 * step + lhi;
+        const int h = n / W;
+        xo = (h - h0) * a.stride * W + (n - h * W);
+      }
+#pragma unroll
+      for (int t = 0; t < TG; ++t) bv[t] = xt[t][xo];
+    };
+    auto mma = [&](float av, float(&bv)[TG]) {
+      if (ACT) av = __builtin_fmaf(a.slope_g, __builtin_fminf(av, 0.f), __builtin_fmaxf(av, 0.f));
+#pragma unroll
+      for (int t = 0; t < TG; ++t) {
+        float v = bv[t];
+        if (ACT) v = __builtin_fmaf(a.slope_x, __builtin_fminf(v, 0.f), __builtin_fmaxf(v, 0.f));
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, v, acc[t], 0, 0, 0);
+      }
+    };
+    // ping-pong: the next step's LDS reads are issued before this step's MFMAs
+    float a0, a1, b0[TG], b1[TG];
+    load_ops(0, a0, b0);
+#pragma unroll 4
+    for (int step = 0; step < STEPS; step += 2) {
+      load_ops(step + 1, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMA group they hide under
+      mma(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_ops(step + 2 < STEPS ? step + 2 : step, a0, b0);  // (last pair: harmless re-read)
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // (b, n0) of the chunk being computed and of the one being staged, carried without divisions
+  int cb_b = c_begin / a.chunks_per_item;
+  int cb_n0 = (c_begin - cb_b * a.chunks_per_item) * TT;
+  int nb_b = cb_b, nb_n0 = cb_n0;
+  auto advance = [&](int& b, int& n0) {
+    n0 += TT;
+    if (n0 >= a.chunks_per_item * TT) {
+      n0 = 0;
+      ++b;
+    }
+  };
+  if (c_begin < c_end) issue(nb_b, nb_n0, smem);
   for (int c = c_begin; c < c_end; ++c) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    float* buf = smem + ((c - c_begin) & 1) * buf_floats;
-    if (c + 1 < c_end) issue(c + 1, smem + ((c + 1 - c_begin) & 1) * buf_floats);
+    const int par = (c - c_begin) & 1;
+    float* buf = smem + par * buf_floats;
+    if (c + 1 < c_end) {
+      advance(nb_b, nb_n0);
+      issue(nb_b, nb_n0, smem + (par ^ 1) * buf_floats);
+    }
     const float* gs = buf;
     const float* xs = buf + BT * TT;
-    const int b = c / a.chunks_per_item;
-    const int n0 = (c - b * a.chunks_per_item) * TT;
+    const int n0 = cb_n0;
+    advance(cb_b, cb_n0);
     const int h0 = n0 / W;
     const int orow = wave_o * 32 + l31;
     const float* grow = gs + orow * 32;
     const int irow = wave_i * 32 + l31;
     const float* xrow = xs + irow * (WIN ? 32 : XS) + (WIN ? t0 * (BT * TT) : t0 * a.dil * W);
-#pragma unroll 4
-    for (int step = 0; step < TT / 2; ++step) {
-      const int nl = 2 * step + lhi;          // column within the chunk
-      const int cb = nl >> 5, nb = nl & 31;   // 32-column block / column within it
-      float av = grow[cb * (BT * 32) + ((nb + orow) & 31)];
-      av = __builtin_fmaf(a.slope_g, __builtin_fminf(av, 0.f), __builtin_fmaxf(av, 0.f));
-      int xo;
-      if (WIN) {
-        xo = cb * (BT * 32) + ((nb + irow) & 31);
-      } else if (W == 1) {
-        xo = nl * a.stride;
-      } else {
-        const int n = n0 + nl;
-        const int h = n / W;
-        xo = (h - h0) * a.stride * W + (n - h * W);
-      }
-#pragma unroll
-      for (int t = 0; t < TG; ++t) {
-        if (t < ntaps) {
-          float bv = WIN ? xrow[xo + t * (BT * TT)] : xrow[xo + t * a.dil * W];
-          bv = __builtin_fmaf(a.slope_x, __builtin_fminf(bv, 0.f), __builtin_fmaxf(bv, 0.f));
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
-        }
-      }
-    }
+    if (ntaps > 0) mac_chunk(grow, xrow, n0, h0, orow, irow);
   }
 
   // ---- epilogue: D layout col = lane&31 (-> i), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (-> o).
@@ -254,7 +365,17 @@ static WgPlan wgrad_plan(int co_g, int ci_g, int groups, int k, int stride, int 
     p.tg = per_wave <= 1 ? 1 : per_wave <= 2 ? 2 : per_wave <= 3 ? 3 : per_wave <= 4 ? 4 : per_wave <= 6 ? 6 : 11;
     p.taps_block = 4 * p.tg;
   } else {
-    p.tg = k <= 4 ? 4 : (k <= 6 || k == 11 || k == 12) ? 6 : (k == 7 || k == 41 || k == 42 || k == 14) ? 7 : 8;
+    // taps per workgroup: every tap group costs its MFMAs (TG, padded taps included) plus a fixed
+    // staging overhead worth about two taps
+    int best = 1 << 30;
+    p.tg = 1;
+    for (int tg = 1; tg <= 7; ++tg) {  // ties go to the smaller (higher-occupancy, no padded taps) group
+      const int cost = ceil_div(k, tg) * (tg + 2);
+      if (cost < best) {
+        best = cost;
+        p.tg = tg;
+      }
+    }
     p.taps_block = p.tg;
   }
   const int bt = p.small ? 32 : 64;
@@ -262,7 +383,7 @@ static WgPlan wgrad_plan(int co_g, int ci_g, int groups, int k, int stride, int 
   p.win = stride == 1 && width == 1 && (ntaps_max - 1) * dil > 96;  // taps far apart: per-tap windows
   // longest chunk whose double-buffered tiles keep two workgroups per CU (<= 80 KB), at most ~n_cols
   p.tt = 32;
-  for (int tt = 128; tt >= 32; tt >>= 1) {
+  for (int tt = p.small ? 128 : 32; tt >= 32; tt >>= 1) {
     int xs;
     if (tt > 32 && tt > n_cols) continue;
     if (wgrad_lds(p.small, p.win, p.taps_block, tt, stride, dil, width, k, &xs) <= 80 * 1024) {
@@ -284,15 +405,15 @@ static WgPlan wgrad_plan(int co_g, int ci_g, int groups, int k, int stride, int 
   return p;
 }
 
-template <int TG, bool SMALL, int TT>
-static int launch_wgrad(WgArgs a, const WgPlan& p, float* dw_out, float* workspace, size_t ws_floats,
+template <int TG, bool SMALL, int TT, bool WIN, int MODE>
+static int launch_wgrad_mode(WgArgs a, const WgPlan& p, float* dw_out, float* workspace, size_t ws_floats,
                         hipStream_t stream, double flops, double bytes) {
   a.xs_stride = p.xs_stride;
   a.chunks_per_item = p.chunks_per_item;
   a.chunks_total = p.chunks_total;
   const size_t lds = p.lds;
   PWG_REQUIRE(lds <= 160 * 1024, PWG_ERR_UNSUPPORTED, "conv1d_backward_weight: tile needs %zu B of LDS", lds);
-  void (*kern)(WgArgs) = p.win ? conv1d_wgrad_kernel<TG, true, SMALL, TT> : conv1d_wgrad_kernel<TG, false, SMALL, TT>;
+  void (*kern)(WgArgs) = conv1d_wgrad_kernel<TG, WIN, SMALL, TT, MODE>;
   if (lds > 64 * 1024 && !lds_limit_is_set(reinterpret_cast<const void*>(kern), lds)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -324,6 +445,23 @@ static int launch_wgrad(WgArgs a, const WgPlan& p, float* dw_out, float* workspa
     PWG_CHECK_LAUNCH("reduce_slabs");
   }
   return PWG_OK;
+}
+
+template <int TG, bool SMALL, int TT>
+static int launch_wgrad(WgArgs a, const WgPlan& p, float* dw_out, float* workspace, size_t ws_floats,
+                        hipStream_t stream, double flops, double bytes) {
+  const bool act = a.slope_g != 1.f || a.slope_x != 1.f;
+#define WG_GO(WINV, MODEV) \
+  return launch_wgrad_mode<TG, SMALL, TT, WINV, MODEV>(a, p, dw_out, workspace, ws_floats, stream, flops, bytes)
+  if (a.width != 1) WG_GO(false, 2);  // per-tap windows need width == 1 and stride == 1 (wgrad_plan)
+  if (a.stride != 1) WG_GO(false, 3);
+  if (p.win) {
+    if (act) WG_GO(true, 1);
+    WG_GO(true, 0);
+  }
+  if (act) WG_GO(false, 1);
+  WG_GO(false, 0);
+#undef WG_GO
 }
 
 }  // namespace pwg
@@ -428,11 +566,16 @@ extern "C" int pwg_conv1d_backward_weight(const pwg_conv1d_desc* d, const float*
       default: WG_CASE(11, true);
     }
   }
-  switch (p.tg) {
-    case 4: WG_CASE(4, false);
-    case 6: WG_CASE(6, false);
-    case 7: WG_CASE(7, false);
-    default: WG_CASE(8, false);
+#undef WG_CASE
+#define WG_CASE(TGV) return launch_wgrad<TGV, false, 32>(a, p, dw, workspace, workspace_floats, stream, flops, bytes)
+  switch (p.tg) {  // 64x64 tiles always run 32-column chunks (LDS)
+    case 1: WG_CASE(1);
+    case 2: WG_CASE(2);
+    case 3: WG_CASE(3);
+    case 4: WG_CASE(4);
+    case 5: WG_CASE(5);
+    case 6: WG_CASE(6);
+    default: WG_CASE(7);
   }
 #undef WG_CASE
 }
