@@ -62,6 +62,22 @@ bool lds_limit_is_set(const void* kern, size_t bytes);
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 
+// A stride-1 (k,1) convolution over (rows, width) is a plain 1-D convolution over the flattened
+// rows*width axis with dilation*width and pad*width (the width index survives shifts by multiples of
+// width, and zero padding above/below the rows is zero padding of the flat axis).  Flattening lets
+// the period discriminators' 1024-channel layers run the fast width-1 paths.
+static inline pwg_conv1d_desc flatten_width(const pwg_conv1d_desc& d) {
+  pwg_conv1d_desc f = d;
+  if (d.width > 1 && d.stride == 1 && d.pad_mode == PWG_PAD_ZERO) {
+    f.t_in = d.t_in * d.width;
+    f.t_out = d.t_out * d.width;
+    f.dilation = d.dilation * d.width;
+    f.pad_left = d.pad_left * d.width;
+    f.width = 1;
+  }
+  return f;
+}
+
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   switch (act) {
     case PWG_ACT_LEAKY_RELU: return v > 0.f ? v : v * slope;

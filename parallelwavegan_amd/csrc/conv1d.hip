@@ -816,7 +816,7 @@ static int fill_args(const pwg_conv1d_desc* d, const Geometry& g, const float* x
 using namespace pwg;
 
 extern "C" size_t pwg_conv1d_packed_weight_floats(const pwg_conv1d_desc* d) {
-  Geometry g;
+  Geometry g;  // (the packed layout does not depend on width / dilation: no flattening needed)
   if (make_geometry(d, &g) != PWG_OK) return 0;
   return (size_t)d->groups * g.k_phase * g.cin_pad * g.m_pad;
 }
@@ -849,9 +849,12 @@ extern "C" int pwg_conv1d_pack_weight(const pwg_conv1d_desc* d, const float* w, 
   return PWG_OK;
 }
 
-extern "C" int pwg_conv1d_forward(const pwg_conv1d_desc* d, const float* x, const float* w_packed,
+extern "C" int pwg_conv1d_forward(const pwg_conv1d_desc* d_in, const float* x, const float* w_packed,
                                   const float* bias, const float* add1, const float* add2, float* y,
                                   void* stream) {
+  PWG_REQUIRE(d_in != nullptr, PWG_ERR_NULL, "conv1d: NULL descriptor");
+  const pwg_conv1d_desc flat = flatten_width(*d_in);
+  const pwg_conv1d_desc* d = &flat;
   Geometry g;
   int rc = make_geometry(d, &g);
   if (rc != PWG_OK) return rc;
@@ -907,6 +910,7 @@ extern "C" int pwg_conv1d_backward_data(const pwg_conv1d_desc* d, const float* d
               "conv1d_backward_data: the forward input is needed for the pre-activation derivative");
   pwg_conv1d_desc dd;
   dual_desc(d, &dd);
+  dd = flatten_width(dd);
   Geometry g;
   int rc = make_geometry(&dd, &g);
   if (rc != PWG_OK) return rc;

@@ -307,11 +307,39 @@ __global__ __launch_bounds__(256, (TG > 7 ? 1 : 2)) void conv1d_wgrad_kernel(WgA
   }
 }
 
-// dw[e] = sum_s slabs[s][e]
-__global__ void reduce_slabs_kernel(const float* slabs, float* dw, long elems, int nslabs) {
+// dw[e] = sum_s slabs[s][e].  Few slabs: one thread per element.  Many slabs (narrow layers cut
+// into hundreds of reduction slices): 32 elements x 8 slab lanes per workgroup, every lane sums its
+// slabs (stride 8) in a fixed order, then the 8 partials are added in a fixed order (deterministic).
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ dw, long elems, int nslabs) {
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < elems; e += (long)gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int j = 0; j < nslabs; ++j) s += slabs[(long)j * elems + e];
+    dw[e] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* __restrict__ slabs,
+                                                                float* __restrict__ dw, long elems, int nslabs) {
+  __shared__ float part[8][32];
+  const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const long e = (long)blockIdx.x * 32 + el;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < elems) {
+    int j = sl;
+    for (; j + 24 < nslabs; j += 32) {
+      s0 += slabs[(long)j * elems + e];
+      s1 += slabs[(long)(j + 8) * elems + e];
+      s2 += slabs[(long)(j + 16) * elems + e];
+      s3 += slabs[(long)(j + 24) * elems + e];
+    }
+    for (; j < nslabs; j += 8) s0 += slabs[(long)j * elems + e];
+  }
+  part[sl][el] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sl == 0 && e < elems) {
+    float s = part[0][el];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) s += part[q][el];
     dw[e] = s;
   }
 }
@@ -396,8 +424,10 @@ static WgPlan wgrad_plan(int co_g, int ci_g, int groups, int k, int stride, int 
   p.chunks_total = p.chunks_per_item * batch;
   p.tap_groups = ceil_div(k, p.taps_block);
   p.tiles = ceil_div(co_g, bt) * ceil_div(ci_g, bt) * groups;
-  // ~3 workgroups per CU, but at least 256 columns of reduction per workgroup
-  int splits = ceil_div(768, p.tiles * p.tap_groups);
+  // one wave of resident workgroups (register-limited: 2 per CU with 6-7 accumulators, else 3), all
+  // with the same amount of work; at least 256 columns of reduction per workgroup
+  const int resident = 256 * ((!p.small && p.tg >= 6) ? 2 : 3);
+  int splits = resident / (p.tiles * p.tap_groups);
   const int min_chunks = 256 / p.tt > 1 ? 256 / p.tt : 1;
   if (splits > p.chunks_total / min_chunks) splits = p.chunks_total / min_chunks;
   if (splits < 1) splits = 1;
@@ -437,11 +467,16 @@ static int launch_wgrad_mode(WgArgs a, const WgPlan& p, float* dw_out, float* wo
   }
   PWG_CHECK_LAUNCH("conv1d_backward_weight");
   if (p.splits > 1) {
-    long blocks = (a.slab_elems + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
     ProfScope prof(stream, "reduce_slabs_kernel", 0, 4.0 * a.slab_elems * (p.splits + 1));
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((int)blocks), dim3(256), 0, stream, workspace, dw_out, a.slab_elems,
-                       p.splits);
+    if (p.splits >= 16) {
+      hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)((a.slab_elems + 31) / 32)), dim3(256), 0, stream,
+                         workspace, dw_out, a.slab_elems, p.splits);
+    } else {
+      long blocks = (a.slab_elems + 255) / 256;
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(reduce_slabs_kernel, dim3((int)blocks), dim3(256), 0, stream, workspace, dw_out,
+                         a.slab_elems, p.splits);
+    }
     PWG_CHECK_LAUNCH("reduce_slabs");
   }
   return PWG_OK;
@@ -480,18 +515,22 @@ static void wgrad_roles(const pwg_conv1d_desc* d, int* co_g, int* ci_g, int* n_c
   }
 }
 
-extern "C" size_t pwg_conv1d_backward_weight_workspace_floats(const pwg_conv1d_desc* d) {
-  if (!d || d->groups <= 0 || d->c_in % d->groups || d->c_out % d->groups) return 0;
+extern "C" size_t pwg_conv1d_backward_weight_workspace_floats(const pwg_conv1d_desc* d_in) {
+  if (!d_in || d_in->groups <= 0 || d_in->c_in % d_in->groups || d_in->c_out % d_in->groups) return 0;
+  const pwg_conv1d_desc flat = flatten_width(*d_in);
+  const pwg_conv1d_desc* d = &flat;
   int co_g, ci_g, n_cols;
   wgrad_roles(d, &co_g, &ci_g, &n_cols);
   const WgPlan p = wgrad_plan(co_g, ci_g, d->groups, d->kernel, d->stride, d->dilation, d->width, n_cols, d->batch);
   return p.splits > 1 ? (size_t)p.splits * co_g * d->groups * ci_g * d->kernel : 0;
 }
 
-extern "C" int pwg_conv1d_backward_weight(const pwg_conv1d_desc* d, const float* x, const float* dy,
+extern "C" int pwg_conv1d_backward_weight(const pwg_conv1d_desc* d_in, const float* x, const float* dy,
                                           float* dw, float* db, float* workspace, size_t workspace_floats,
                                           void* stream_) {
-  PWG_REQUIRE(d && x && dy, PWG_ERR_NULL, "conv1d_backward_weight: NULL pointer");
+  PWG_REQUIRE(d_in && x && dy, PWG_ERR_NULL, "conv1d_backward_weight: NULL pointer");
+  const pwg_conv1d_desc flat = flatten_width(*d_in);
+  const pwg_conv1d_desc* d = &flat;
   PWG_REQUIRE(d->c_in % d->groups == 0 && d->c_out % d->groups == 0 && d->groups > 0, PWG_ERR_BAD_SHAPE,
               "conv1d_backward_weight: bad groups");
   PWG_REQUIRE(d->pad_mode == PWG_PAD_ZERO, PWG_ERR_UNSUPPORTED,
