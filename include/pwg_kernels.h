@@ -138,8 +138,10 @@ int pwg_conv1d_backward_data(const pwg_conv1d_desc* d, const float* dy, const fl
                              const float* x, const float* accum, float* dx, void* stream);
 /* dw (torch layout, same shape as the forward weight) = sum_{b,t} dy * pre_act(x) taps;
  * db[c] = sum dy.  The (batch, time) reduction is cut into slices that each write a private
- * slab of `workspace`; a second kernel sums the slabs (deterministic, no atomics).  Query the
- * workspace size (floats, may be 0) first.  Either of dw/db may be NULL.          */
+ * slab of `workspace`; a second kernel sums the slabs (deterministic, no atomics).  For plain
+ * convolutions the bias gradient is produced by the same launch (row sums of the dy tiles the
+ * kernel stages anyway).  Query the workspace size (floats, may be 0) first.  Either of dw/db
+ * may be NULL.                                                                      */
 size_t pwg_conv1d_backward_weight_workspace_floats(const pwg_conv1d_desc* d);
 int pwg_conv1d_backward_weight(const pwg_conv1d_desc* d, const float* x, const float* dy, float* dw,
                                float* db, float* workspace, size_t workspace_floats, void* stream);

@@ -29,7 +29,9 @@ struct WgArgs {
   int batch;
   int chunks_per_item, chunks_total, chunks_per_block;
   int xs_stride;    // odd
-  long slab_elems;  // elements of one gradient slab (= the whole dW)
+  float* db;        // bias-gradient rows of the slabs (nullptr: not fused); same slab stride as dw
+  long slab_elems;  // elements of dW
+  long slab_stride; // floats between consecutive slabs (dW + fused bias row)
   float slope_g, slope_x;  // branch-free pre-activation slopes (1 = none)
   unsigned g_bytes, x_bytes;
 };
@@ -203,6 +205,7 @@ __global__ __launch_bounds__(256, (TG > 7 ? 1 : 2)) void conv1d_wgrad_kernel(WgA
     const int tc = min(t, max(ntaps - 1, 0));
     toff[t] = tc * (WIN ? BT * TT : a.dil * W);
   }
+  float bsum = 0.f;
   auto mac_chunk = [&](const float* grow, const float* xrow, int n0, int h0, int orow, int irow) {
     constexpr bool ACT = MODE != 0;
     constexpr bool S1 = MODE <= 1 && !WIN;  // stride 1, width 1: step offsets fold into the LDS instructions
@@ -231,6 +234,7 @@ __global__ __launch_bounds__(256, (TG > 7 ? 1 : 2)) void conv1d_wgrad_kernel(WgA
       for (int t = 0; t < TG; ++t) bv[t] = xt[t][xo];
     };
     auto mma = [&](float av, float(&bv)[TG]) {
+      bsum += av;  // fused bias gradient: row sums of G (only used where G is the raw output gradient)
       if (ACT) av = __builtin_fmaf(a.slope_g, __builtin_fminf(av, 0.f), __builtin_fmaxf(av, 0.f));
 #pragma unroll
       for (int t = 0; t < TG; ++t) {
@@ -291,7 +295,15 @@ __global__ __launch_bounds__(256, (TG > 7 ? 1 : 2)) void conv1d_wgrad_kernel(WgA
   // ---- epilogue: D layout col = lane&31 (-> i), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (-> o).
   // Every reduction slice owns a private slab (torch weight layout) that it fully overwrites with
   // plain stores; slabs are summed by reduce_slabs_kernel (no atomics, deterministic).
-  float* slab = a.dw + (long)blockIdx.x * a.slab_elems;
+  float* slab = a.dw + (long)blockIdx.x * a.slab_stride;
+  if (a.db != nullptr && it == 0 && blockIdx.z == 0) {
+    // lanes l and l+32 hold the even/odd columns of row (wave_o*32 + l31); every wave of a narrow
+    // tile sees the same G rows, the first one writes
+    const float rs = bsum + __shfl_down(bsum, 32, 64);
+    const int o = o0 + wave_o * 32 + l31;
+    if ((SMALL ? wave == 0 : wave_i == 0) && lhi == 0 && o < a.co_g)
+      a.db[(long)blockIdx.x * a.slab_stride + grp * a.co_g + o] = rs;
+  }
   const int i = i0 + wave_i * 32 + l31;
   if (i < a.ci_g) {
 #pragma unroll
@@ -310,16 +322,20 @@ __global__ __launch_bounds__(256, (TG > 7 ? 1 : 2)) void conv1d_wgrad_kernel(WgA
 // dw[e] = sum_s slabs[s][e].  Few slabs: one thread per element.  Many slabs (narrow layers cut
 // into hundreds of reduction slices): 32 elements x 8 slab lanes per workgroup, every lane sums its
 // slabs (stride 8) in a fixed order, then the 8 partials are added in a fixed order (deterministic).
-__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ dw, long elems, int nslabs) {
+// Elements [0, dw_elems) of a slab go to dw, the rest (fused bias row) to db.
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ dw, float* __restrict__ db,
+                                    long dw_elems, long elems, int nslabs) {
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < elems; e += (long)gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int j = 0; j < nslabs; ++j) s += slabs[(long)j * elems + e];
-    dw[e] = s;
+    if (e < dw_elems) dw[e] = s;
+    else db[e - dw_elems] = s;
   }
 }
 
 __global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* __restrict__ slabs,
-                                                                float* __restrict__ dw, long elems, int nslabs) {
+                                                                float* __restrict__ dw, float* __restrict__ db,
+                                                                long dw_elems, long elems, int nslabs) {
   __shared__ float part[8][32];
   const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const long e = (long)blockIdx.x * 32 + el;
@@ -340,7 +356,8 @@ __global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* __r
     float s = part[0][el];
 #pragma unroll
     for (int q = 1; q < 8; ++q) s += part[q][el];
-    dw[e] = s;
+    if (e < dw_elems) dw[e] = s;
+    else db[e - dw_elems] = s;
   }
 }
 
@@ -452,13 +469,16 @@ static int launch_wgrad_mode(WgArgs a, const WgPlan& p, float* dw_out, float* wo
   }
   a.chunks_per_block = ceil_div(a.chunks_total, p.splits);
   a.slab_elems = (long)a.co_g * a.groups * a.ci_g * a.k;
+  float* db_out = a.db;  // non-null: the bias gradient rides along (row sums of the G tiles)
+  a.slab_stride = a.slab_elems + (db_out ? (long)a.co_g * a.groups : 0);
   if (p.splits == 1) {
-    a.dw = dw_out;  // single slice: write the gradient directly
+    a.dw = dw_out;  // single slice: write the gradients directly
   } else {
-    PWG_REQUIRE(workspace && ws_floats >= (size_t)p.splits * a.slab_elems, PWG_ERR_WORKSPACE,
+    PWG_REQUIRE(workspace && ws_floats >= (size_t)p.splits * a.slab_stride, PWG_ERR_WORKSPACE,
                 "conv1d_backward_weight: workspace of %zu floats needed, %zu given",
-                (size_t)p.splits * a.slab_elems, ws_floats);
+                (size_t)p.splits * a.slab_stride, ws_floats);
     a.dw = workspace;
+    if (db_out) a.db = workspace + a.slab_elems;
   }
   dim3 grid(p.splits, p.tiles, p.tap_groups);
   {
@@ -467,15 +487,15 @@ static int launch_wgrad_mode(WgArgs a, const WgPlan& p, float* dw_out, float* wo
   }
   PWG_CHECK_LAUNCH("conv1d_backward_weight");
   if (p.splits > 1) {
-    ProfScope prof(stream, "reduce_slabs_kernel", 0, 4.0 * a.slab_elems * (p.splits + 1));
+    ProfScope prof(stream, "reduce_slabs_kernel", 0, 4.0 * a.slab_stride * (p.splits + 1));
     if (p.splits >= 16) {
-      hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)((a.slab_elems + 31) / 32)), dim3(256), 0, stream,
-                         workspace, dw_out, a.slab_elems, p.splits);
+      hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)((a.slab_stride + 31) / 32)), dim3(256), 0, stream,
+                         workspace, dw_out, db_out, a.slab_elems, a.slab_stride, p.splits);
     } else {
-      long blocks = (a.slab_elems + 255) / 256;
+      long blocks = (a.slab_stride + 255) / 256;
       if (blocks > 2048) blocks = 2048;
-      hipLaunchKernelGGL(reduce_slabs_kernel, dim3((int)blocks), dim3(256), 0, stream, workspace, dw_out,
-                         a.slab_elems, p.splits);
+      hipLaunchKernelGGL(reduce_slabs_kernel, dim3((int)blocks), dim3(256), 0, stream, workspace, dw_out, db_out,
+                         a.slab_elems, a.slab_stride, p.splits);
     }
     PWG_CHECK_LAUNCH("reduce_slabs");
   }
@@ -522,7 +542,8 @@ extern "C" size_t pwg_conv1d_backward_weight_workspace_floats(const pwg_conv1d_d
   int co_g, ci_g, n_cols;
   wgrad_roles(d, &co_g, &ci_g, &n_cols);
   const WgPlan p = wgrad_plan(co_g, ci_g, d->groups, d->kernel, d->stride, d->dilation, d->width, n_cols, d->batch);
-  return p.splits > 1 ? (size_t)p.splits * co_g * d->groups * ci_g * d->kernel : 0;
+  // one slab per reduction slice: dW plus the fused bias row
+  return p.splits > 1 ? (size_t)p.splits * ((size_t)co_g * d->groups * ci_g * d->kernel + (size_t)co_g * d->groups) : 0;
 }
 
 extern "C" int pwg_conv1d_backward_weight(const pwg_conv1d_desc* d_in, const float* x, const float* dy,
@@ -540,7 +561,10 @@ extern "C" int pwg_conv1d_backward_weight(const pwg_conv1d_desc* d_in, const flo
   const long x_elems = (long)d->batch * d->c_in * d->t_in * d->width;
   PWG_REQUIRE(y_elems * 4 < 0xFFFFFFF0L && x_elems * 4 < 0xFFFFFFF0L, PWG_ERR_UNSUPPORTED,
               "conv1d_backward_weight: tensors above 4 GiB need batch splitting");
-  if (db) {
+  // The bias gradient (row sums of dy) is fused into the weight-gradient kernel whenever dy plays the
+  // G role there (plain convolutions); ConvTranspose1d and bias-only calls use the separate kernel.
+  const bool fuse_bias = db && dw && !d->transposed;
+  if (db && !fuse_bias) {
     const int n = d->t_out * d->width;
     const int segs = ceil_div(n, BG_SEG);
     (void)hipMemsetAsync(db, 0, sizeof(float) * d->c_out, stream);
@@ -578,6 +602,7 @@ extern "C" int pwg_conv1d_backward_weight(const pwg_conv1d_desc* d_in, const flo
     a.x_bytes = (unsigned)(y_elems * 4);
   }
   a.dw = nullptr;
+  a.db = fuse_bias ? db : nullptr;
   a.groups = d->groups;
   a.k = d->kernel;
   a.stride = d->stride;
