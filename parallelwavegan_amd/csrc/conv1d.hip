@@ -590,7 +590,9 @@ struct HasFast {
                                 (WM == 1 && WN == 1 && WAVES_M == 1 && WAVES_N == 4 && CK == 8) ||   // 32x128x8
                                 (WM == 2 && WN == 2 && WAVES_M == 1 && WAVES_N == 4 && CK == 4) ||   // 64x256x4
                                 (WM == 1 && WN == 2 && WAVES_M == 2 && WAVES_N == 2 && CK == 8) ||   // 64x128x8
-                                (WM == 1 && WN == 1 && WAVES_M == 2 && WAVES_N == 2 && CK == 8);     // 64x64x8
+                                (WM == 1 && WN == 1 && WAVES_M == 2 && WAVES_N == 2 && CK == 8) ||   // 64x64x8
+                                (WM == 1 && WN == 1 && WAVES_M == 2 && WAVES_N == 2 && CK == 16) ||  // 64x64x16
+                                (WM == 1 && WN == 1 && WAVES_M == 1 && WAVES_N == 4 && CK == 16);    // 32x128x16
 };
 
 template <int WM, int WN, int WAVES_M, int WAVES_N, int CK>
@@ -674,8 +676,10 @@ struct TileCfg {
   X(15, 2, 2, 1, 4, 4)    \
   X(16, 1, 2, 2, 2, 8)    \
   X(17, 1, 1, 2, 2, 8)    \
-  X(18, 1, 1, 4, 1, 8)
-static const int kNumCfgs = 19;
+  X(18, 1, 1, 4, 1, 8)    \
+  X(19, 1, 1, 2, 2, 16)   \
+  X(20, 1, 1, 1, 4, 16)
+static const int kNumCfgs = 21;
 
 static TileCfg cfg_info(int id) {
   switch (id) {
@@ -761,7 +765,21 @@ static int choose_cfg(const Geometry& g, int W, int batch, int groups, bool dma)
       }
     }
   }
-  return best >= 0 ? best : 13;
+  if (best < 0) return 13;
+  // Long reductions over few columns (1024-channel discriminator layers, deep generator layers at
+  // training lengths): the launch cannot fill the chip with big tiles, and a small tile's chunk time
+  // is a DMA round trip rather than MFMA work -- 16-channel chunks halve the number of round trips
+  // (tools/bench_dconv.py sweep: 10-20 % over the 8-channel tiles).
+  if (dma && (best == 17 || best == 13 || best == 12) && g.cin_g >= 256 && g.cin_g % 16 == 0) {
+    const TileCfg cb = cfg_info(best);
+    const long blocks = (long)ceil_div(g.n_cols, cb.bn) * ceil_div(m, cb.bm) * groups * batch;
+    if (blocks <= 1024) {
+      const int wide = (g.n_cols > 64 && g.n_cols <= 128) ? 20 : 19;  // one 128-column tile per item, else 64x64
+      if (cfg_lds(wide, g, W, dma) <= 80 * 1024) return wide;
+      if (cfg_lds(19, g, W, dma) <= 80 * 1024) return 19;
+    }
+  }
+  return best;
 }
 
 static int fill_args(const pwg_conv1d_desc* d, const Geometry& g, const float* x, const float* w_packed,
@@ -932,9 +950,12 @@ extern "C" int pwg_conv1d_backward_data(const pwg_conv1d_desc* d, const float* d
 
 extern "C" int pwg_conv1d_num_tile_configs(void) { return kNumCfgs; }
 
-extern "C" int pwg_conv1d_forward_cfg(const pwg_conv1d_desc* d, const float* x, const float* w_packed,
+extern "C" int pwg_conv1d_forward_cfg(const pwg_conv1d_desc* d_in, const float* x, const float* w_packed,
                                       const float* bias, const float* add1, const float* add2, float* y,
                                       int32_t tile_config, int32_t use_dma, void* stream) {
+  PWG_REQUIRE(d_in != nullptr, PWG_ERR_NULL, "conv1d: NULL descriptor");
+  const pwg_conv1d_desc flat = flatten_width(*d_in);
+  const pwg_conv1d_desc* d = &flat;
   Geometry g;
   int rc = make_geometry(d, &g);
   if (rc != PWG_OK) return rc;
