@@ -252,8 +252,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step measurement")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-utterance latency runs")
-    ap.add_argument("--train-steps", type=int, default=8)
-    ap.add_argument("--train-warmup", type=int, default=4, help=">= 3 so that the hipGraph capture is not timed")
+    ap.add_argument("--train-steps", type=int, default=50)
+    ap.add_argument("--train-warmup", type=int, default=10, help=">= 3 so that the hipGraph capture is not timed")
     ap.add_argument("--no-graph", action="store_true", help="run the training step eagerly (no hipGraph replay)")
     ap.add_argument("--train-batch", type=int, default=16)
     args = ap.parse_args()

@@ -7,9 +7,9 @@ R=/root/repo
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 if [ -z "$PMC_ONLY" ]; then
-rocprofv3 --kernel-trace --stats -d $O/trace -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-graph > $O/trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/trace -o bench -- python $R/bench.py --steps 5 --warmup 2 --train-steps 8 --train-warmup 4 --no-cpu-baseline --no-graph > $O/trace.log 2>&1
 fi
-[ -z "$PMC_ONLY" ] && python $R/tools/rocprof_summary.py $(ls $O/trace/*.db | head -1) $O/kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-graph (eager launches so that every kernel is a separate dispatch; inference B=16x800 frames: 2 warm-up + 5 timed + 3 event-profiled + 2 latency shapes; training B=16x8192: 4 warm-up + 8 timed + 1 event-profiled steps)"
+[ -z "$PMC_ONLY" ] && python $R/tools/rocprof_summary.py $(ls $O/trace/*.db | head -1) $O/kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --train-steps 8 --train-warmup 4 --no-cpu-baseline --no-graph (eager launches so that every kernel is a separate dispatch; inference B=16x800 frames: 2 warm-up + 5 timed + 3 event-profiled + 2 latency shapes; training B=16x8192: 4 warm-up + 8 timed + 1 event-profiled steps)"
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_$C -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-train --no-latency > $O/pmc_$C.log 2>&1
 done
