@@ -184,7 +184,7 @@ int pwg_weight_norm_backward(const float* dw, const float* v, const float* g, fl
  * HiFi-GAN scale discriminator (models/hifigan.py:613-621,750-754).  w_orig viewed as
  * (rows, cols) = (c_out, c_in/groups * k).  do_iter != 0 updates u (rows) and v (cols) in
  * place (training-mode forward); sigma[0] = u^T W v; w = w_orig / sigma.
- * tmp: max(rows, cols) floats of workspace.                                       */
+ * tmp: max(rows, 32 * cols) floats of workspace (row-sliced partial sums of W^T u). */
 int pwg_spectral_norm_forward(const float* w_orig, float* u, float* v, float* sigma, float* w, float* tmp,
                               int32_t rows, int32_t cols, int32_t do_iter, float eps, void* stream);
 /* dw_orig = dw / sigma - (<dw, w_orig> / sigma^2) u v^T ;  scratch: 1 float.       */

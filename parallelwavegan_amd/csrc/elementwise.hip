@@ -249,13 +249,24 @@ __global__ void log_clamp_bwd_kernel(const float* x, const float* dy, float* dx,
 }
 
 // ---- spectral norm (torch.nn.utils.spectral_norm, dim 0, 1 power iteration) --------------
-// t[c] = sum_r W[r][c] u[r]        (coalesced over columns)
-__global__ void matvec_t_kernel(const float* w, const float* u, float* t, int rows, int cols) {
-  GRID_STRIDE(c, cols) {
-    float acc = 0.f;
-    for (int r = 0; r < rows; ++r) acc += w[(long)r * cols + c] * u[r];
-    t[c] = acc;
-  }
+// parts[rs][c] = sum over the rs-th slice of rows of W[r][c] u[r]   (coalesced over columns; a
+// workgroup = 64 columns x 4 row lanes; the slices are summed in a fixed order by
+// normalize_kernel: deterministic).  SN_SPLITS row slices keep >= 256 workgroups in flight for the
+// 1024 x 5120 layer instead of 20 column blocks walking 1024 rows serially.
+constexpr int SN_SPLITS = 32;
+__global__ __launch_bounds__(256) void matvec_t_kernel(const float* __restrict__ w, const float* __restrict__ u,
+                                                       float* __restrict__ parts, int rows, int cols, int rows_per_split) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int r0 = blockIdx.y * rows_per_split;
+  const int r1 = min(rows, r0 + rows_per_split);
+  float acc = 0.f;
+  if (c < cols)
+    for (int r = r0 + rl; r < r1; r += 4) acc += w[(long)r * cols + c] * u[r];
+  red[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && c < cols) parts[(long)blockIdx.y * cols + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 // s[r] = sum_c W[r][c] v[c]        (one workgroup per row)
 __global__ void matvec_kernel(const float* w, const float* v, float* s, int cols) {
@@ -267,6 +278,14 @@ __global__ void matvec_kernel(const float* w, const float* v, float* s, int cols
   if (threadIdx.x == 0) s[blockIdx.x] = acc;
 }
 // out = in / max(|in|, eps)   and optionally dot = <a, b>   (single workgroup)
+// parts[0][i] = sum_p parts[p][i]   (fixed order)
+__global__ void sum_parts_kernel(float* parts, int n, int nparts) {
+  GRID_STRIDE(i, n) {
+    float t = parts[i];
+    for (int p = 1; p < nparts; ++p) t += parts[(long)p * n + i];
+    parts[i] = t;
+  }
+}
 __global__ void normalize_kernel(const float* in, float* out, int n, float eps) {
   __shared__ float red[4];
   float s = 0.f;
@@ -528,7 +547,7 @@ extern "C" int pwg_log_clamp_backward(const float* x, const float* dy, float* dx
 
 // u (rows), v (cols) are updated in place when do_iter != 0 (training-mode forward of
 // torch.nn.utils.spectral_norm: models/hifigan.py:613-621); sigma[0] = u^T W v; w = w_orig / sigma.
-// tmp: workspace of max(rows, cols) floats.
+// tmp: workspace of max(rows, 32 * cols) floats (row-sliced partial sums of W^T u).
 extern "C" int pwg_spectral_norm_forward(const float* w_orig, float* u, float* v, float* sigma, float* w,
                                          float* tmp, int32_t rows, int32_t cols, int32_t do_iter, float eps,
                                          void* stream_) {
@@ -536,7 +555,11 @@ extern "C" int pwg_spectral_norm_forward(const float* w_orig, float* u, float* v
   PWG_REQUIRE(rows > 0 && cols > 0, PWG_ERR_BAD_SHAPE, "spectral_norm: bad shape");
   hipStream_t stream = (hipStream_t)stream_;
   if (do_iter) {
-    hipLaunchKernelGGL(matvec_t_kernel, dim3(grid_for(cols)), dim3(256), 0, stream, w_orig, u, tmp, rows, cols);
+    const int splits = rows >= 4 * SN_SPLITS ? SN_SPLITS : 1;
+    const int rps = (rows + splits - 1) / splits;
+    hipLaunchKernelGGL(matvec_t_kernel, dim3((cols + 63) / 64, splits), dim3(256), 0, stream, w_orig, u, tmp, rows,
+                       cols, rps);
+    if (splits > 1) hipLaunchKernelGGL(sum_parts_kernel, dim3(grid_for(cols)), dim3(256), 0, stream, tmp, cols, splits);
     hipLaunchKernelGGL(normalize_kernel, dim3(1), dim3(256), 0, stream, tmp, v, cols, eps);
     hipLaunchKernelGGL(matvec_kernel, dim3(rows), dim3(256), 0, stream, w_orig, v, tmp, cols);
     hipLaunchKernelGGL(normalize_kernel, dim3(1), dim3(256), 0, stream, tmp, u, rows, eps);

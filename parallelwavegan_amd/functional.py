@@ -56,7 +56,7 @@ class SpectralNormFn(torch.autograd.Function):
         cols = w_orig.numel() // rows
         sigma = torch.empty(1, device=w_orig.device, dtype=torch.float32)
         w = torch.empty_like(w_orig)
-        tmp = torch.empty(max(rows, cols), device=w_orig.device, dtype=torch.float32)
+        tmp = torch.empty(max(rows, 32 * cols), device=w_orig.device, dtype=torch.float32)
         _lib.check(_L().pwg_spectral_norm_forward(_ptr(w_orig), _ptr(u), _ptr(v), _ptr(sigma), _ptr(w), _ptr(tmp),
                                                   rows, cols, int(bool(do_iter)), float(eps), _stream()),
                    "spectral_norm_forward")
