@@ -119,10 +119,16 @@ int pwg_conv1d_pack_weight(const pwg_conv1d_desc* d, const float* w, const float
                            float* w_packed, void* stream);
 
 /* y = fused conv forward (see above).  bias/add1/add2 may be NULL; y must not alias any input.
- * x: (batch, c_in, t_in*width)  y/add1/add2: (batch, c_out, t_out*width)     */
+ * x: (batch, c_in, t_in*width)  y/add1/add2: (batch, c_out, t_out*width).
+ * workspace (optional, may be NULL/0): launches that cannot fill the chip but have a long
+ * reduction (e.g. 1024 channels over 9..110 columns per item) are run as 2/4/8 reduction
+ * slices of a bigger tile; each slice writes a y-shaped slab of `workspace` and a second kernel
+ * sums the slabs in slice order and applies the fused terms (deterministic).  Query the size
+ * (floats, 0 = not needed) first; without a workspace the launch runs unsplit.              */
+size_t pwg_conv1d_forward_workspace_floats(const pwg_conv1d_desc* d);
 int pwg_conv1d_forward(const pwg_conv1d_desc* d, const float* x, const float* w_packed,
                        const float* bias, const float* add1, const float* add2, float* y,
-                       void* stream);
+                       float* workspace, size_t workspace_floats, void* stream);
 
 /* ---- backward (training; replaces ATen convolution_backward at the same call sites) ---- */
 /* Weight image for the data-gradient direction (the dual convolution).          */
@@ -133,9 +139,12 @@ int pwg_conv1d_pack_weight_bwd(const pwg_conv1d_desc* d, const float* w, const f
  * (its post_act/out_mul/out_div are NOT differentiated here: the caller passes the gradient
  * w.r.t. the pre-post_act, pre-scale result).  x: forward input (may be NULL when
  * pre_act == NONE); accum: optional tensor added to the result (gradient accumulation);
- * it must NOT alias dx (the kernels treat outputs as restrict).                                                                 */
+ * it must NOT alias dx (the kernels treat outputs as restrict).  workspace: as for
+ * pwg_conv1d_forward (split reduction), sized by the query below.                    */
+size_t pwg_conv1d_backward_data_workspace_floats(const pwg_conv1d_desc* d);
 int pwg_conv1d_backward_data(const pwg_conv1d_desc* d, const float* dy, const float* w_packed_bwd,
-                             const float* x, const float* accum, float* dx, void* stream);
+                             const float* x, const float* accum, float* dx, float* workspace,
+                             size_t workspace_floats, void* stream);
 /* dw (torch layout, same shape as the forward weight) = sum_{b,t} dy * pre_act(x) taps;
  * db[c] = sum dy.  The (batch, time) reduction is cut into slices that each write a private
  * slab of `workspace`; a second kernel sums the slabs (deterministic, no atomics).  For plain

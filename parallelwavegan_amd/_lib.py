@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libpwgkernels.so")
 
 PWG_ACT_NONE, PWG_ACT_LEAKY_RELU, PWG_ACT_TANH, PWG_ACT_RELU = 0, 1, 2, 3
 PWG_PAD_ZERO, PWG_PAD_REFLECT, PWG_PAD_REPLICATE = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class ConvDesc(ctypes.Structure):
@@ -59,10 +59,14 @@ SIGNATURES = {
                                     ctypes.POINTER(ctypes.c_double)]),
     "pwg_conv1d_packed_weight_floats": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
     "pwg_conv1d_pack_weight": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
-    "pwg_conv1d_forward": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pwg_conv1d_forward_workspace_floats": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
+    "pwg_conv1d_forward": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t,
+                                          _vp]),
     "pwg_conv1d_packed_weight_bwd_floats": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
     "pwg_conv1d_pack_weight_bwd": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
-    "pwg_conv1d_backward_data": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pwg_conv1d_backward_data_workspace_floats": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
+    "pwg_conv1d_backward_data": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t,
+                                                _vp]),
     "pwg_conv1d_backward_weight_workspace_floats": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
     "pwg_conv1d_backward_weight": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "pwg_conv1d_num_tile_configs": (ctypes.c_int, []),

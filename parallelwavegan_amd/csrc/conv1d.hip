@@ -62,7 +62,13 @@ struct ConvArgs {
   // backward-data only: multiply by d(pre_act)/dx evaluated at the forward input
   const float* mask_src;
   float mask_slope;
-  int dbg;  // timing experiments only (PWG_DBG env): 1 = no DMA after chunk 0, 2 = no barriers, 4 = no epilogue  // derivative for mask_src <= 0 (LeakyReLU slope, 0 for ReLU)
+  int dbg;  // timing experiments only (PWG_DBG env): 1 = no DMA after chunk 0, 2 = no barriers, 4 = no epilogue
+  // split-K (DMA kernel): the ci-chunks are cut into ksplit slices (blockIdx.z = item * ksplit + slice);
+  // each slice stores its raw partial sums into its own y-shaped slab of `partial`, and
+  // splitk_finish_kernel sums the slabs and applies the fused epilogue.
+  int ksplit;
+  float* partial;
+  long slab_elems;
 };
 
 template <int WM, int WN, int WAVES_M, int WAVES_N, int CK>
@@ -246,8 +252,10 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 //   two column sub-tiles of a wave come from one ds_read2_b32; the pre-activation is
 //   ACT = 0 none / 1 LeakyReLU with 0 < slope < 1 as max(v, slope*v) (2 VALU) / 2 generic (3 VALU).
 // FAST = false: any geometry (runtime row stride, per-lane column offsets), generic activation.
+// (second launch bound: at least 2 waves per SIMD unless the wave owns 8 accumulator tiles -- hipcc's
+// allocation for the 2x2-tile waves otherwise flips between 174 and 256 VGPRs on unrelated edits)
 template <int WM, int WN, int WAVES_M, int WAVES_N, int CK, bool FAST, int ACT>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv1d_mfma_dma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WM * WN >= 8 ? 1 : 2)) void conv1d_mfma_dma_kernel(ConvArgs a) {
   constexpr int BM = 32 * WM * WAVES_M;
   constexpr int BN = 32 * WN * WAVES_N;
   constexpr int NWAVES = WAVES_M * WAVES_N;
@@ -271,7 +279,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv1d_mfma_dma_kernel
   const int mtiles = (a.m_g + BM - 1) / BM;
   const int g = blockIdx.y / mtiles;
   const int m0 = (blockIdx.y % mtiles) * BM;
-  const int b = blockIdx.z;
+  const int b = blockIdx.z / a.ksplit;
+  const int ks = blockIdx.z - b * a.ksplit;  // reduction slice of this workgroup
 
   const int W = a.width;
   const int h0 = n0 / W;
@@ -334,13 +343,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv1d_mfma_dma_kernel
   };
 
   const float slope_eff = a.pre_act == PWG_ACT_LEAKY_RELU ? a.pre_slope : (a.pre_act == PWG_ACT_RELU ? 0.f : 1.f);
-  const int nchunks = (a.cin_g + CK - 1) / CK;
-  issue(0, smem);
+  const int nchunks_all = (a.cin_g + CK - 1) / CK;
+  const int per_slice = (nchunks_all + a.ksplit - 1) / a.ksplit;
+  const int c_first = ks * per_slice;
+  const int nchunks = max(0, min(per_slice, nchunks_all - c_first));
+  if (nchunks > 0) issue(c_first * CK, smem);
   for (int c = 0; c < nchunks; ++c) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (!(a.dbg & 2)) __syncthreads();
     float* buf = smem + (c & 1) * buf_floats;
-    if (c + 1 < nchunks && !(a.dbg & 1)) issue((c + 1) * CK, smem + ((c + 1) & 1) * buf_floats);
+    if (c + 1 < nchunks && !(a.dbg & 1)) issue((c_first + c + 1) * CK, smem + ((c + 1) & 1) * buf_floats);
     const float* xs = buf;
     const float* wl = buf + CK * XS + wave_m * (WM * 32) + l31 + lhi * BM;  // + tap*CK*BM + 2*kk*BM + mi*32
     const float* xl = xs + lhi * XS + (FAST ? wave_n * (WN * 32) + l31 : 0);  // + tap*tap_step + 2*kk*XS + coff
@@ -400,13 +412,41 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv1d_mfma_dma_kernel
   // Per 32x32 accumulator tile: first ALL addend loads of the lane's 16 outputs are issued (they are
   // independent: y never aliases bias/add1/add2), then the arithmetic, then 16 stores -- memory
   // latency is paid once per tile instead of once per element.
+  const long ybase = (long)b * a.y_bstride;
+  const bool single_phase = a.m_g == a.cout_g;
+  if (a.ksplit > 1) {
+    // split-K slice: raw partial sums into this slice's y-shaped slab; bias / addends / activation
+    // are applied by splitk_finish_kernel.  (Kept apart from the fused epilogue below so that its
+    // register allocation -- 2 waves per SIMD for the 128x128 tiles -- is untouched.)
+    float* __restrict__ slab = a.partial + (long)ks * a.slab_elems;
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni) {
+      const int n = n0 + (wave_n * WN + ni) * 32 + l31;
+      const int q = n / W;
+      const int wcol = n - q * W;
+#pragma unroll
+      for (int mi = 0; mi < WM; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + (wave_m * WM + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          int phase = 0, co = m;
+          if (!single_phase) {
+            phase = m / a.cout_g;
+            co = m - phase * a.cout_g;
+          }
+          const int u = q * a.out_stride + phase - a.out_off;
+          if (n < a.n_cols && m < a.m_g && u >= 0 && u < a.t_out)
+            slab[ybase + (long)(g * a.cout_g + co) * a.y_cstride + (long)u * W + wcol] = acc[mi][ni][r];
+        }
+      }
+    }
+    return;
+  }
   const float* __restrict__ bias_p = a.bias;
   const float* __restrict__ add1_p = a.add1;
   const float* __restrict__ add2_p = a.add2;
   const float* __restrict__ mask_p = a.mask_src;
   float* __restrict__ y_p = a.y;
-  const long ybase = (long)b * a.y_bstride;
-  const bool single_phase = a.m_g == a.cout_g;
 #pragma unroll
   for (int ni = 0; ni < WN; ++ni) {
     const int n = n0 + (wave_n * WN + ni) * 32 + l31;
@@ -447,6 +487,37 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv1d_mfma_dma_kernel
         if (ok[r]) y_p[off[r]] = v;
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// split-K epilogue: y = post((sum_s partial[s] + bias) * mask' + add1 + add2) * out_mul / out_div)
+// elementwise over the y layout (B, C_out, T_out*W); slabs are summed in slice order (deterministic).
+// ---------------------------------------------------------------------------
+struct FinishArgs {
+  const float* partial;
+  const float* bias;
+  const float* add1;
+  const float* add2;
+  const float* mask_src;
+  float* y;
+  long elems, slab_elems;
+  int nslabs, y_cstride, c_out;
+  int post_act;
+  float post_slope, out_mul, out_div, mask_slope;
+};
+
+__global__ __launch_bounds__(256) void splitk_finish_kernel(FinishArgs a) {
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < a.elems; e += (long)gridDim.x * 256L) {
+    float v = a.partial[e];
+    for (int s = 1; s < a.nslabs; ++s) v += a.partial[(long)s * a.slab_elems + e];
+    if (a.bias) v += a.bias[(e / a.y_cstride) % a.c_out];
+    if (a.mask_src) v *= (a.mask_src[e] > 0.f ? 1.f : a.mask_slope);
+    if (a.add1) v += a.add1[e];
+    if (a.add2) v += a.add2[e];
+    if (a.out_mul != 1.0f) v *= a.out_mul;
+    if (a.out_div != 1.0f) v = v / a.out_div;
+    a.y[e] = apply_act(v, a.post_act, a.post_slope);
   }
 }
 
@@ -637,7 +708,8 @@ static int launch_conv(const ConvArgs& a0, const Geometry& g, int batch, int gro
     PWG_REQUIRE(e == hipSuccess, PWG_ERR_LAUNCH, "conv1d: cannot raise LDS limit to %zu: %s", lds,
                 hipGetErrorString(e));
   }
-  dim3 grid(ceil_div(g.n_cols, BN), ceil_div(g.m_g, BM) * groups, batch);
+  if (!DMA) a.ksplit = 1;  // (the register-staged kernel has no split-K)
+  dim3 grid(ceil_div(g.n_cols, BN), ceil_div(g.m_g, BM) * groups, batch * a.ksplit);
   dim3 block(64 * WAVES_M * WAVES_N);
   // algorithmic work of this launch: 2*taps*Cin_g MACs per real output element, and one read of
   // x / one write of y / one read of each fused addend / one read of the packed weights
@@ -647,15 +719,42 @@ static int launch_conv(const ConvArgs& a0, const Geometry& g, int batch, int gro
   const double bytes = 4.0 * ((double)batch * groups * g.cin_g * a.t_in * a.width +
                               out_elems * (1 + (a.add1 != nullptr) + (a.add2 != nullptr)) +
                               (double)groups * g.k_phase * g.cin_g * g.m_g);
-  ProfScope prof(stream, DMA ? "conv1d_mfma_dma_kernel" : "conv1d_mfma_kernel", flops, bytes);
-  hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
+  {
+    ProfScope prof(stream, DMA ? "conv1d_mfma_dma_kernel" : "conv1d_mfma_kernel", flops, bytes);
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
+  }
   PWG_CHECK_LAUNCH("conv1d_forward");
+  if (a.ksplit > 1) {
+    FinishArgs f;
+    f.partial = a.partial;
+    f.bias = a.bias;
+    f.add1 = a.add1;
+    f.add2 = a.add2;
+    f.mask_src = a.mask_src;
+    f.y = a.y;
+    f.elems = f.slab_elems = a.slab_elems;
+    f.nslabs = a.ksplit;
+    f.y_cstride = a.y_cstride;
+    f.c_out = g.cout_g * groups;
+    f.post_act = a.post_act;
+    f.post_slope = a.post_slope;
+    f.out_mul = a.out_mul;
+    f.out_div = a.out_div;
+    f.mask_slope = a.mask_slope;
+    long blocks = (f.elems + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    const int extra = (a.add1 != nullptr) + (a.add2 != nullptr) + (a.mask_src != nullptr);
+    ProfScope prof(stream, "splitk_finish_kernel", 0, 4.0 * f.elems * (a.ksplit + 1 + extra));
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3((int)blocks), dim3(256), 0, stream, f);
+    PWG_CHECK_LAUNCH("splitk_finish");
+  }
   return PWG_OK;
 }
 
 // Tile configurations (id -> instantiation).  ids are stable: tools/bench_conv.py sweeps them.
 struct TileCfg {
   int bm, bn, ck;
+  int wm, wn;  // 32x32 accumulator tiles per wave
 };
 #define PWG_CONV_CFGS(X)  \
   X(0, 2, 2, 2, 2, 8)     \
@@ -685,11 +784,11 @@ static TileCfg cfg_info(int id) {
   switch (id) {
 #define X(ID, WM, WN, WVM, WVN, CK) \
   case ID:                          \
-    return TileCfg{32 * WM * WVM, 32 * WN * WVN, CK};
+    return TileCfg{32 * WM * WVM, 32 * WN * WVN, CK, WM, WN};
     PWG_CONV_CFGS(X)
 #undef X
   }
-  return TileCfg{0, 0, 0};
+  return TileCfg{0, 0, 0, 0, 0};
 }
 
 static size_t cfg_lds(int id, const Geometry& g, int W, bool dma) {
@@ -727,11 +826,18 @@ struct Cand {
   int id;
   float speed;
 };
-static int choose_cfg(const Geometry& g, int W, int batch, int groups, bool dma) {
+// ksplit (optional out): number of reduction slices.  A workgroup walks its ci-chunks serially and a
+// chunk costs at least one DMA + barrier round trip (~2.7 us measured) however little MFMA work it
+// carries; when the chosen tile leaves the SIMDs that idle (few workgroups, short chunks: the
+// 1024-channel discriminator layers with T = 9..32, C -> 1 output convs, deep generator layers at
+// training lengths) the reduction is cut into 2/4/8 slices so that 2-8 workgroups interleave per
+// CU.  Slices are added only while the per-SIMD MFMA time of a chunk stays below the round trip.
+static int choose_cfg(const Geometry& g, int W, int batch, int groups, bool dma, int* ksplit = nullptr) {
   const int m = g.m_g;
   const int k = g.k_phase;
-  static const Cand big_few[] = {{12, 0.95f}, {0, 0.85f}, {16, 0.85f}, {17, 0.75f}, {18, 0.6f}, {2, 0.8f}};
-  static const Cand big_many[] = {{2, 1.0f}, {12, 0.9f}, {16, 0.85f}, {17, 0.75f}, {18, 0.6f}};
+  static const Cand big_few[] = {{12, 0.95f}, {0, 0.85f}, {16, 0.85f}, {17, 0.75f}, {18, 0.6f}, {2, 0.8f},
+                                 {19, 0.8f}, {20, 0.82f}};
+  static const Cand big_many[] = {{2, 1.0f}, {12, 0.9f}, {16, 0.85f}, {17, 0.75f}, {18, 0.6f}, {19, 0.8f}, {20, 0.82f}};
   static const Cand mid_few[] = {{13, 1.0f}, {15, 0.8f}, {17, 0.8f}};
   static const Cand mid_many[] = {{15, 1.0f}, {13, 0.9f}, {17, 0.8f}};
   static const Cand small_any[] = {{13, 1.0f}};
@@ -739,7 +845,7 @@ static int choose_cfg(const Geometry& g, int W, int batch, int groups, bool dma)
   int ncand;
   if (m > 64) {
     cand = k <= 4 ? big_few : big_many;
-    ncand = k <= 4 ? 6 : 5;
+    ncand = k <= 4 ? 8 : 7;
   } else if (m > 32) {
     cand = k <= 8 ? mid_few : mid_many;
     ncand = 3;
@@ -747,38 +853,43 @@ static int choose_cfg(const Geometry& g, int W, int batch, int groups, bool dma)
     cand = small_any;
     ncand = 1;
   }
-  int best = -1;
+  // slices the latency rule allows for a tile: more workgroups per CU only while the per-SIMD MFMA
+  // time of a chunk stays below the DMA + barrier round trip (6200 cycles ~ 2.7 us)
+  auto max_split = [&](const TileCfg& c, long blocks) {
+    if (!ksplit || !dma) return 1;
+    const long per_cu = (blocks + 255) / 256;                       // = waves per SIMD (4-wave workgroups)
+    const double mfma_chunk = 64.0 * c.wm * c.wn * k * (c.ck / 2);  // MFMA cycles per chunk per wave
+    const int nchunks = ceil_div(g.cin_g, c.ck);
+    int split = 1;
+    while (split < 8 && nchunks >= 8 * split && mfma_chunk * per_cu * (2 * split) <= 6200.0) split *= 2;
+    return split;
+  };
+  int best = -1, best_split = 1;
   float best_score = -1.f;
   for (int pass = 0; pass < 2 && best < 0; ++pass) {
     const size_t cap = pass == 0 ? 80 * 1024 : 160 * 1024;  // first try to keep >= 2 workgroups per CU
     for (int i = 0; i < ncand; ++i) {
       if (cfg_lds(cand[i].id, g, W, dma) > cap) continue;
       const TileCfg c = cfg_info(cand[i].id);
+      if (c.ck == 16 && (!dma || g.cin_g < 256)) continue;  // 16-channel chunks: long reductions only
       const long ntiles = ceil_div(g.n_cols, c.bn);
       const long blocks = ntiles * ceil_div(m, c.bm) * groups * batch;
-      const float fill = blocks >= 512 ? 1.f : (float)blocks / 512.f;
+      const int split = max_split(c, blocks);
+      const float fill = blocks * split >= 512 ? 1.f : (float)(blocks * split) / 512.f;
       const float useful = (float)g.n_cols / (float)(ntiles * c.bn) * (float)m / (float)(ceil_div(m, c.bm) * c.bm);
-      const float score = fill * useful * cand[i].speed;
+      const float score = fill * useful * cand[i].speed * (split > 1 ? 0.9f : 1.f);
       if (score > best_score) {
         best_score = score;
         best = cand[i].id;
+        best_split = split;
       }
     }
   }
-  if (best < 0) return 13;
-  // Long reductions over few columns (1024-channel discriminator layers, deep generator layers at
-  // training lengths): the launch cannot fill the chip with big tiles, and a small tile's chunk time
-  // is a DMA round trip rather than MFMA work -- 16-channel chunks halve the number of round trips
-  // (tools/bench_dconv.py sweep: 10-20 % over the 8-channel tiles).
-  if (dma && (best == 17 || best == 13 || best == 12) && g.cin_g >= 256 && g.cin_g % 16 == 0) {
-    const TileCfg cb = cfg_info(best);
-    const long blocks = (long)ceil_div(g.n_cols, cb.bn) * ceil_div(m, cb.bm) * groups * batch;
-    if (blocks <= 1024) {
-      const int wide = (g.n_cols > 64 && g.n_cols <= 128) ? 20 : 19;  // one 128-column tile per item, else 64x64
-      if (cfg_lds(wide, g, W, dma) <= 80 * 1024) return wide;
-      if (cfg_lds(19, g, W, dma) <= 80 * 1024) return 19;
-    }
+  if (best < 0) {
+    best = 13;
+    best_split = 1;
   }
+  if (ksplit) *ksplit = best_split;
   return best;
 }
 
@@ -825,6 +936,9 @@ static int fill_args(const pwg_conv1d_desc* d, const Geometry& g, const float* x
   a.mask_slope = 0.f;
   static const int dbg = getenv("PWG_DBG") ? atoi(getenv("PWG_DBG")) : 0;
   a.dbg = dbg;
+  a.ksplit = 1;
+  a.partial = nullptr;
+  a.slab_elems = (long)d->batch * d->c_out * d->t_out * d->width;
   *out = a;
   return PWG_OK;
 }
@@ -867,9 +981,57 @@ extern "C" int pwg_conv1d_pack_weight(const pwg_conv1d_desc* d, const float* w, 
   return PWG_OK;
 }
 
+// tile configuration, staging path and split-K factor of a (flattened) forward-form descriptor
+struct ConvPlan {
+  int id, ksplit;
+  bool dma;
+};
+static ConvPlan plan_conv(const pwg_conv1d_desc* d, const Geometry& g) {
+  ConvPlan p;
+  p.dma = d->pad_mode == PWG_PAD_ZERO;  // reflect/replicate need index remapping: register path
+  p.ksplit = 1;
+  p.id = choose_cfg(g, d->width, d->batch, d->groups, p.dma, &p.ksplit);
+  if (p.dma && cfg_lds(p.id, g, d->width, true) > 160 * 1024) {  // very long filters (PQMF k=63): single buffer
+    p.dma = false;
+    p.ksplit = 1;
+    p.id = choose_cfg(g, d->width, d->batch, d->groups, false);
+  }
+  return p;
+}
+
+static int run_conv(const pwg_conv1d_desc* d, const Geometry& g, ConvArgs& a, float* workspace, size_t ws_floats,
+                    hipStream_t stream) {
+  ConvPlan p = plan_conv(d, g);
+  if (p.ksplit > 1) {
+    const size_t need = (size_t)p.ksplit * a.slab_elems;
+    if (workspace && ws_floats >= need) {
+      a.ksplit = p.ksplit;
+      a.partial = workspace;
+    } else {
+      // no (or too small a) workspace: run unsplit with the best unsplit tile
+      p.id = choose_cfg(g, d->width, d->batch, d->groups, p.dma);
+    }
+  }
+  static const bool trace = getenv("PWG_TRACE_CFG") != nullptr;
+  if (trace)
+    fprintf(stderr, "[pwg] conv B=%d Cin=%d Cout=%d Tin=%d Tout=%d k=%d s=%d d=%d g=%d tr=%d -> cfg %d split %d dma %d\n",
+            d->batch, d->c_in, d->c_out, d->t_in, d->t_out, d->kernel, d->stride, d->dilation, d->groups,
+            d->transposed, p.id, a.ksplit, (int)p.dma);
+  return launch_cfg(p.id, p.dma, a, g, d->batch, d->groups, stream);
+}
+
+extern "C" size_t pwg_conv1d_forward_workspace_floats(const pwg_conv1d_desc* d_in) {
+  if (!d_in) return 0;
+  const pwg_conv1d_desc flat = flatten_width(*d_in);
+  Geometry g;
+  if (make_geometry(&flat, &g) != PWG_OK) return 0;
+  const ConvPlan p = plan_conv(&flat, g);
+  return p.ksplit > 1 ? (size_t)p.ksplit * flat.batch * flat.c_out * flat.t_out * flat.width : 0;
+}
+
 extern "C" int pwg_conv1d_forward(const pwg_conv1d_desc* d_in, const float* x, const float* w_packed,
                                   const float* bias, const float* add1, const float* add2, float* y,
-                                  void* stream) {
+                                  float* workspace, size_t workspace_floats, void* stream) {
   PWG_REQUIRE(d_in != nullptr, PWG_ERR_NULL, "conv1d: NULL descriptor");
   const pwg_conv1d_desc flat = flatten_width(*d_in);
   const pwg_conv1d_desc* d = &flat;
@@ -879,13 +1041,7 @@ extern "C" int pwg_conv1d_forward(const pwg_conv1d_desc* d_in, const float* x, c
   ConvArgs a;
   rc = fill_args(d, g, x, w_packed, bias, add1, add2, y, &a);
   if (rc != PWG_OK) return rc;
-  bool dma = d->pad_mode == PWG_PAD_ZERO;  // reflect/replicate need index remapping: register path
-  int id = choose_cfg(g, d->width, d->batch, d->groups, dma);
-  if (dma && cfg_lds(id, g, d->width, true) > 160 * 1024) {  // very long filters (PQMF k=63): single buffer
-    dma = false;
-    id = choose_cfg(g, d->width, d->batch, d->groups, false);
-  }
-  return launch_cfg(id, dma, a, g, d->batch, d->groups, (hipStream_t)stream);
+  return run_conv(d, g, a, workspace, workspace_floats, (hipStream_t)stream);
 }
 
 // The data gradient of a convolution is the transposed convolution with the same torch-layout
@@ -919,8 +1075,16 @@ extern "C" int pwg_conv1d_pack_weight_bwd(const pwg_conv1d_desc* d, const float*
   return pwg_conv1d_pack_weight(&dd, w, scale, w_packed_bwd, stream);
 }
 
+extern "C" size_t pwg_conv1d_backward_data_workspace_floats(const pwg_conv1d_desc* d) {
+  if (!d) return 0;
+  pwg_conv1d_desc dd;
+  dual_desc(d, &dd);
+  return pwg_conv1d_forward_workspace_floats(&dd);
+}
+
 extern "C" int pwg_conv1d_backward_data(const pwg_conv1d_desc* d, const float* dy, const float* w_packed_bwd,
-                                        const float* x, const float* accum, float* dx, void* stream) {
+                                        const float* x, const float* accum, float* dx, float* workspace,
+                                        size_t workspace_floats, void* stream) {
   PWG_REQUIRE(d, PWG_ERR_NULL, "conv1d_backward_data: NULL descriptor");
   PWG_REQUIRE(d->pad_mode == PWG_PAD_ZERO, PWG_ERR_UNSUPPORTED,
               "conv1d_backward_data: only zero padding (pad reflect/replicate inputs explicitly)");
@@ -939,13 +1103,7 @@ extern "C" int pwg_conv1d_backward_data(const pwg_conv1d_desc* d, const float* d
     a.mask_src = x;
     a.mask_slope = d->pre_act == PWG_ACT_LEAKY_RELU ? d->pre_slope : 0.f;
   }
-  bool dma = true;
-  int id = choose_cfg(g, dd.width, dd.batch, dd.groups, true);
-  if (cfg_lds(id, g, dd.width, true) > 160 * 1024) {
-    dma = false;
-    id = choose_cfg(g, dd.width, dd.batch, dd.groups, false);
-  }
-  return launch_cfg(id, dma, a, g, dd.batch, dd.groups, (hipStream_t)stream);
+  return run_conv(&dd, g, a, workspace, workspace_floats, (hipStream_t)stream);
 }
 
 extern "C" int pwg_conv1d_num_tile_configs(void) { return kNumCfgs; }

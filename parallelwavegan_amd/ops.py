@@ -78,14 +78,22 @@ def pack_weight(desc, w, scale=None):
     return out
 
 
+def _workspace(n_floats, device):
+    """Scratch for a split reduction (caller-owned per the C ABI: torch's caching allocator here)."""
+    if not n_floats:
+        return None, 0
+    return torch.empty(n_floats, device=device, dtype=torch.float32), n_floats
+
+
 def conv1d_forward(desc, x, w_packed, bias=None, add1=None, add2=None, out=None):
     _require_device(x, w_packed, bias, add1, add2, out)
     if out is None:
         out = torch.empty((desc.batch, desc.c_out, desc.t_out * desc.width), device=x.device, dtype=torch.float32)
     assert x.numel() == desc.batch * desc.c_in * desc.t_in * desc.width, (tuple(x.shape), desc.batch, desc.c_in, desc.t_in)
     assert out.numel() == desc.batch * desc.c_out * desc.t_out * desc.width
+    ws, ws_n = _workspace(_lib.lib().pwg_conv1d_forward_workspace_floats(ctypes.byref(desc)), x.device)
     _lib.check(_lib.lib().pwg_conv1d_forward(ctypes.byref(desc), _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(add1),
-                                             _ptr(add2), _ptr(out), _stream()), "conv1d_forward")
+                                             _ptr(add2), _ptr(out), _ptr(ws), ws_n, _stream()), "conv1d_forward")
     return out
 
 
@@ -106,8 +114,10 @@ def conv1d_backward_data(desc, dy, w_packed_bwd, x=None, accum=None, out=None):
     _require_device(dy, w_packed_bwd, x, accum, out)
     if out is None:
         out = torch.empty((desc.batch, desc.c_in, desc.t_in * desc.width), device=dy.device, dtype=torch.float32)
+    ws, ws_n = _workspace(_lib.lib().pwg_conv1d_backward_data_workspace_floats(ctypes.byref(desc)), dy.device)
     _lib.check(_lib.lib().pwg_conv1d_backward_data(ctypes.byref(desc), _ptr(dy), _ptr(w_packed_bwd), _ptr(x),
-                                                   _ptr(accum), _ptr(out), _stream()), "conv1d_backward_data")
+                                                   _ptr(accum), _ptr(out), _ptr(ws), ws_n, _stream()),
+               "conv1d_backward_data")
     return out
 
 

@@ -185,3 +185,47 @@ def test_large_dilation_weight_gradient(dil, device):
     _close(ops.conv1d_backward_data(desc, dyd, ops.pack_weight_bwd(desc, wd)), x.grad, "backward_data")
     dw, db = ops.conv1d_backward_weight(desc, xd, dyd, tuple(w.shape))
     _close(dw, w.grad, "backward_weight")
+
+
+SPLIT_CASES = [
+    # B, Cin, Cout, T, K, stride, pad, groups   (long reductions over few columns: split-K candidates)
+    (4, 1024, 1024, 17, 5, 1, 2, 1),
+    (2, 512, 1024, 40, 5, 1, 2, 1),
+    (3, 1024, 512, 9, 3, 1, 1, 1),
+    (2, 512, 256, 32, 7, 1, 3, 1),
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,K,stride,pad,groups", SPLIT_CASES)
+def test_split_reduction_forward_backward(B, Cin, Cout, T, K, stride, pad, groups, device):
+    """Launches with few columns and a long reduction run as reduction slices + a finishing kernel
+    (pwg_conv1d_forward_workspace_floats > 0); results must match the plain convolution, including
+    every fused epilogue term and the pre-activation mask of the data gradient."""
+    import ctypes
+    from parallelwavegan_amd import _lib
+
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    x = torch.randn(B, Cin, T, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin // groups, K, generator=g) / (Cin * K) ** 0.5).requires_grad_()
+    b = torch.randn(Cout, generator=g)
+    r1 = torch.randn(B, Cout, T, generator=g)
+    y_ref = F.leaky_relu((F.conv1d(F.leaky_relu(x, 0.1), w, b, padding=pad, groups=groups) + r1) / 2, 0.2)
+    dy = torch.randn(y_ref.shape, generator=g)
+    desc = ops.make_conv_desc(B, Cin, Cout, T, T, K, stride, 1, pad, groups, pre_act="leaky_relu", pre_slope=0.1,
+                              post_act="leaky_relu", post_slope=0.2, out_div=2.0)
+    n_ws = _lib.lib().pwg_conv1d_forward_workspace_floats(ctypes.byref(desc))
+    assert n_ws > 0 and n_ws % (B * Cout * T) == 0, "case no longer exercises the split path"
+    xd, wd, bd, r1d, dyd = (t.detach().to(device).contiguous() for t in (x, w, b, r1, dy))
+    y = ops.conv1d_forward(desc, xd, ops.pack_weight(desc, wd), bd, r1d)
+    _close(y, y_ref, "split forward")
+    # unsplit path on the same data (explicit tile configuration never splits)
+    y_plain = ops.conv1d_forward_cfg(desc, xd, ops.pack_weight(desc, wd), bd, r1d, tile_config=17, use_dma=True)
+    _close(y, y_plain.cpu(), "split vs unsplit")
+    # data gradient of conv(leaky_relu(x)) with accumulation
+    pre = F.conv1d(F.leaky_relu(x, 0.1), w, None, padding=pad, groups=groups)
+    pre.backward(dy)
+    acc = torch.randn(B, Cin, T, generator=g)
+    desc_b = ops.make_conv_desc(B, Cin, Cout, T, T, K, stride, 1, pad, groups, pre_act="leaky_relu", pre_slope=0.1)
+    assert _lib.lib().pwg_conv1d_backward_data_workspace_floats(ctypes.byref(desc_b)) > 0
+    dx = ops.conv1d_backward_data(desc_b, dyd, ops.pack_weight_bwd(desc_b, wd), xd, acc.to(device))
+    _close(dx, x.grad + acc, "split backward_data")
