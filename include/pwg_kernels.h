@@ -211,11 +211,14 @@ int pwg_gate_backward(const float* z, const float* dout, float* dz, int32_t batc
                       int64_t t, void* stream);
 /* One stage of the mel upsampler: F.interpolate(nearest, x scale) followed by the
  * (1, 2*scale+1) single-channel Conv2d, fused (layers/upsample.py:43-45,97-103,121-127):
- *   y[r][t] = sum_j w[j] * x[r][(t + j - scale) / scale],  rows = B * mel channels.  */
+ *   y[r][t] = sum_j w[j] * x[r][(t + j - pad_left) / scale],  rows = B * mel channels;
+ * pad_left = scale (centred) or 2*scale (use_causal_conv: :96-99,121-125, output trimmed
+ * to the stretched length).                                                          */
 int pwg_stretch_conv_forward(const float* x, const float* w, float* y, int64_t rows, int32_t t_in,
-                             int32_t scale, int32_t kernel, void* stream);
+                             int32_t scale, int32_t kernel, int32_t pad_left, void* stream);
 int pwg_stretch_conv_backward(const float* dy, const float* x, const float* w, float* dx, float* dw,
-                              int64_t rows, int32_t t_in, int32_t scale, int32_t kernel, void* stream);
+                              int64_t rows, int32_t t_in, int32_t scale, int32_t kernel, int32_t pad_left,
+                              void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Pooling / explicit padding                                                  */

@@ -488,3 +488,127 @@ def pqmf_synthesis(x, subbands=4, taps=62, cutoff_ratio=0.142, beta=9.0):
     _, hs = pqmf_filters(subbands, taps, cutoff_ratio, beta)
     x = F.conv_transpose1d(x, _updown(subbands) * subbands, stride=subbands)
     return F.conv1d(F.pad(x, (taps // 2, taps // 2)), hs)
+
+
+# ----------------------------------------------------------------------------
+# causal variants (layers/causal_conv.py:12-77 and the use_causal_conv branches of the models)
+# ----------------------------------------------------------------------------
+def causal_conv1d(x, w, b, dilation=1, pad_mode="constant"):
+    """``CausalConv1d.forward`` layers/causal_conv.py:33-43: left pad (k-1)*d, conv, keep the first T."""
+    p = (w.shape[-1] - 1) * dilation
+    xp = F.pad(x, (p, p), mode=pad_mode) if pad_mode != "constant" else F.pad(x, (p, p))
+    return F.conv1d(xp, w, b, dilation=dilation)[:, :, : x.size(2)]
+
+
+def causal_conv_transpose1d(x, w, b, stride):
+    """``CausalConvTranspose1d.forward`` layers/causal_conv.py:67-77: replicate-pad one sample on the
+    left, transposed conv, drop ``stride`` samples at both ends."""
+    return F.conv_transpose1d(F.pad(x, (1, 0), mode="replicate"), w, b, stride=stride)[:, :, stride:-stride]
+
+
+def hifigan_generator_causal(sd, c, upsample_scales=(8, 8, 2, 2), resblock_kernel_sizes=(3, 7, 11),
+                             resblock_dilations=((1, 3, 5), (1, 3, 5), (1, 3, 5)), use_additional_convs=True,
+                             slope=0.1, **_unused):
+    """``HiFiGANGenerator.forward`` with ``use_causal_conv=True`` (models/hifigan.py:82-88,115-123,156-162;
+    layers/residual_block.py:196-241).  NOTE: ``CausalConv1d`` pads on BOTH sides and trims the tail
+    (causal_conv.py:27,43), which equals left-only padding."""
+    c = causal_conv1d(c, get_weight(sd, "input_conv.conv"), get_bias(sd, "input_conv.conv"))
+    nb = len(resblock_kernel_sizes)
+    for i, s in enumerate(upsample_scales):
+        p = f"upsamples.{i}.1.deconv"
+        c = causal_conv_transpose1d(F.leaky_relu(c, slope), get_weight(sd, p), get_bias(sd, p), s)
+        cs = 0.0
+        for j in range(nb):
+            x = c
+            for idx, d in enumerate(resblock_dilations[j]):
+                p1 = f"blocks.{i * nb + j}.convs1.{idx}.1.conv"
+                xt = causal_conv1d(F.leaky_relu(x, slope), get_weight(sd, p1), get_bias(sd, p1), d)
+                if use_additional_convs:
+                    p2 = f"blocks.{i * nb + j}.convs2.{idx}.1.conv"
+                    xt = causal_conv1d(F.leaky_relu(xt, slope), get_weight(sd, p2), get_bias(sd, p2), 1)
+                x = xt + x
+            cs = cs + x
+        c = cs / nb
+    p = "output_conv.1.conv"
+    return torch.tanh(causal_conv1d(F.leaky_relu(c, 0.01), get_weight(sd, p), get_bias(sd, p)))
+
+
+def melgan_generator_causal(sd, c, upsample_scales=(8, 8, 2, 2), stack_kernel_size=3, stacks=3, slope=0.2,
+                            use_final_nonlinear_activation=True, **_unused):
+    """``MelGANGenerator.forward`` with ``use_causal_conv=True`` (models/melgan.py:75-84,104-112,142-151;
+    layers/residual_stack.py:56-69): reflection padding, left side only after the trim."""
+    x = causal_conv1d(c, get_weight(sd, "melgan.0.conv"), get_bias(sd, "melgan.0.conv"), pad_mode="reflect")
+    idx = 1
+    for s in upsample_scales:
+        p = f"melgan.{idx + 1}.deconv"
+        x = causal_conv_transpose1d(F.leaky_relu(x, slope), get_weight(sd, p), get_bias(sd, p), s)
+        idx += 2
+        for j in range(stacks):
+            d = stack_kernel_size ** j
+            pre = f"melgan.{idx}"
+            t = causal_conv1d(F.leaky_relu(x, slope), get_weight(sd, pre + ".stack.1.conv"),
+                              get_bias(sd, pre + ".stack.1.conv"), d, pad_mode="reflect")
+            t = F.conv1d(F.leaky_relu(t, slope), get_weight(sd, pre + ".stack.3"), get_bias(sd, pre + ".stack.3"))
+            x = t + F.conv1d(x, get_weight(sd, pre + ".skip_layer"), get_bias(sd, pre + ".skip_layer"))
+            idx += 1
+    p = f"melgan.{idx + 1}.conv"
+    x = causal_conv1d(F.leaky_relu(x, slope), get_weight(sd, p), get_bias(sd, p), pad_mode="reflect")
+    return torch.tanh(x) if use_final_nonlinear_activation else x
+
+
+def pwg_generator_causal(sd, z, c, layers=30, stacks=3, kernel_size=3, aux_context_window=2, upsample_params=None,
+                         **_unused):
+    """``ParallelWaveGANGenerator.forward`` with ``use_causal_conv=True`` (layers/upsample.py:96-99,
+    121-125,160-164,192-193; layers/residual_block.py:74-76,118-119)."""
+    scales = (upsample_params or {}).get("upsample_scales", (4, 4, 4, 4))
+    c = F.conv1d(c, get_weight(sd, "upsample_net.conv_in"))  # kernel aux_context_window + 1
+    if aux_context_window > 0:
+        c = c[:, :, :-aux_context_window]
+    c = c.unsqueeze(1)
+    for i, s in enumerate(scales):
+        c = F.interpolate(c, scale_factor=(1, s), mode="nearest")
+        c = F.conv2d(c, get_weight(sd, f"upsample_net.upsample.up_layers.{2 * i + 1}"), padding=(0, 2 * s))[..., : c.size(-1)]
+    c = c.squeeze(1)
+    assert c.size(-1) == z.size(-1)
+    x = F.conv1d(z, get_weight(sd, "first_conv"), get_bias(sd, "first_conv"))
+    skips = 0
+    per_stack = layers // stacks
+    for l in range(layers):
+        p = f"conv_layers.{l}"
+        d = 2 ** (l % per_stack)
+        residual = x
+        h = F.conv1d(x, get_weight(sd, p + ".conv"), get_bias(sd, p + ".conv"), dilation=d,
+                     padding=(kernel_size - 1) * d)[:, :, : residual.size(-1)]
+        xa, xb = h.split(h.size(1) // 2, dim=1)
+        a = F.conv1d(c, get_weight(sd, p + ".conv1x1_aux"))
+        ca, cb = a.split(a.size(1) // 2, dim=1)
+        g = torch.tanh(xa + ca) * torch.sigmoid(xb + cb)
+        s = F.conv1d(g, get_weight(sd, p + ".conv1x1_skip"), get_bias(sd, p + ".conv1x1_skip"))
+        x = (F.conv1d(g, get_weight(sd, p + ".conv1x1_out"), get_bias(sd, p + ".conv1x1_out")) + residual) * math.sqrt(0.5)
+        skips = skips + s
+    skips = skips * math.sqrt(1.0 / layers)
+    x = F.conv1d(F.relu(skips), get_weight(sd, "last_conv_layers.1"), get_bias(sd, "last_conv_layers.1"))
+    return F.conv1d(F.relu(x), get_weight(sd, "last_conv_layers.3"), get_bias(sd, "last_conv_layers.3"))
+
+
+def residual_pwg_discriminator(sd, x, layers=30, stacks=3, kernel_size=3, slope=0.2, use_causal_conv=False, **_unused):
+    """``ResidualParallelWaveGANDiscriminator.forward`` models/parallel_wavegan.py:471-494."""
+    x = F.leaky_relu(F.conv1d(x, get_weight(sd, "first_conv.0"), get_bias(sd, "first_conv.0")), slope)
+    skips = 0
+    per_stack = layers // stacks
+    for l in range(layers):
+        p = f"conv_layers.{l}"
+        d = 2 ** (l % per_stack)
+        residual = x
+        pad = (kernel_size - 1) * d if use_causal_conv else (kernel_size - 1) // 2 * d
+        h = F.conv1d(x, get_weight(sd, p + ".conv"), get_bias(sd, p + ".conv"), dilation=d, padding=pad)
+        if use_causal_conv:
+            h = h[:, :, : residual.size(-1)]
+        xa, xb = h.split(h.size(1) // 2, dim=1)
+        g = torch.tanh(xa) * torch.sigmoid(xb)
+        s = F.conv1d(g, get_weight(sd, p + ".conv1x1_skip"), get_bias(sd, p + ".conv1x1_skip"))
+        x = (F.conv1d(g, get_weight(sd, p + ".conv1x1_out"), get_bias(sd, p + ".conv1x1_out")) + residual) * math.sqrt(0.5)
+        skips = skips + s
+    skips = skips * math.sqrt(1.0 / layers)
+    x = F.conv1d(F.leaky_relu(skips, slope), get_weight(sd, "last_conv_layers.1"), get_bias(sd, "last_conv_layers.1"))
+    return F.conv1d(F.leaky_relu(x, slope), get_weight(sd, "last_conv_layers.3"), get_bias(sd, "last_conv_layers.3"))

@@ -78,8 +78,8 @@ SIGNATURES = {
     "pwg_spectral_norm_backward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "pwg_gate_forward": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i64, _vp]),
     "pwg_gate_backward": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i64, _vp]),
-    "pwg_stretch_conv_forward": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
-    "pwg_stretch_conv_backward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "pwg_stretch_conv_forward": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "pwg_stretch_conv_backward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "pwg_avg_pool1d_forward": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pwg_avg_pool1d_backward": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pwg_pad1d_forward": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),

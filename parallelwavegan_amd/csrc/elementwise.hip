@@ -354,9 +354,9 @@ __global__ void gate_bwd_kernel(const float* z, const float* dout, float* dz, in
 
 // ---- PWG mel upsampler stage: nearest stretch x s along time fused with the (1, 2s+1) smoothing
 // conv (layers/upsample.py:43-45,97-103):  y[r][t] = sum_j w[j] * x[r][(t + j - s) / s]   (zero pad)
-__global__ void stretch_conv_fwd_kernel(const float* x, const float* w, float* y, long rows, int t_in, int s, int k) {
+__global__ void stretch_conv_fwd_kernel(const float* x, const float* w, float* y, long rows, int t_in, int s, int k,
+                                        int pad) {
   const int t_out = t_in * s;
-  const int pad = (k - 1) / 2;
   const long n = rows * t_out;
   GRID_STRIDE(i, n) {
     const long r = i / t_out;
@@ -371,9 +371,8 @@ __global__ void stretch_conv_fwd_kernel(const float* x, const float* w, float* y
   }
 }
 __global__ void stretch_conv_bwd_data_kernel(const float* dy, const float* w, float* dx, long rows, int t_in, int s,
-                                             int k) {
+                                             int k, int pad) {
   const int t_out = t_in * s;
-  const int pad = (k - 1) / 2;
   const long n = rows * t_in;
   GRID_STRIDE(i, n) {
     const long r = i / t_in;
@@ -390,10 +389,9 @@ __global__ void stretch_conv_bwd_data_kernel(const float* dy, const float* w, fl
 }
 // dw[j] = sum_{r,t} dy[r][t] * xs[r][t + j - pad];  dw must be zeroed (block partials + atomics, k <= 64)
 __global__ void stretch_conv_bwd_weight_kernel(const float* dy, const float* x, float* dw, long rows, int t_in, int s,
-                                               int k) {
+                                               int k, int pad) {
   __shared__ float red[4];
   const int t_out = t_in * s;
-  const int pad = (k - 1) / 2;
   const long n = rows * t_out;
   for (int j = 0; j < k; ++j) {
     float acc = 0.f;
@@ -607,31 +605,32 @@ extern "C" int pwg_gate_backward(const float* z, const float* dout, float* dz, i
 }
 
 extern "C" int pwg_stretch_conv_forward(const float* x, const float* w, float* y, int64_t rows, int32_t t_in,
-                                        int32_t scale, int32_t kernel, void* stream) {
+                                        int32_t scale, int32_t kernel, int32_t pad_left, void* stream) {
   PWG_REQUIRE(x && w && y, PWG_ERR_NULL, "stretch_conv_forward: NULL pointer");
-  PWG_REQUIRE(rows > 0 && t_in > 0 && scale > 0 && kernel > 0 && kernel % 2 == 1 && kernel <= 64, PWG_ERR_BAD_SHAPE,
-              "stretch_conv: bad geometry");
+  PWG_REQUIRE(rows > 0 && t_in > 0 && scale > 0 && kernel > 0 && kernel <= 64 && pad_left >= 0 && pad_left < kernel,
+              PWG_ERR_BAD_SHAPE, "stretch_conv: bad geometry");
   const long n = rows * (long)t_in * scale;
   ProfScope prof((hipStream_t)stream, "stretch_conv_fwd_kernel", 2.0 * n * kernel, 4.0 * (rows * (double)t_in + n));
-  LAUNCH1D(stretch_conv_fwd_kernel, n, stream, x, w, y, (long)rows, t_in, scale, kernel);
+  LAUNCH1D(stretch_conv_fwd_kernel, n, stream, x, w, y, (long)rows, t_in, scale, kernel, pad_left);
   return PWG_OK;
 }
 
 extern "C" int pwg_stretch_conv_backward(const float* dy, const float* x, const float* w, float* dx, float* dw,
-                                         int64_t rows, int32_t t_in, int32_t scale, int32_t kernel, void* stream) {
+                                         int64_t rows, int32_t t_in, int32_t scale, int32_t kernel, int32_t pad_left,
+                                         void* stream) {
   PWG_REQUIRE(dy && w && (dx || dw), PWG_ERR_NULL, "stretch_conv_backward: NULL pointer");
-  PWG_REQUIRE(rows > 0 && t_in > 0 && scale > 0 && kernel > 0 && kernel % 2 == 1 && kernel <= 64, PWG_ERR_BAD_SHAPE,
-              "stretch_conv: bad geometry");
+  PWG_REQUIRE(rows > 0 && t_in > 0 && scale > 0 && kernel > 0 && kernel <= 64 && pad_left >= 0 && pad_left < kernel,
+              PWG_ERR_BAD_SHAPE, "stretch_conv: bad geometry");
   if (dx) {
     const long n = rows * (long)t_in;
-    LAUNCH1D(stretch_conv_bwd_data_kernel, n, stream, dy, w, dx, (long)rows, t_in, scale, kernel);
+    LAUNCH1D(stretch_conv_bwd_data_kernel, n, stream, dy, w, dx, (long)rows, t_in, scale, kernel, pad_left);
   }
   if (dw) {
     PWG_REQUIRE(x, PWG_ERR_NULL, "stretch_conv_backward: x needed for dw");
     (void)hipMemsetAsync(dw, 0, sizeof(float) * kernel, (hipStream_t)stream);
     const long n = rows * (long)t_in * scale;
     hipLaunchKernelGGL(stretch_conv_bwd_weight_kernel, dim3(grid_for(n, 256, 512)), dim3(256), 0, (hipStream_t)stream,
-                       dy, x, dw, (long)rows, t_in, scale, kernel);
+                       dy, x, dw, (long)rows, t_in, scale, kernel, pad_left);
     PWG_CHECK_LAUNCH("stretch_conv_bwd_weight");
   }
   return PWG_OK;

@@ -257,10 +257,11 @@ class GateFn(torch.autograd.Function):
 
 
 class StretchConvFn(torch.autograd.Function):
-    """Nearest stretch by ``scale`` along time + (1, 2*scale+1) smoothing conv; x (B, C, T), w (k,)."""
+    """Nearest stretch by ``scale`` along time + (1, 2*scale+1) smoothing conv; x (B, C, T), w (k,).
+    ``pad_left`` = scale (centred, default) or 2*scale (causal)."""
 
     @staticmethod
-    def forward(ctx, x, w, scale):
+    def forward(ctx, x, w, scale, pad_left=None):
         x = _c(x)
         ctx.w_shape = tuple(w.shape)
         w = _c(w.reshape(-1))
@@ -268,10 +269,11 @@ class StretchConvFn(torch.autograd.Function):
         t_in = x.shape[-1]
         rows = x.numel() // t_in
         y = torch.empty(x.shape[:-1] + (t_in * scale,), device=x.device, dtype=torch.float32)
-        _lib.check(_L().pwg_stretch_conv_forward(_ptr(x), _ptr(w), _ptr(y), rows, t_in, scale, w.numel(), _stream()),
-                   "stretch_conv_forward")
+        pad_left = (w.numel() - 1) // 2 if pad_left is None else int(pad_left)
+        _lib.check(_L().pwg_stretch_conv_forward(_ptr(x), _ptr(w), _ptr(y), rows, t_in, scale, w.numel(), pad_left,
+                                                 _stream()), "stretch_conv_forward")
         ctx.save_for_backward(x, w)
-        ctx.scale = scale
+        ctx.scale, ctx.pad_left = scale, pad_left
         return y
 
     @staticmethod
@@ -283,8 +285,8 @@ class StretchConvFn(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
         _lib.check(_L().pwg_stretch_conv_backward(_ptr(dy), _ptr(x), _ptr(w), _ptr(dx), _ptr(dw), rows, t_in, ctx.scale,
-                                                  w.numel(), _stream()), "stretch_conv_backward")
-        return dx, (None if dw is None else dw.reshape(ctx.w_shape)), None
+                                                  w.numel(), ctx.pad_left, _stream()), "stretch_conv_backward")
+        return dx, (None if dw is None else dw.reshape(ctx.w_shape)), None, None
 
 
 # ---------------------------------------------------------------------------------------------

@@ -30,6 +30,11 @@ class _ConvNd(torch.nn.Module):
         if in_channels % groups or out_channels % groups:
             raise ValueError("in_channels and out_channels must be divisible by groups")
         self.in_channels, self.out_channels = in_channels, out_channels
+        # padding: int (both sides) or (left, right) -- causal layers pad on the left only
+        if isinstance(padding, (tuple, list)):
+            padding, self.padding_right = int(padding[0]), int(padding[1])
+        else:
+            self.padding_right = int(padding)
         self.kernel_size, self.stride, self.padding = int(kernel_size), int(stride), int(padding)
         self.dilation, self.groups, self.output_padding = int(dilation), int(groups), int(output_padding)
         self.pad_mode = pad_mode
@@ -187,12 +192,13 @@ class _ConvNd(torch.nn.Module):
         return w.reshape(w.shape[0], w.shape[1], -1).contiguous()
 
     def _probe_len(self):
-        return self.kernel_size * self.dilation + self.stride
+        # any length with at least one output column (packing does not depend on it)
+        return self.kernel_size * self.dilation + self.stride + max(0, -self.padding_right)
 
     def geom(self):
         return dict(kernel=self.kernel_size, stride=self.stride, dilation=self.dilation, padding=self.padding,
-                    groups=self.groups, transposed=self.transposed, output_padding=self.output_padding,
-                    width=1, pad_mode=self.pad_mode)
+                    padding_right=self.padding_right, groups=self.groups, transposed=self.transposed,
+                    output_padding=self.output_padding, width=1, pad_mode=self.pad_mode)
 
     def out_length(self, t_in):
         raise NotImplementedError
@@ -216,11 +222,11 @@ class _ConvNd(torch.nn.Module):
             geom = self.geom()
             if self.width_mode:
                 geom["width"] = x.shape[-1]
-            if self.pad_mode != "zero" and self.padding > 0:
+            if self.pad_mode != "zero" and (self.padding > 0 or self.padding_right > 0):
                 # the backward kernels implement zero padding: pad explicitly (HIP kernel with its own
                 # backward); pad and the element-wise pre-activation commute
-                x = Fn.pad1d(x, self.padding, self.padding, self.pad_mode)
-                geom["padding"], geom["pad_mode"] = 0, "zero"
+                x = Fn.pad1d(x, self.padding, self.padding_right, self.pad_mode)
+                geom["padding"], geom["padding_right"], geom["pad_mode"] = 0, 0, "zero"
             return Fn.FusedConvFn.apply(x, self.weight_tensor(), self.bias, add1, add2, geom, fused, None)
         with torch.no_grad():
             b = x.shape[0]
@@ -248,7 +254,7 @@ class Conv1d(_ConvNd):
     transposed = False
 
     def out_length(self, t_in):
-        return ops.conv_out_length(t_in, self.kernel_size, self.stride, self.dilation, self.padding, self.padding)
+        return ops.conv_out_length(t_in, self.kernel_size, self.stride, self.dilation, self.padding, self.padding_right)
 
     def make_desc(self, batch, t_in, width=1, **fused):
         return ops.make_conv_desc(batch, self.in_channels, self.out_channels, t_in, self.out_length(t_in),

@@ -8,6 +8,9 @@ from .activation import FusedActivation
 from .conv import Conv1d as _Conv1d
 
 
+from .causal_conv import CausalConv1d  # noqa: E402  (depends on .conv only)
+
+
 class Conv1d(_Conv1d):
     """Conv1d with the reference's customised initialisation (kaiming normal for ReLU, zero bias;
     layers/residual_block.py:19-30)."""
@@ -35,13 +38,17 @@ class WaveNetResidualBlock(torch.nn.Module):
     def __init__(self, kernel_size=3, residual_channels=64, gate_channels=128, skip_channels=64, aux_channels=80,
                  dropout=0.0, dilation=1, bias=True, use_causal_conv=False):
         super().__init__()
-        if use_causal_conv:
-            raise NotImplementedError("use_causal_conv=True is outside the accelerated path")
-        assert (kernel_size - 1) % 2 == 0, "Not support even number kernel size."
         self.dropout = dropout
         self.use_causal_conv = use_causal_conv
-        self.conv = Conv1d(residual_channels, gate_channels, kernel_size, padding=(kernel_size - 1) // 2 * dilation,
-                           dilation=dilation, bias=bias)
+        if use_causal_conv:
+            # the reference pads (k-1)*d on both sides and drops the future part of the output
+            # (layers/residual_block.py:74-76,118-119): identical to left-only padding
+            padding = ((kernel_size - 1) * dilation, 0)
+        else:
+            assert (kernel_size - 1) % 2 == 0, "Not support even number kernel size."
+            padding = (kernel_size - 1) // 2 * dilation
+        self.conv = Conv1d(residual_channels, gate_channels, kernel_size, padding=padding, dilation=dilation,
+                           bias=bias)
         self.conv1x1_aux = Conv1d1x1(aux_channels, gate_channels, bias=False) if aux_channels > 0 else None
         gate_out_channels = gate_channels // 2
         self.conv1x1_out = Conv1d1x1(gate_out_channels, residual_channels, bias=bias)
@@ -74,8 +81,6 @@ class HiFiGANResidualBlock(torch.nn.Module):
                  use_causal_conv=False):
         super().__init__()
         assert kernel_size % 2 == 1, "Kernel size must be odd number."
-        if use_causal_conv:
-            raise NotImplementedError("use_causal_conv=True is outside the accelerated path (SURVEY.md s8f-3)")
         self.use_additional_convs = use_additional_convs
         self.use_causal_conv = use_causal_conv
         self.kernel_size = kernel_size
@@ -83,16 +88,19 @@ class HiFiGANResidualBlock(torch.nn.Module):
         self.convs1 = torch.nn.ModuleList()
         if use_additional_convs:
             self.convs2 = torch.nn.ModuleList()
+        def conv(dilation):
+            # causal: left-only padding inside CausalConv1d (layers/residual_block.py:196-241 of the reference)
+            if use_causal_conv:
+                return CausalConv1d(channels, channels, kernel_size, dilation=dilation, bias=bias)
+            return Conv1d(channels, channels, kernel_size, 1, dilation=dilation, bias=bias,
+                          padding=(kernel_size - 1) // 2 * dilation)
+
         for d in self.dilations:
             self.convs1.append(torch.nn.Sequential(
-                FusedActivation(nonlinear_activation, **nonlinear_activation_params),
-                Conv1d(channels, channels, kernel_size, 1, dilation=d, bias=bias, padding=(kernel_size - 1) // 2 * d),
-            ))
+                FusedActivation(nonlinear_activation, **nonlinear_activation_params), conv(d)))
             if use_additional_convs:
                 self.convs2.append(torch.nn.Sequential(
-                    FusedActivation(nonlinear_activation, **nonlinear_activation_params),
-                    Conv1d(channels, channels, kernel_size, 1, dilation=1, bias=bias, padding=(kernel_size - 1) // 2),
-                ))
+                    FusedActivation(nonlinear_activation, **nonlinear_activation_params), conv(1)))
 
     def forward(self, x, accum=None, out_div=1.0):
         """Returns ``(block(x) + accum) / out_div``; accum/out_div let the caller fold the

@@ -2,6 +2,7 @@
 import torch
 
 from .activation import FusedActivation
+from .causal_conv import CausalConv1d
 from .conv import Conv1d
 from .padding import get_pad
 
@@ -15,22 +16,34 @@ class ResidualStack(torch.nn.Module):
                  nonlinear_activation_params={"negative_slope": 0.2}, pad="ReflectionPad1d", pad_params={},
                  use_causal_conv=False):
         super().__init__()
+        self.use_causal_conv = use_causal_conv
         if use_causal_conv:
-            raise NotImplementedError("use_causal_conv=True is outside the accelerated path")
-        assert (kernel_size - 1) % 2 == 0, "Not support even number kernel size."
-        p = (kernel_size - 1) // 2 * dilation
-        padm = get_pad(pad, p, **pad_params)
-        self.stack = torch.nn.Sequential(
-            FusedActivation(nonlinear_activation, **nonlinear_activation_params),
-            padm,
-            Conv1d(channels, channels, kernel_size, dilation=dilation, bias=bias, padding=p, pad_mode=padm.mode),
-            FusedActivation(nonlinear_activation, **nonlinear_activation_params),
-            Conv1d(channels, channels, 1, bias=bias),
-        )
+            # layers/residual_stack.py:56-69 of the reference: no separate pad module, hence 4 entries
+            self.stack = torch.nn.Sequential(
+                FusedActivation(nonlinear_activation, **nonlinear_activation_params),
+                CausalConv1d(channels, channels, kernel_size, dilation=dilation, bias=bias, pad=pad,
+                             pad_params=pad_params),
+                FusedActivation(nonlinear_activation, **nonlinear_activation_params),
+                Conv1d(channels, channels, 1, bias=bias),
+            )
+        else:
+            assert (kernel_size - 1) % 2 == 0, "Not support even number kernel size."
+            p = (kernel_size - 1) // 2 * dilation
+            padm = get_pad(pad, p, **pad_params)
+            self.stack = torch.nn.Sequential(
+                FusedActivation(nonlinear_activation, **nonlinear_activation_params),
+                padm,
+                Conv1d(channels, channels, kernel_size, dilation=dilation, bias=bias, padding=p, pad_mode=padm.mode),
+                FusedActivation(nonlinear_activation, **nonlinear_activation_params),
+                Conv1d(channels, channels, 1, bias=bias),
+            )
         self.skip_layer = Conv1d(channels, channels, 1, bias=bias)
 
     def forward(self, c):
-        a0, conv0, a1, conv1 = self.stack[0], self.stack[2], self.stack[3], self.stack[4]
+        if self.use_causal_conv:
+            a0, conv0, a1, conv1 = self.stack[0], self.stack[1], self.stack[2], self.stack[3]
+        else:
+            a0, conv0, a1, conv1 = self.stack[0], self.stack[2], self.stack[3], self.stack[4]
         skip = self.skip_layer(c)
         t = conv0(c, pre_act=a0.kind, pre_slope=a0.slope)
         return conv1(t, pre_act=a1.kind, pre_slope=a1.slope, add1=skip)

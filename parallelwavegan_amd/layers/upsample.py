@@ -64,18 +64,23 @@ class UpsampleNetwork(torch.nn.Module):
     def __init__(self, upsample_scales, nonlinear_activation=None, nonlinear_activation_params={},
                  interpolate_mode="nearest", freq_axis_kernel_size=1, use_causal_conv=False):
         super().__init__()
-        if nonlinear_activation is not None or freq_axis_kernel_size != 1 or use_causal_conv:
+        if nonlinear_activation is not None or freq_axis_kernel_size != 1:
             raise NotImplementedError("UpsampleNetwork: only the configuration of the shipped YAMLs is accelerated")
         self.use_causal_conv = use_causal_conv
         self.up_layers = torch.nn.ModuleList()
         for scale in upsample_scales:
             self.up_layers.append(Stretch2d(scale, 1, interpolate_mode))
-            self.up_layers.append(Conv2d(1, 1, kernel_size=(1, scale * 2 + 1), padding=(0, scale), bias=False))
+            # causal: padding (0, 2*scale) and the output trimmed to the stretched length
+            # (layers/upsample.py:96-99,121-125) == left-only padding of 2*scale inside the kernel
+            self.up_layers.append(Conv2d(1, 1, kernel_size=(1, scale * 2 + 1),
+                                         padding=(0, scale * 2 if use_causal_conv else scale), bias=False))
 
     def forward(self, c):
         """c: (B, C, T) -> (B, C, T * prod(upsample_scales))."""
         for i in range(0, len(self.up_layers), 2):
-            c = Fn.StretchConvFn.apply(c, self.up_layers[i + 1].weight_tensor(), self.up_layers[i].x_scale)
+            scale = self.up_layers[i].x_scale
+            c = Fn.StretchConvFn.apply(c, self.up_layers[i + 1].weight_tensor(), scale,
+                                       2 * scale if self.use_causal_conv else scale)
         return c
 
 
@@ -86,11 +91,13 @@ class ConvInUpsampleNetwork(torch.nn.Module):
                  interpolate_mode="nearest", freq_axis_kernel_size=1, aux_channels=80, aux_context_window=0,
                  use_causal_conv=False):
         super().__init__()
-        if use_causal_conv:
-            raise NotImplementedError("use_causal_conv=True is outside the accelerated path")
         self.aux_context_window = aux_context_window
-        self.use_causal_conv = False
-        self.conv_in = Conv1d(aux_channels, aux_channels, kernel_size=2 * aux_context_window + 1, bias=False)
+        self.use_causal_conv = use_causal_conv and aux_context_window > 0
+        # causal: kernel aux_context_window + 1 and the last aux_context_window outputs dropped
+        # (layers/upsample.py:160-164,192-193): a negative right "padding" makes the kernel stop there
+        kernel_size = aux_context_window + 1 if use_causal_conv else 2 * aux_context_window + 1
+        self.conv_in = Conv1d(aux_channels, aux_channels, kernel_size=kernel_size, bias=False,
+                              padding=(0, -aux_context_window) if self.use_causal_conv else 0)
         self.upsample = UpsampleNetwork(upsample_scales=upsample_scales, nonlinear_activation=nonlinear_activation,
                                         nonlinear_activation_params=nonlinear_activation_params,
                                         interpolate_mode=interpolate_mode, freq_axis_kernel_size=freq_axis_kernel_size,

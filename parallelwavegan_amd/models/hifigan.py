@@ -12,6 +12,7 @@ import torch
 
 from .. import functional as Fn
 from ..layers.activation import FusedActivation
+from ..layers.causal_conv import CausalConv1d, CausalConvTranspose1d
 from ..layers.conv import Conv1d, Conv2d, ConvTranspose1d
 from ..layers.pooling import get_pooling
 from ..streams import run_branches
@@ -45,13 +46,14 @@ class HiFiGANGenerator(torch.nn.Module):
         assert kernel_size % 2 == 1, "Kernel size must be odd number."
         assert len(upsample_scales) == len(upsample_kernel_sizes)
         assert len(resblock_dilations) == len(resblock_kernel_sizes)
-        if use_causal_conv:
-            raise NotImplementedError("use_causal_conv=True is outside the accelerated path (SURVEY.md s8f-3)")
         self.num_upsamples = len(upsample_kernel_sizes)
         self.num_blocks = len(resblock_kernel_sizes)
         self.use_causal_conv = use_causal_conv
         self.upsample_factor = int(np.prod(upsample_scales))
-        self.input_conv = Conv1d(in_channels, channels, kernel_size, bias=bias, padding=(kernel_size - 1) // 2)
+        if use_causal_conv:  # models/hifigan.py:82-88,115-123,156-162 of the reference
+            self.input_conv = CausalConv1d(in_channels, channels, kernel_size, bias=bias)
+        else:
+            self.input_conv = Conv1d(in_channels, channels, kernel_size, bias=bias, padding=(kernel_size - 1) // 2)
         self.upsamples = torch.nn.ModuleList()
         self.blocks = torch.nn.ModuleList()
         ch = channels
@@ -59,6 +61,7 @@ class HiFiGANGenerator(torch.nn.Module):
             assert k == 2 * s
             self.upsamples.append(torch.nn.Sequential(
                 FusedActivation(nonlinear_activation, **nonlinear_activation_params),
+                CausalConvTranspose1d(ch, ch // 2, k, s, bias=bias) if use_causal_conv else
                 ConvTranspose1d(ch, ch // 2, k, s, padding=s // 2 + s % 2, output_padding=s % 2, bias=bias),
             ))
             ch //= 2
@@ -71,6 +74,7 @@ class HiFiGANGenerator(torch.nn.Module):
         # (models/hifigan.py:139-151), not nonlinear_activation_params
         self.output_conv = torch.nn.Sequential(
             FusedActivation("LeakyReLU"),
+            CausalConv1d(ch, out_channels, kernel_size, bias=bias) if use_causal_conv else
             Conv1d(ch, out_channels, kernel_size, bias=bias, padding=(kernel_size - 1) // 2),
             torch.nn.Identity(),  # index 2 is the (fused) Tanh in the reference
         )

@@ -6,6 +6,7 @@ import numpy as np
 import torch
 
 from ..layers.activation import FusedActivation
+from ..layers.causal_conv import CausalConv1d, CausalConvTranspose1d
 from ..layers.conv import Conv1d, ConvTranspose1d
 from ..layers.padding import FusedPad, get_pad
 from ..layers.pooling import get_pooling
@@ -45,18 +46,24 @@ class MelGANGenerator(torch.nn.Module, _MelGANNormMixin):
                  nonlinear_activation_params={"negative_slope": 0.2}, pad="ReflectionPad1d", pad_params={},
                  use_final_nonlinear_activation=True, use_weight_norm=True, use_causal_conv=False):
         super().__init__()
-        if use_causal_conv:
-            raise NotImplementedError("use_causal_conv=True is outside the accelerated path (SURVEY.md s8f-3)")
         assert channels >= np.prod(upsample_scales)
         assert channels % (2 ** len(upsample_scales)) == 0
-        assert (kernel_size - 1) % 2 == 0, "Not support even number kernel size."
+        if not use_causal_conv:
+            assert (kernel_size - 1) % 2 == 0, "Not support even number kernel size."
         p = (kernel_size - 1) // 2
-        pad0 = get_pad(pad, p, **pad_params)
-        layers = [pad0, Conv1d(in_channels, channels, kernel_size, bias=bias, padding=p, pad_mode=pad0.mode)]
+        if use_causal_conv:  # models/melgan.py:75-84 of the reference: one module, pad inside
+            layers = [CausalConv1d(in_channels, channels, kernel_size, bias=bias, pad=pad, pad_params=pad_params)]
+        else:
+            pad0 = get_pad(pad, p, **pad_params)
+            layers = [pad0, Conv1d(in_channels, channels, kernel_size, bias=bias, padding=p, pad_mode=pad0.mode)]
         for i, s in enumerate(upsample_scales):
             layers.append(FusedActivation(nonlinear_activation, **nonlinear_activation_params))
-            layers.append(ConvTranspose1d(channels // (2 ** i), channels // (2 ** (i + 1)), s * 2, stride=s,
-                                          padding=s // 2 + s % 2, output_padding=s % 2, bias=bias))
+            if use_causal_conv:
+                layers.append(CausalConvTranspose1d(channels // (2 ** i), channels // (2 ** (i + 1)), s * 2, stride=s,
+                                                    bias=bias))
+            else:
+                layers.append(ConvTranspose1d(channels // (2 ** i), channels // (2 ** (i + 1)), s * 2, stride=s,
+                                              padding=s // 2 + s % 2, output_padding=s % 2, bias=bias))
             for j in range(stacks):
                 layers.append(ResidualStack(kernel_size=stack_kernel_size, channels=channels // (2 ** (i + 1)),
                                             dilation=stack_kernel_size ** j, bias=bias,
@@ -64,9 +71,13 @@ class MelGANGenerator(torch.nn.Module, _MelGANNormMixin):
                                             nonlinear_activation_params=nonlinear_activation_params, pad=pad,
                                             pad_params=pad_params, use_causal_conv=use_causal_conv))
         layers.append(FusedActivation(nonlinear_activation, **nonlinear_activation_params))
-        pad1 = get_pad(pad, p, **pad_params)
-        layers += [pad1, Conv1d(channels // (2 ** (i + 1)), out_channels, kernel_size, bias=bias, padding=p,
-                                pad_mode=pad1.mode)]
+        if use_causal_conv:
+            layers.append(CausalConv1d(channels // (2 ** (i + 1)), out_channels, kernel_size, bias=bias, pad=pad,
+                                       pad_params=pad_params))
+        else:
+            pad1 = get_pad(pad, p, **pad_params)
+            layers += [pad1, Conv1d(channels // (2 ** (i + 1)), out_channels, kernel_size, bias=bias, padding=p,
+                                    pad_mode=pad1.mode)]
         self.use_final_nonlinear_activation = use_final_nonlinear_activation
         if use_final_nonlinear_activation:
             layers.append(torch.nn.Identity())  # the (fused) Tanh of the reference
@@ -82,7 +93,7 @@ class MelGANGenerator(torch.nn.Module, _MelGANNormMixin):
         mods = list(self.melgan)
         x = c
         act = None
-        last_conv = max(i for i, m in enumerate(mods) if isinstance(m, Conv1d))
+        last_conv = max(i for i, m in enumerate(mods) if isinstance(m, (Conv1d, CausalConv1d)))
         for i, m in enumerate(mods):
             if isinstance(m, FusedActivation):
                 act = m

@@ -41,8 +41,6 @@ class ParallelWaveGANGenerator(torch.nn.Module, _WeightNormMixin):
                  use_weight_norm=True, use_causal_conv=False, upsample_conditional_features=True,
                  upsample_net="ConvInUpsampleNetwork", upsample_params={"upsample_scales": [4, 4, 4, 4]}):
         super().__init__()
-        if use_causal_conv:
-            raise NotImplementedError("use_causal_conv=True is outside the accelerated path (SURVEY.md s8f-3)")
         self.in_channels, self.out_channels = in_channels, out_channels
         self.aux_channels, self.aux_context_window = aux_channels, aux_context_window
         self.layers, self.stacks, self.kernel_size = layers, stacks, kernel_size
@@ -167,3 +165,49 @@ class ParallelWaveGANDiscriminator(torch.nn.Module, _WeightNormMixin):
                 x = conv(x)
                 i += 1
         return x
+
+
+class ResidualParallelWaveGANDiscriminator(torch.nn.Module, _WeightNormMixin):
+    """WaveNet-style discriminator (reference: models/parallel_wavegan.py:374-513): 1x1 conv +
+    LeakyReLU, ``layers`` gated residual blocks without conditioning, skip sum * sqrt(1/layers),
+    LeakyReLU, 1x1, LeakyReLU, 1x1.  Activations, the running skip sum and its scale ride on the
+    convolution kernels' epilogues exactly as in the generator."""
+
+    def __init__(self, in_channels=1, out_channels=1, kernel_size=3, layers=30, stacks=3, residual_channels=64,
+                 gate_channels=128, skip_channels=64, dropout=0.0, bias=True, use_weight_norm=True,
+                 use_causal_conv=False, nonlinear_activation="LeakyReLU",
+                 nonlinear_activation_params={"negative_slope": 0.2}):
+        super().__init__()
+        assert (kernel_size - 1) % 2 == 0, "Not support even number kernel size."
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.layers, self.stacks, self.kernel_size = layers, stacks, kernel_size
+        assert layers % stacks == 0
+        layers_per_stack = layers // stacks
+
+        def act():
+            return FusedActivation(nonlinear_activation, **nonlinear_activation_params)
+
+        self.first_conv = torch.nn.Sequential(Conv1d1x1(in_channels, residual_channels, bias=True), act())
+        self.conv_layers = torch.nn.ModuleList()
+        for layer in range(layers):
+            self.conv_layers.append(ResidualBlock(
+                kernel_size=kernel_size, residual_channels=residual_channels, gate_channels=gate_channels,
+                skip_channels=skip_channels, aux_channels=-1, dilation=2 ** (layer % layers_per_stack),
+                dropout=dropout, bias=bias, use_causal_conv=use_causal_conv))
+        self.last_conv_layers = torch.nn.ModuleList([
+            act(), Conv1d1x1(skip_channels, skip_channels, bias=True), act(),
+            Conv1d1x1(skip_channels, out_channels, bias=True)])
+        if use_weight_norm:
+            self.apply_weight_norm()
+
+    def forward(self, x):
+        """(B, 1, T) -> (B, 1, T)."""
+        a0 = self.first_conv[1]
+        x = self.first_conv[0](x, post_act=a0.kind, post_slope=a0.slope)
+        skips = None
+        n = len(self.conv_layers)
+        for i, f in enumerate(self.conv_layers):
+            x, skips = f(x, None, skips=skips, skip_scale=math.sqrt(1.0 / n) if i == n - 1 else 1.0)
+        a1, c1, a2, c2 = self.last_conv_layers
+        x = c1(skips, pre_act=a1.kind, pre_slope=a1.slope)
+        return c2(x, pre_act=a2.kind, pre_slope=a2.slope)

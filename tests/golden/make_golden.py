@@ -350,7 +350,33 @@ def mb_melgan_train_steps(name, seed, n_steps=2):
     print(name, {k: round(float(v), 6) for k, v in out.items() if k.startswith("step")})
 
 
+def causal_variants(name, seed):
+    """Forward outputs of the use_causal_conv=True generators and of the residual PWG discriminator."""
+    import parallel_wavegan.models as RM
+
+    out = {}
+    with torch.no_grad():
+        g = RM.HiFiGANGenerator(**synth.HIFIGAN_CAUSAL).eval()
+        g.load_state_dict(synth.synth_state_dict(g.state_dict(), seed=seed, g_scale=G_SCALE))
+        out["hifigan"] = g(synth.synth_input("c", (2, 80, 24), seed=seed)).numpy()
+        m = RM.MelGANGenerator(**synth.MELGAN_CAUSAL).eval()
+        m.load_state_dict(synth.synth_state_dict(m.state_dict(), seed=seed + 1, g_scale=synth.MELGAN_G_SCALE))
+        out["melgan"] = m(synth.synth_input("c", (2, 80, 20), seed=seed + 1)).numpy()
+        p = RM.ParallelWaveGANGenerator(**synth.PWG_CAUSAL).eval()
+        p.load_state_dict(synth.synth_state_dict(p.state_dict(), seed=seed + 2, g_scale=1.0))
+        z = synth.synth_input("z", (2, 1, 18 * 16), seed=seed + 2)
+        c = synth.synth_input("c", (2, 80, 18 + 4), seed=seed + 2)
+        out["pwg"] = p(z, c).numpy()
+        for key, causal in (("res_d", False), ("res_d_causal", True)):
+            d = RM.ResidualParallelWaveGANDiscriminator(use_causal_conv=causal, **synth.RESIDUAL_PWG_D).eval()
+            d.load_state_dict(synth.synth_state_dict(d.state_dict(), seed=seed + 3, g_scale=1.0))
+            out[key] = d(0.5 * synth.synth_input("wave", (2, 1, 700), seed=seed + 3)).numpy()
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), meta=np.array([seed]), g_scale=np.float64(G_SCALE), **out)
+    print(name, {k: (v.shape, float(np.abs(v).max())) for k, v in out.items()})
+
+
 JOBS = {
+    "causal_variants": lambda: causal_variants("causal_variants", 91),
     "hifigan_v1_g": lambda: hifigan_generator("hifigan_v1_g", synth.HIFIGAN_V1, 2, 32, 11),
     "hifigan_v1_libritts_g": lambda: hifigan_generator("hifigan_v1_libritts_g", synth.HIFIGAN_V1_LIBRITTS, 1, 28, 12),
     "hifigan_tiny_g": lambda: hifigan_generator("hifigan_tiny_g", synth.HIFIGAN_TINY, 3, 21, 13),

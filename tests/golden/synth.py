@@ -112,3 +112,14 @@ HIFIGAN_TINY = dict(
     resblock_kernel_sizes=[3, 5],
     resblock_dilations=[[1, 3], [1, 2]],
 )
+
+
+# ---- causal variants / residual PWG discriminator: small configurations
+HIFIGAN_CAUSAL = dict(in_channels=80, out_channels=1, channels=64, kernel_size=7, upsample_scales=(4, 2, 2),
+                      upsample_kernel_sizes=(8, 4, 4), resblock_kernel_sizes=(3, 7),
+                      resblock_dilations=[(1, 3, 5), (1, 3)], use_additional_convs=True, use_causal_conv=True)
+MELGAN_CAUSAL = dict(in_channels=80, out_channels=1, kernel_size=7, channels=64, upsample_scales=[4, 2, 2],
+                     stack_kernel_size=3, stacks=2, use_causal_conv=True)
+PWG_CAUSAL = dict(layers=6, stacks=2, aux_context_window=2, use_causal_conv=True,
+                  upsample_params={"upsample_scales": [4, 4]})
+RESIDUAL_PWG_D = dict(layers=6, stacks=2, residual_channels=32, gate_channels=64, skip_channels=32)

@@ -106,9 +106,8 @@ def test_pwg_generator_variants(over, device):
 
 
 def test_unsupported_options_fail_loudly():
-    with pytest.raises(NotImplementedError):
-        models.HiFiGANGenerator(use_causal_conv=True)
-    with pytest.raises(NotImplementedError):
-        models.MelGANGenerator(use_causal_conv=True)
+    # (use_causal_conv=True is supported since the causal layers landed: tests/test_causal_gpu.py)
     with pytest.raises(NotImplementedError):
         models.HiFiGANGenerator(nonlinear_activation="GELU", nonlinear_activation_params={})
+    with pytest.raises(NotImplementedError):
+        models.ParallelWaveGANGenerator(upsample_net="MelGANGenerator")
