@@ -220,6 +220,15 @@ int pwg_stretch_conv_backward(const float* dy, const float* x, const float* w, f
                               int64_t rows, int32_t t_in, int32_t scale, int32_t kernel, int32_t pad_left,
                               void* stream);
 
+/* ---- inference I/O helpers (around bin/decode.py:214-243) ---- */
+/* pcm[i] = (int16) rint(clamp(x[i], -1, 1) * 32767): the PCM_16 conversion of the synthesised wave. */
+int pwg_wave_to_pcm16(const float* x, int16_t* pcm, int64_t n, void* stream);
+/* y (batch, channels, frames) = (x (batch, frames, channels) - mean[c]) / scale[c]: the
+ * `normalize_before` step of `inference` (models/hifigan.py:262-266) fused with its transpose;
+ * mean/scale may both be NULL (transpose only).                                       */
+int pwg_normalize_transpose(const float* x, const float* mean, const float* scale, float* y,
+                            int32_t batch, int32_t frames, int32_t channels, void* stream);
+
 /* ------------------------------------------------------------------------- */
 /* Pooling / explicit padding                                                  */
 /* ------------------------------------------------------------------------- */

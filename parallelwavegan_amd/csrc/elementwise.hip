@@ -416,6 +416,30 @@ __global__ void add3_div_kernel(const float* a, const float* b, const float* c, 
   }
 }
 
+// pcm[i] = (int16) rint(clamp(x[i], -1, 1) * 32767)   (the PCM_16 write of bin/decode.py:235-243)
+__global__ void wave_to_pcm16_kernel(const float* x, short* pcm, long n) {
+  GRID_STRIDE(i, n) {
+    const float v = fminf(fmaxf(x[i], -1.f), 1.f) * 32767.f;
+    pcm[i] = (short)__float2int_rn(v);
+  }
+}
+
+// y[b][c][t] = (x[b][t][c] - mean[c]) / scale[c]: feature normalisation fused with the (T', C) -> (C, T')
+// transpose that `inference` performs (models/hifigan.py:262-266; bin/normalize.py:238-270)
+__global__ void normalize_transpose_kernel(const float* x, const float* mean, const float* scale, float* y, int batch,
+                                           int frames, int channels) {
+  const long n = (long)batch * frames * channels;
+  GRID_STRIDE(i, n) {
+    const int t = (int)(i % frames);
+    const long r = i / frames;
+    const int c = (int)(r % channels);
+    const long b = r / channels;
+    float v = x[(b * frames + t) * channels + c];
+    if (mean) v = (v - mean[c]) / scale[c];
+    y[i] = v;
+  }
+}
+
 }  // namespace pwg
 
 using namespace pwg;
@@ -642,5 +666,23 @@ extern "C" int pwg_add3_div(const float* a, const float* b, const float* c, floa
   PWG_REQUIRE(n > 0 && div != 0.f, PWG_ERR_BAD_SHAPE, "add3_div: bad arguments");
   ProfScope prof((hipStream_t)stream, "add3_div_kernel", 0, 16.0 * n);
   LAUNCH1D(add3_div_kernel, n, stream, a, b, c, y, (long)n, div);
+  return PWG_OK;
+}
+
+extern "C" int pwg_wave_to_pcm16(const float* x, int16_t* pcm, int64_t n, void* stream) {
+  PWG_REQUIRE(x && pcm, PWG_ERR_NULL, "wave_to_pcm16: NULL pointer");
+  PWG_REQUIRE(n > 0, PWG_ERR_BAD_SHAPE, "wave_to_pcm16: empty");
+  ProfScope prof((hipStream_t)stream, "wave_to_pcm16_kernel", 0, 6.0 * n);
+  LAUNCH1D(wave_to_pcm16_kernel, n, stream, x, (short*)pcm, (long)n);
+  return PWG_OK;
+}
+
+extern "C" int pwg_normalize_transpose(const float* x, const float* mean, const float* scale, float* y,
+                                       int32_t batch, int32_t frames, int32_t channels, void* stream) {
+  PWG_REQUIRE(x && y && ((mean == nullptr) == (scale == nullptr)), PWG_ERR_NULL, "normalize_transpose: NULL pointer");
+  PWG_REQUIRE(batch > 0 && frames > 0 && channels > 0, PWG_ERR_BAD_SHAPE, "normalize_transpose: bad shape");
+  const long n = (long)batch * frames * channels;
+  ProfScope prof((hipStream_t)stream, "normalize_transpose_kernel", 0, 8.0 * n);
+  LAUNCH1D(normalize_transpose_kernel, n, stream, x, mean, scale, y, batch, frames, channels);
   return PWG_OK;
 }
