@@ -220,6 +220,18 @@ int pwg_stretch_conv_backward(const float* dy, const float* x, const float* w, f
                               int64_t rows, int32_t t_in, int32_t scale, int32_t kernel, int32_t pad_left,
                               void* stream);
 
+/* ---- training input assembly (bin/train.py:646-896 Collater, mel -> waveform branch) ---- */
+/* Random-crop batch from a device-resident corpus: audio / mel are the utterances concatenated
+ * (mel row-major (frames, channels)), *_off their start offsets (elements / frames), audio_len the
+ * waveform lengths.  For item b of utterance utt[b] and start frame start[b]:
+ *   y (batch, 1, steps)                 = audio[start*hop : start*hop + steps]   (edge-padded)
+ *   c (batch, channels, frames_ctx)     = mel[start - acw : start - acw + frames_ctx]^T
+ * with frames_ctx = steps/hop + 2*acw.  The start frames are drawn by the caller.     */
+int pwg_gather_crop(const float* audio, const int64_t* audio_off, const int64_t* audio_len, const float* mel,
+                    const int64_t* mel_off, const int32_t* utt, const int32_t* start, float* y, float* c,
+                    int32_t batch, int32_t steps, int32_t hop, int32_t frames_ctx, int32_t acw,
+                    int32_t channels, void* stream);
+
 /* ---- inference I/O helpers (around bin/decode.py:214-243) ---- */
 /* pcm[i] = (int16) rint(clamp(x[i], -1, 1) * 32767): the PCM_16 conversion of the synthesised wave. */
 int pwg_wave_to_pcm16(const float* x, int16_t* pcm, int64_t n, void* stream);

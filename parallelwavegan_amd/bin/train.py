@@ -487,3 +487,75 @@ class Collater(object):
             y = y.pin_memory()
             inputs = tuple(t.pin_memory() for t in inputs)
         return inputs, y
+
+
+class DeviceCollater(object):
+    """Collater whose corpus lives in HBM: the ``(audio[T], mel[T', C])`` pairs are
+    uploaded once (288 GB per GPU hold thousands of hours of 22 kHz audio + mels), and a batch is ONE
+    HIP gather launch (``pwg_gather_crop``) instead of numpy crops, ``np.stack``, ``torch.tensor`` and
+    a pinned host-to-device copy per step (the reference's ``Collater`` + DataLoader path,
+    bin/train.py:646-896,1125-1142).  Same crop rule and the same ``np.random.randint`` draw per item
+    as :class:`Collater`, so with the same numpy seed both produce identical batches.
+
+    ``collater(indices)`` takes utterance indices (what a sampler yields) and returns
+    ``((z,) c), y`` on the device.
+    """
+
+    def __init__(self, pairs, device, batch_max_steps=20480, hop_size=256, aux_context_window=2,
+                 use_noise_input=False):
+        import numpy as np
+
+        self._np = np
+        if batch_max_steps % hop_size != 0:
+            batch_max_steps -= batch_max_steps % hop_size
+        self.hop_size, self.batch_max_steps = hop_size, batch_max_steps
+        self.batch_max_frames = batch_max_steps // hop_size
+        self.aux_context_window = aux_context_window
+        self.use_noise_input = use_noise_input
+        self.start_offset = aux_context_window
+        self.end_offset = -(self.batch_max_frames + aux_context_window)
+        self.mel_threshold = self.batch_max_frames + 2 * aux_context_window
+        self.device = torch.device(device)
+        audio_len = np.array([len(a) for a, _ in pairs], dtype=np.int64)
+        self.mel_len = np.array([len(m) for _, m in pairs], dtype=np.int64)
+        self.channels = int(pairs[0][1].shape[1])
+        for (a, m) in pairs:
+            # Collater._adjust_length: audio may be shorter than frames * hop (edge-padded), never longer
+            assert len(a) <= len(m) * hop_size, (len(a), len(m), hop_size)
+        audio_off = np.concatenate([[0], np.cumsum(audio_len)[:-1]])
+        mel_off = np.concatenate([[0], np.cumsum(self.mel_len)[:-1]])
+        dev = self.device
+        self.audio = torch.from_numpy(np.concatenate([np.asarray(a, dtype=np.float32) for a, _ in pairs])).to(dev)
+        self.mel = torch.from_numpy(np.concatenate([np.asarray(m, dtype=np.float32) for _, m in pairs])).to(dev)
+        self.audio_off = torch.from_numpy(audio_off.astype(np.int64)).to(dev)
+        self.audio_len = torch.from_numpy(audio_len).to(dev)
+        self.mel_off = torch.from_numpy(mel_off.astype(np.int64)).to(dev)
+
+    def __len__(self):
+        return len(self.mel_len)
+
+    def __call__(self, indices):
+        import ctypes
+
+        from .. import _lib
+        from ..ops import _ptr, _stream
+
+        np = self._np
+        keep = [int(i) for i in indices if self.mel_len[int(i)] > self.mel_threshold]
+        starts = [np.random.randint(self.start_offset, self.mel_len[i] + self.end_offset) for i in keep]
+        b = len(keep)
+        # the two small index vectors are the only host -> device traffic of a batch
+        utt = torch.tensor(keep, dtype=torch.int32).to(self.device, non_blocking=True)
+        start = torch.tensor(starts, dtype=torch.int32).to(self.device, non_blocking=True)
+        frames_ctx = self.batch_max_frames + 2 * self.aux_context_window
+        y = torch.empty((b, 1, self.batch_max_steps), device=self.device, dtype=torch.float32)
+        c = torch.empty((b, self.channels, frames_ctx), device=self.device, dtype=torch.float32)
+        _lib.check(_lib.lib().pwg_gather_crop(
+            _ptr(self.audio), ctypes.c_void_p(self.audio_off.data_ptr()), ctypes.c_void_p(self.audio_len.data_ptr()),
+            _ptr(self.mel), ctypes.c_void_p(self.mel_off.data_ptr()), ctypes.c_void_p(utt.data_ptr()),
+            ctypes.c_void_p(start.data_ptr()), _ptr(y), _ptr(c), b, self.batch_max_steps, self.hop_size, frames_ctx,
+            self.aux_context_window, self.channels, _stream()), "gather_crop")
+        inputs = (c,)
+        if self.use_noise_input:
+            inputs = (torch.randn(y.size(), device=self.device),) + inputs
+        return inputs, y

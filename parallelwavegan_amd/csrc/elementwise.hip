@@ -440,6 +440,33 @@ __global__ void normalize_transpose_kernel(const float* x, const float* mean, co
   }
 }
 
+// Random-crop batch assembly from a device-resident corpus (the Collater of bin/train.py:646-896
+// without the host round trip):
+//   y[b][0][i]  = audio[audio_off[utt[b]] + min(start[b]*hop + i, audio_len[utt[b]] - 1)]   (edge pad,
+//                 as Collater._adjust_length pads a short waveform)
+//   c[b][ch][f] = mel[(mel_off[utt[b]] + start[b] - acw + f) * channels + ch]                 (transpose)
+__global__ void gather_crop_kernel(const float* audio, const long* audio_off, const long* audio_len, const float* mel,
+                                   const long* mel_off, const int* utt, const int* start, float* y, float* c,
+                                   int batch, int steps, int hop, int frames_ctx, int acw, int channels) {
+  const long ny = (long)batch * steps;
+  const long nc = (long)batch * channels * frames_ctx;
+  GRID_STRIDE(i, ny + nc) {
+    if (i < ny) {
+      const int b = (int)(i / steps);
+      const long k = (long)start[b] * hop + (i - (long)b * steps);
+      const int u = utt[b];
+      y[i] = audio[audio_off[u] + (k < audio_len[u] ? k : audio_len[u] - 1)];
+    } else {
+      const long j = i - ny;
+      const int f = (int)(j % frames_ctx);
+      const long r = j / frames_ctx;
+      const int ch = (int)(r % channels);
+      const int b = (int)(r / channels);
+      c[j] = mel[(mel_off[utt[b]] + start[b] - acw + f) * channels + ch];
+    }
+  }
+}
+
 }  // namespace pwg
 
 using namespace pwg;
@@ -684,5 +711,20 @@ extern "C" int pwg_normalize_transpose(const float* x, const float* mean, const 
   const long n = (long)batch * frames * channels;
   ProfScope prof((hipStream_t)stream, "normalize_transpose_kernel", 0, 8.0 * n);
   LAUNCH1D(normalize_transpose_kernel, n, stream, x, mean, scale, y, batch, frames, channels);
+  return PWG_OK;
+}
+
+extern "C" int pwg_gather_crop(const float* audio, const int64_t* audio_off, const int64_t* audio_len, const float* mel,
+                               const int64_t* mel_off, const int32_t* utt, const int32_t* start, float* y, float* c,
+                               int32_t batch, int32_t steps, int32_t hop, int32_t frames_ctx, int32_t acw,
+                               int32_t channels, void* stream) {
+  PWG_REQUIRE(audio && audio_off && audio_len && mel && mel_off && utt && start && y && c, PWG_ERR_NULL,
+              "gather_crop: NULL pointer");
+  PWG_REQUIRE(batch > 0 && steps > 0 && hop > 0 && frames_ctx > 0 && acw >= 0 && channels > 0, PWG_ERR_BAD_SHAPE,
+              "gather_crop: bad shape");
+  const long n = (long)batch * steps + (long)batch * channels * frames_ctx;
+  ProfScope prof((hipStream_t)stream, "gather_crop_kernel", 0, 8.0 * n);
+  LAUNCH1D(gather_crop_kernel, n, stream, audio, (const long*)audio_off, (const long*)audio_len, mel,
+           (const long*)mel_off, utt, start, y, c, batch, steps, hop, frames_ctx, acw, channels);
   return PWG_OK;
 }
