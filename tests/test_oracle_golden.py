@@ -76,3 +76,24 @@ def test_causal_variants_oracle_matches_reference_golden():
                            seed + 3, 1.0)
             y = torch_cpu.residual_pwg_discriminator(sd, x, use_causal_conv=causal, **synth.RESIDUAL_PWG_D)
             assert max_abs(y, gold[key]) < 1e-5, key
+
+
+def test_logmel_numpy_oracle_matches_torch_stft_formulation():
+    """oracle/logmel_numpy.py (restated librosa STFT + mel) vs the torch.stft formulation of the
+    reference's MelSpectrogram (losses/mel_loss.py:81-110), which the reference's own test_mel_loss.py
+    asserts equal to logmelfilterbank."""
+    import numpy as np
+
+    from oracle import logmel_numpy, slaney_mel
+
+    rng = np.random.RandomState(0)
+    audio = (0.3 * rng.randn(12000)).astype(np.float32)
+    for fft_size, hop, win, fmin, fmax in ((1024, 256, None, 80, 7600), (2048, 300, 1200, None, None)):
+        got = logmel_numpy.logmelfilterbank(audio, 22050, fft_size, hop, win, "hann", 80, fmin, fmax)
+        wl = fft_size if win is None else win
+        spec = torch.stft(torch.from_numpy(audio).double(), fft_size, hop, wl, torch.hann_window(wl, dtype=torch.float64),
+                          center=True, pad_mode="reflect", return_complex=True).abs().T.numpy()
+        basis = slaney_mel.mel(22050, fft_size, 80, 0 if fmin is None else fmin, 11025 if fmax is None else fmax)
+        want = np.log10(np.maximum(1e-10, spec @ basis.astype(np.float64).T))
+        assert got.shape == want.shape == (1 + len(audio) // hop, 80)
+        assert np.abs(got - want).max() < 1e-8
