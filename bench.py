@@ -207,10 +207,12 @@ def bench_train(args, dev, rank, world, dist):
     tr._flush_pending()
     finite = all(v == v and abs(v) != float("inf") for v in tr.total_train_loss.values())
     out = None
+    # one more (eager) step with per-kernel event timing; every rank runs it -- a data-parallel step
+    # contains collectives -- but only rank 0 reports
+    tr.config["use_hip_graph"] = False
+    with ops.profile() as prof:
+        tr._train_step(batch)
     if rank == 0:
-        tr.config["use_hip_graph"] = False  # per-kernel event timing needs eager launches
-        with ops.profile() as prof:
-            tr._train_step(batch)
         tot_ms = sum(v["ms"] for v in prof.results.values())
         kern = {k: {"ms_per_step": round(v["ms"], 3), "launches": v["launches"],
                     "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
@@ -266,9 +268,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
+        # "nccl" is RCCL on ROCm; PWG_DIST_BACKEND=gloo lets two ranks share one GPU for smoke tests
+        dist.init_process_group(os.environ.get("PWG_DIST_BACKEND", "nccl"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
 
     from parallelwavegan_amd import ops
