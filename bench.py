@@ -210,6 +210,10 @@ def bench_train(args, dev, rank, world, dist):
     # one more (eager) step with per-kernel event timing; every rank runs it -- a data-parallel step
     # contains collectives -- but only rank 0 reports
     tr.config["use_hip_graph"] = False
+    for m in model.values():  # serial launches: concurrent branches would inflate each kernel's event time
+        for sub in m.modules():
+            if hasattr(sub, "branch_streams"):
+                sub.branch_streams = False
     with ops.profile() as prof:
         tr._train_step(batch)
     if rank == 0:
