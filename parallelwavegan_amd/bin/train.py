@@ -209,6 +209,11 @@ class Trainer(object):
             self._flush_pending()
             graph = torch.cuda.CUDAGraph()
             self._capturing = True
+            # every cached weight image is dropped so that all weight-preparation kernels of the step
+            # are recorded inside the graph, in order, and re-run at each replay
+            from ..ops import bump_param_epoch
+
+            bump_param_epoch()
             try:
                 with torch.cuda.graph(graph):
                     self._device_step(static_x, static_y)

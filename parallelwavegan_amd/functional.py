@@ -80,16 +80,36 @@ class SpectralNormFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------
 # fused convolution
 # ---------------------------------------------------------------------------------------------
+class PreparedWeights:
+    """Kernel-side images of one layer's weight for the current parameter values: the weight-norm row
+    scale, the packed forward image and (built on first use) the packed data-gradient image.  A layer
+    keeps one instance per parameter epoch, so every forward / backward of that epoch -- e.g. D(y) and
+    D(G(c)) of a discriminator phase -- shares a single scale + pack + pack launch sequence."""
+
+    __slots__ = ("key", "w", "scale", "fwd", "_bwd")
+
+    def __init__(self, key, w, scale, fwd):
+        self.key, self.w, self.scale, self.fwd, self._bwd = key, w, scale, fwd, None
+
+    def bwd(self, desc):
+        if self._bwd is None:
+            with torch.no_grad():
+                self._bwd = ops.pack_weight_bwd(desc, self.w, self.scale)
+        return self._bwd
+
+
 class FusedConvFn(torch.autograd.Function):
     """y = post_act((conv(pre_act(x), w) + bias + add1 + add2) * out_mul / out_div).
 
     ``geom`` = dict(kernel, stride, dilation, padding, groups, transposed, output_padding, width,
     pad_mode); ``fused`` = dict(pre_act, pre_slope, post_act, post_slope, out_mul, out_div).
-    ``packed`` optionally carries a cached forward weight image (inference).
+    ``packed``: None (pack here), a packed forward image, or a :class:`PreparedWeights`.
+    ``g``: when given, ``w`` is the weight-norm direction ``v`` and the effective weight is
+    ``g * v / ||v||`` (folded into the packed images); backward returns (dv, dg).
     """
 
     @staticmethod
-    def forward(ctx, x, w, bias, add1, add2, geom, fused, packed):
+    def forward(ctx, x, w, bias, add1, add2, geom, fused, packed, g=None):
         x = _c(x)
         b = x.shape[0]
         width = geom.get("width", 1)
@@ -111,26 +131,34 @@ class FusedConvFn(torch.autograd.Function):
                                   geom["groups"], transposed=transposed, width=width,
                                   pad_mode=geom.get("pad_mode", "zero"), **fused)
         wc = _c(w.reshape(w.shape[0], w.shape[1], -1))
-        if packed is None:
-            packed = ops.pack_weight(desc, wc)
+        holder = packed if isinstance(packed, PreparedWeights) else None
+        if holder is None:
+            scale = None
+            if g is not None:
+                scale = ops.weight_norm_scale(wc, _c(g).reshape(-1))
+            fwd = packed if packed is not None else ops.pack_weight(desc, wc, scale)
+            holder = PreparedWeights(None, wc, scale, fwd)
         add1c = None if add1 is None else _c(add1).reshape(b, c_out, -1)
         add2c = None if add2 is None else _c(add2).reshape(b, c_out, -1)
-        y = ops.conv1d_forward(desc, x3, packed, None if bias is None else _c(bias), add1c, add2c)
+        y = ops.conv1d_forward(desc, x3, holder.fwd, None if bias is None else _c(bias), add1c, add2c)
         ctx.desc = desc
         ctx.has = (bias is not None, add1 is not None, add2 is not None)
         ctx.fused = fused
         ctx.w_shape = tuple(wc.shape)
         ctx.w_orig_shape = tuple(w.shape)
         ctx.x_shape = tuple(x.shape)
+        ctx.holder = holder
+        ctx.has_g = g is not None
         need_y = fused.get("post_act") not in (None, "none")
-        ctx.save_for_backward(x3, wc, y if need_y else None)
+        ctx.save_for_backward(x3, y if need_y else None, wc if g is not None else None,
+                              _c(g) if g is not None else None)
         if width > 1:
             return y.reshape(b, c_out, t_out, width)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x3, wc, y = ctx.saved_tensors
+        x3, y, v, g = ctx.saved_tensors
         desc, fused = ctx.desc, ctx.fused
         dy = _c(dy).reshape(desc.batch, desc.c_out, -1)
         _require_device(dy)
@@ -139,23 +167,33 @@ class FusedConvFn(torch.autograd.Function):
         scale = float(fused.get("out_mul", 1.0)) / float(fused.get("out_div", 1.0))
         post = fused.get("post_act")
         if post not in (None, "none") or scale != 1.0:
-            g = torch.empty_like(dy)
-            _lib.check(_L().pwg_act_backward(_ptr(dy), _ptr(y), _ptr(g), dy.numel(), ops.ACT[post],
+            gsum = torch.empty_like(dy)
+            _lib.check(_L().pwg_act_backward(_ptr(dy), _ptr(y), _ptr(gsum), dy.numel(), ops.ACT[post],
                                              float(fused.get("post_slope", 0.0)), scale, _stream()), "act_backward")
         else:
-            g = dy
+            gsum = dy
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
-        dx = dw = db = None
+        need_g = ctx.has_g and ctx.needs_input_grad[8]
+        dx = dw = db = dg = None
         if need_x:
-            dx = ops.conv1d_backward_data(desc, g, ops.pack_weight_bwd(desc, wc), x3).reshape(ctx.x_shape)
-        if need_w or (need_b and has_bias):
-            dw, db = ops.conv1d_backward_weight(desc, x3, g, ctx.w_shape, need_dw=need_w, need_db=need_b and has_bias)
+            dx = ops.conv1d_backward_data(desc, gsum, ctx.holder.bwd(desc), x3).reshape(ctx.x_shape)
+        if need_w or need_g or (need_b and has_bias):
+            dw, db = ops.conv1d_backward_weight(desc, x3, gsum, ctx.w_shape, need_dw=need_w or need_g,
+                                                need_db=need_b and has_bias)
+            if dw is not None and ctx.has_g:
+                # weight norm backward: (dv, dg) from the gradient w.r.t. the effective weight
+                dv = torch.empty_like(v)
+                dg = torch.empty_like(g)
+                n0 = v.shape[0]
+                _lib.check(_L().pwg_weight_norm_backward(_ptr(dw), _ptr(v), _ptr(g), _ptr(dv), _ptr(dg), n0,
+                                                         v.numel() // n0, _stream()), "weight_norm_backward")
+                dw = dv
             if dw is not None:
                 dw = dw.reshape(ctx.w_orig_shape)
         gshape = dy.shape if desc.width == 1 else (desc.batch, desc.c_out, desc.t_out, desc.width)
-        dadd1 = g.reshape(gshape) if has_add1 and ctx.needs_input_grad[3] else None
-        dadd2 = g.reshape(gshape) if has_add2 and ctx.needs_input_grad[4] else None
-        return dx, dw, db, dadd1, dadd2, None, None, None
+        dadd1 = gsum.reshape(gshape) if has_add1 and ctx.needs_input_grad[3] else None
+        dadd2 = gsum.reshape(gshape) if has_add2 and ctx.needs_input_grad[4] else None
+        return dx, dw, db, dadd1, dadd2, None, None, None, dg
 
 
 class Add3DivFn(torch.autograd.Function):

@@ -167,25 +167,34 @@ class _ConvNd(torch.nn.Module):
         ps = [self.raw_weight] + ([self.weight_g] if self.has_weight_norm else [])
         if self.has_spectral_norm:
             ps += [self.weight_u, self.weight_v]
-        return (ops.PARAM_EPOCH[0],) + tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
+        # the fused optimizers update parameters through raw pointers: they bump a per-parameter
+        # epoch (ops.param_epoch) instead of torch's version counter
+        return (ops.PARAM_EPOCH[0],) + tuple((p.data_ptr(), p._version, ops.param_epoch(p), str(p.device)) for p in ps)
+
+    def prepared(self):
+        """:class:`functional.PreparedWeights` for the current parameter values (weight or weight-norm
+        layers): weight-norm scale, packed forward image and, lazily, the packed data-gradient image.
+        Shared by every forward / backward until a parameter changes."""
+        key = self._params_key()
+        if self._cache_key != key or self._cache_packed is None:
+            desc = self.make_desc(1, self._probe_len())
+            with torch.no_grad():
+                if self.has_weight_norm:
+                    v = self._w3(self.weight_v.detach())
+                    scale = ops.weight_norm_scale(v, self.weight_g.detach().reshape(-1).contiguous())
+                    self._cache_packed = Fn.PreparedWeights(key, v, scale, ops.pack_weight(desc, v, scale))
+                else:
+                    w = self._w3(self.effective_weight())
+                    self._cache_packed = Fn.PreparedWeights(key, w, None, ops.pack_weight(desc, w))
+            self._cache_key = key
+        return self._cache_packed
 
     def packed_weight(self):
         """Cached forward weight image (no-grad path)."""
         if self.has_spectral_norm and self.training:
             # every training-mode forward performs a power iteration: nothing to cache
             return ops.pack_weight(self.make_desc(1, self._probe_len()), self._w3(self.effective_weight()))
-        key = self._params_key()
-        if key != self._cache_key:
-            desc = self.make_desc(1, self._probe_len())
-            with torch.no_grad():
-                if self.has_weight_norm:
-                    v = self._w3(self.weight_v.detach())
-                    scale = ops.weight_norm_scale(v, self.weight_g.detach().reshape(-1).contiguous())
-                    self._cache_packed = ops.pack_weight(desc, v, scale)
-                else:
-                    self._cache_packed = ops.pack_weight(desc, self._w3(self.effective_weight()))
-            self._cache_key = key
-        return self._cache_packed
+        return self.prepared().fwd
 
     @staticmethod
     def _w3(w):
@@ -227,7 +236,13 @@ class _ConvNd(torch.nn.Module):
                 # backward); pad and the element-wise pre-activation commute
                 x = Fn.pad1d(x, self.padding, self.padding_right, self.pad_mode)
                 geom["padding"], geom["padding_right"], geom["pad_mode"] = 0, 0, "zero"
-            return Fn.FusedConvFn.apply(x, self.weight_tensor(), self.bias, add1, add2, geom, fused, None)
+            if self.has_spectral_norm:
+                # one power iteration per training forward: the weight is a fresh autograd node
+                return Fn.FusedConvFn.apply(x, self.weight_tensor(), self.bias, add1, add2, geom, fused, None)
+            if self.has_weight_norm:
+                return Fn.FusedConvFn.apply(x, self.weight_v, self.bias, add1, add2, geom, fused, self.prepared(),
+                                            self.weight_g)
+            return Fn.FusedConvFn.apply(x, self.weight, self.bias, add1, add2, geom, fused, self.prepared())
         with torch.no_grad():
             b = x.shape[0]
             if self.width_mode:

@@ -20,7 +20,19 @@ PARAM_EPOCH = [0]
 
 
 def bump_param_epoch():
+    """Invalidate every cached weight image (e.g. before a hipGraph capture, so that all weight
+    preparation kernels of the captured step are recorded inside the graph)."""
     PARAM_EPOCH[0] += 1
+
+
+def param_epoch(p):
+    return getattr(p, "_pwg_epoch", 0)
+
+
+def bump_params(params):
+    """Mark parameters as changed through raw pointers (fused optimizer kernels)."""
+    for p in params:
+        p._pwg_epoch = getattr(p, "_pwg_epoch", 0) + 1
 
 
 def _require_device(*tensors):

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from .. import _lib
-from ..ops import _stream, bump_param_epoch
+from ..ops import _stream, bump_params
 
 CHUNK = 65536
 
@@ -156,7 +156,10 @@ class _FusedBase(torch.optim.Optimizer):
             fn = getattr(lib, self._entry)
             _lib.check(fn(ctypes.c_void_p(d["table_dev"].data_ptr()), d["n_chunks"],
                           ctypes.c_void_p(d["hyper_dev"].data_ptr()), _stream()), self._entry)
-        bump_param_epoch()  # parameters changed behind torch's back: invalidate packed-weight caches
+        # parameters changed behind torch's back: invalidate the packed-weight caches of THESE parameters
+        # (the other model's images -- e.g. the discriminator's during the generator step -- stay valid)
+        for group in self.param_groups:
+            bump_params(group["params"])
         return loss
 
 
