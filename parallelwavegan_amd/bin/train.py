@@ -151,6 +151,8 @@ class Trainer(object):
         return y_, y_mb_
 
     def _step_optimizer(self, key, loss):
+        """Generator: backward, [yield key = gradient-exchange point], clip, update.  The caller
+        completes the exchange at the yield (eagerly: RCCL calls are never captured in a hipGraph)."""
         cfg = self.config
         opt = self.optimizer[key]
         params = list(self._module(key).parameters())
@@ -161,7 +163,8 @@ class Trainer(object):
             reducer.prepare()
         loss.backward()
         if reducer is not None:
-            opt.grad_scale = reducer.finish()
+            yield key
+            opt.grad_scale = 1.0 / reducer.world
             opt.flat_grads = reducer.flat_grads
             pairs = [(p, reducer.flat_grads[p]) for p in params]
         else:
@@ -182,7 +185,7 @@ class Trainer(object):
     # ------------------------------------------------------------------ hipGraph mode
     def _graph_ok(self):
         cfg = self.config
-        return (cfg.get("use_hip_graph", False) and not cfg.get("distributed", False)
+        return (cfg.get("use_hip_graph", False)
                 and cfg.get("generator_grad_norm", -1) <= 0 and cfg.get("discriminator_grad_norm", -1) <= 0)
 
     def _phases(self):
@@ -192,10 +195,14 @@ class Trainer(object):
 
     def _train_step_graphed(self, batch):
         """Replay the whole optimisation step (G forward/backward/update, D forward/backward/update,
-        ~1500 kernel launches) as ONE hipGraph launch.  The first ``graph_warmup_steps`` steps run
+        ~1500 kernel launches) as hipGraph launches.  The first ``graph_warmup_steps`` steps run
         eagerly (they size every cache and the allocator), then the step is captured once per
-        (active phases, batch shapes) signature.  Per replay the host only copies the batch into the
-        static buffers, refreshes the optimizers' device scalars and steps the LR schedulers."""
+        (active phases, batch shapes) signature.  Single GPU: ONE graph.  Data parallel: the step is
+        cut at its gradient-exchange points into up to three graphs (... G backward | G update ... D
+        backward | D update) that share one memory pool; the bucketed RCCL all-reduces run eagerly
+        between the replays (collectives are never captured).  Per replay the host only copies the
+        batch into the static buffers, refreshes the optimizers' device scalars and steps the LR
+        schedulers."""
         x, y = self._parse_batch(batch)
         key = (self._phases(), tuple(tuple(t.shape) for t in x if t is not None), tuple(y.shape))
         entry = self._graphs.get(key)
@@ -207,36 +214,58 @@ class Trainer(object):
             static_x = [None if t is None else t.clone() for t in x]
             static_y = y.clone()
             self._flush_pending()
-            graph = torch.cuda.CUDAGraph()
             self._capturing = True
             # every cached weight image is dropped so that all weight-preparation kernels of the step
             # are recorded inside the graph, in order, and re-run at each replay
             from ..ops import bump_param_epoch
 
             bump_param_epoch()
+            for r in (self.reducers or {}).values():
+                r.defer = True  # hooks only fill the buckets; the exchange happens between the graphs
+            segments = []  # [(graph, exchange key or None)]
+            pool = torch.cuda.graph_pool_handle()
+            step = self._device_step_iter(static_x, static_y)
             try:
-                with torch.cuda.graph(graph):
-                    self._device_step(static_x, static_y)
-                    names = [n for n, _ in self._pending]
-                    vals = torch.stack([v.reshape(()) for _, v in self._pending]) if self._pending else None
+                done = False
+                while not done:
+                    graph = torch.cuda.CUDAGraph()
+                    exchange = None
+                    with torch.cuda.graph(graph, pool=pool):
+                        try:
+                            exchange = next(step)
+                        except StopIteration:
+                            done = True
+                            names = [n for n, _ in self._pending]
+                            vals = (torch.stack([v.reshape(()) for _, v in self._pending])
+                                    if self._pending else None)
+                    segments.append((graph, exchange))
+                    if exchange is not None:
+                        self.reducers[exchange].finish()  # eager: the capture step's own exchange
             finally:
                 self._capturing = False
+                for r in (self.reducers or {}).values():
+                    r.defer = False
             self._pending = []
             accum = torch.zeros_like(vals) if vals is not None else None
-            entry = dict(graph=graph, x=static_x, y=static_y, names=names, vals=vals, accum=accum, count=0)
+            entry = dict(segments=segments, x=static_x, y=static_y, names=names, vals=vals, accum=accum, count=0)
             self._graphs[key] = entry
+            # the capture pass executed nothing: fall through and replay it for this step
         for s, t in zip(entry["x"], x):
             if s is not None:
                 s.copy_(t, non_blocking=True)
         entry["y"].copy_(y, non_blocking=True)
         gen_on, disc_on = key[0]
+        scale = 1.0 / self.reducers["generator"].world if self.reducers else 1.0
         if gen_on:
-            self.optimizer["generator"].grad_scale = 1.0
+            self.optimizer["generator"].grad_scale = scale
             self.optimizer["generator"].prepare()
         if disc_on:
-            self.optimizer["discriminator"].grad_scale = 1.0
+            self.optimizer["discriminator"].grad_scale = scale
             self.optimizer["discriminator"].prepare()
-        entry["graph"].replay()
+        for graph, exchange in entry["segments"]:
+            graph.replay()
+            if exchange is not None:
+                self.reducers[exchange].exchange_all()
         from ..ops import bump_param_epoch
 
         bump_param_epoch()
@@ -261,6 +290,13 @@ class Trainer(object):
         self._check_train_finish()
 
     def _device_step(self, x, y):
+        """One optimisation step, eagerly: the gradient exchanges run where the step yields."""
+        for key in self._device_step_iter(x, y):
+            self.reducers[key].finish()
+
+    def _device_step_iter(self, x, y):
+        """Generator over the step's gradient-exchange points (yields "generator" / "discriminator"
+        after the respective backward when data parallel; yields nothing on a single GPU)."""
         cfg = self.config
         disc_on = self.steps > cfg["discriminator_train_start_steps"]
 
@@ -303,7 +339,7 @@ class Trainer(object):
                 for p in d_params:
                     p.requires_grad_(True)
             self._log("train/generator_loss", gen_loss)
-            self._step_optimizer("generator", gen_loss)
+            yield from self._step_optimizer("generator", gen_loss)
 
         # ---------------- discriminator ----------------
         if disc_on:
@@ -317,7 +353,7 @@ class Trainer(object):
             self._log("train/real_loss", real_loss)
             self._log("train/fake_loss", fake_loss)
             self._log("train/discriminator_loss", dis_loss)
-            self._step_optimizer("discriminator", dis_loss)
+            yield from self._step_optimizer("discriminator", dis_loss)
 
     def _train_epoch(self):
         for train_steps_per_epoch, batch in enumerate(self.data_loader["train"], 1):

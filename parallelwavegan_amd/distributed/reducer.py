@@ -50,6 +50,7 @@ class GradReducer:
         self.flat_grads = {p: b.views[p] for b in self.buckets for p in b.params}
         self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in params]
         self.enabled = True
+        self.defer = False  # True while a hipGraph is being captured: hooks fill buckets, nothing is launched
 
     def broadcast_parameters(self, tensors, src=0):
         """Rank 0's parameters and buffers become everyone's (as DDP does at wrap time)."""
@@ -75,12 +76,25 @@ class GradReducer:
             self._launch(b)
 
     def _launch(self, b):
-        if self.world > 1:
+        if self.world > 1 and not self.defer:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def exchange_all(self):
+        """All-reduce every bucket now and wait (hipGraph mode: the buckets were filled by a replayed
+        graph, whose capture recorded the hook copies but no collective)."""
+        if self.world > 1:
+            works = [dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                     for b in self.buckets]
+            for w in works:
+                w.wait()
 
     def finish(self):
         """Wait for every exchange (parameters that received no gradient count as zero);
         returns the averaging factor to fold into the optimizer step."""
+        if self.defer:  # capture pass of a hipGraph: nothing ran, nothing to exchange
+            for b in self.buckets:
+                b.pending = 0
+            return 1.0 / self.world
         for b in self.buckets:
             if b.pending > 0:  # some parameters got no gradient: exchange the (zero-filled) rest
                 self._launch(b)

@@ -1,0 +1,62 @@
+"""GPU: data-parallel training on two ranks (gloo collectives, both ranks on cuda:0 -- the single-GPU
+test box; RCCL itself is the same torch.distributed call).  The segmented hipGraph mode (graphs cut at
+the gradient-exchange points, collectives eager in between) must follow the eager bucketed-hook mode
+step for step, and both ranks must hold identical parameters afterwards."""
+import os
+import tempfile
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+N_STEPS = 6
+
+
+def _worker(rank, world, port, use_graph, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from tests.golden import synth
+    from tests.test_hifigan_train_gpu import build_trainer
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    tr, _, model, opt = build_trainer(dev, 41, 1.25, 2, N_STEPS, distributed=True)
+    tr.config.update(use_hip_graph=use_graph, graph_warmup_steps=2, rank=rank)
+    tr.tqdm = None
+    # every rank trains on its own shard
+    c = synth.synth_input("c", (2, 80, 32), seed=100 + rank)
+    y = 0.5 * synth.synth_input("y", (2, 1, 8192), seed=100 + rank)
+    log = []
+    for _ in range(N_STEPS):
+        tr._train_step(((c,), y))
+        tr._flush_pending()
+        log.append(dict(tr.total_train_loss))
+    if use_graph:
+        assert len(tr._graphs) == 1
+        (entry,) = tr._graphs.values()
+        assert [k for _, k in entry["segments"]] == ["generator", "discriminator", None]
+    sums = {k: float(sum(p.double().sum().item() for p in model[k].parameters())) for k in model}
+    absd = {k: float(sum(p.double().abs().sum().item() for p in model[k].parameters())) for k in model}
+    torch.save(dict(log=log, sums=sums, absd=absd), os.path.join(out_dir, f"r{rank}_g{int(use_graph)}.pt"))
+    dist.destroy_process_group()
+
+
+def test_segmented_graph_ddp_matches_eager_ddp():
+    out = tempfile.mkdtemp()
+    for i, use_graph in enumerate((False, True)):
+        mp.spawn(_worker, args=(2, 29620 + i, use_graph, out), nprocs=2, join=True)
+    res = {(r, g): torch.load(os.path.join(out, f"r{r}_g{g}.pt")) for r in (0, 1) for g in (0, 1)}
+    for g in (0, 1):  # replicas stay in lock-step: identical parameters on both ranks
+        for k in ("generator", "discriminator"):
+            assert res[(0, g)]["sums"][k] == res[(1, g)]["sums"][k], (g, k)
+    for r in (0, 1):  # graph mode follows eager mode
+        for i, (a, b) in enumerate(zip(res[(r, 0)]["log"], res[(r, 1)]["log"])):
+            for k in a:
+                assert abs(a[k] - b[k]) <= 2e-4 * max(abs(a[k]), 1e-3), (r, i, k, a[k], b[k])
+        for k in ("generator", "discriminator"):
+            d = abs(res[(r, 0)]["sums"][k] - res[(r, 1)]["sums"][k])
+            assert d <= 1e-6 * res[(r, 0)]["absd"][k], (r, k, d)
