@@ -182,18 +182,31 @@ def bench_train(args, dev, rank, world, dist):
     c = torch.randn(b, 80, t // 256, generator=gen).to(dev)
     y = (0.3 * torch.randn(b, 1, t, generator=gen)).to(dev)
     batch = ((c,), y)
-    tr = Trainer(steps=1, epochs=0, data_loader={"train": [batch], "dev": [batch]},
-                 sampler={"train": None, "dev": None}, model=model, criterion=criterion, optimizer=opt,
-                 scheduler=sched, config=config, device=dev)
-    tr.tqdm = None
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(warmup):
-        tr._train_step(batch)
+    # hipGraph replay of the step (data parallel: graphs cut at the gradient exchanges); should the
+    # capture fail on some stack, every rank sees the same exception and the run continues eagerly
+    for use_graph in ([True, False] if config["use_hip_graph"] else [False]):
+        config["use_hip_graph"] = use_graph
+        tr = Trainer(steps=1, epochs=0, data_loader={"train": [batch], "dev": [batch]},
+                     sampler={"train": None, "dev": None}, model=model, criterion=criterion, optimizer=opt,
+                     scheduler=sched, config=config, device=dev)
+        tr.tqdm = None
+        try:
+            for _ in range(warmup):
+                tr._train_step(batch)
+            break
+        except Exception as e:  # noqa: BLE001
+            if not use_graph:
+                raise
+            print(f"[bench] hipGraph training step failed ({type(e).__name__}: {e}); falling back to eager",
+                  file=sys.stderr, flush=True)
+            for r in (tr.reducers or {}).values():
+                r.remove()
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
