@@ -176,7 +176,8 @@ def bench_train(args, dev, rank, world, dist):
                   generator_train_start_steps=0, discriminator_train_start_steps=0,
                   train_max_steps=10 ** 9, save_interval_steps=10 ** 9, eval_interval_steps=10 ** 9,
                   log_interval_steps=10 ** 9, distributed=world > 1, rank=rank, outdir=tempfile.mkdtemp(),
-                  progress=False, use_hip_graph=not args.no_graph, graph_warmup_steps=2)
+                  progress=False, use_hip_graph=not args.no_graph, graph_warmup_steps=2,
+                  reuse_real_discriminator_pass=os.environ.get("PWG_REUSE_REAL", "1") == "1")
     gen = torch.Generator(device="cpu").manual_seed(200 + rank)
     b, t = args.train_batch, 8192
     c = torch.randn(b, 80, t // 256, generator=gen).to(dev)

@@ -299,6 +299,7 @@ class Trainer(object):
         after the respective backward when data parallel; yields nothing on a single GPU)."""
         cfg = self.config
         disc_on = self.steps > cfg["discriminator_train_start_steps"]
+        p_real = None  # discriminator outputs on the real signal, shared by the two phases
 
         # ---------------- generator ----------------
         if self.steps > cfg.get("generator_train_start_steps", 0):
@@ -322,22 +323,31 @@ class Trainer(object):
                 self._log("train/mel_loss", mel_loss)
             gen_loss = gen_loss * cfg.get("lambda_aux", 1.0)
             if disc_on:
-                # D acts as a fixed critic here: no D weight gradients (they would be discarded)
+                # D acts as a fixed critic for G(c): no D weight gradients (they would be discarded)
                 d_params = list(self._module("discriminator").parameters())
                 for p in d_params:
                     p.requires_grad_(False)
                 p_ = self.model["discriminator"](y_)
+                for p in d_params:
+                    p.requires_grad_(True)
                 adv_loss = self.criterion["gen_adv"](p_)
                 self._log("train/adversarial_loss", adv_loss)
                 if cfg.get("use_feat_match_loss", False):
-                    with torch.no_grad():
-                        p = self.model["discriminator"](y)
-                    fm_loss = self.criterion["feat_match"](p_, p)
+                    # The discriminator's weights do not change between this phase and the discriminator
+                    # phase, so its pass over the real signal (feature-matching targets here) is
+                    # evaluated once WITH autograd state and reused there -- except for sub-discriminators
+                    # whose forward has a side effect (spectral-norm power iteration): those are
+                    # re-evaluated, in the reference's order, exactly as often as the reference does.
+                    if (cfg.get("reuse_real_discriminator_pass", True)
+                            and hasattr(self._module("discriminator"), "stateful_outputs")):
+                        p = p_real = self.model["discriminator"](y)
+                    else:
+                        with torch.no_grad():
+                            p = self.model["discriminator"](y)
+                    fm_loss = self.criterion["feat_match"](p_, p)  # (targets are detached inside)
                     self._log("train/feature_matching_loss", fm_loss)
                     adv_loss = adv_loss + cfg["lambda_feat_match"] * fm_loss
                 gen_loss = gen_loss + cfg["lambda_adv"] * adv_loss
-                for p in d_params:
-                    p.requires_grad_(True)
             self._log("train/generator_loss", gen_loss)
             yield from self._step_optimizer("generator", gen_loss)
 
@@ -346,7 +356,12 @@ class Trainer(object):
             if cfg.get("update_prediction_after_generator_update", True):
                 with torch.no_grad():
                     y_, _ = self._generator_forward(x)
-            p = self.model["discriminator"](y)
+            if p_real is not None:
+                redo = self._module("discriminator").stateful_outputs()
+                fresh = self.model["discriminator"](y, only=redo) if redo else []
+                p = [fresh[i] if i in redo else p_real[i] for i in range(len(p_real))]
+            else:
+                p = self.model["discriminator"](y)
             p_ = self.model["discriminator"](y_.detach())
             real_loss, fake_loss = self.criterion["dis_adv"](p_, p)
             dis_loss = real_loss + fake_loss

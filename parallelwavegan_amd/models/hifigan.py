@@ -404,13 +404,33 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
         self.msd.branch_streams = bool(value)
         self.mpd.branch_streams = bool(value)
 
-    def forward(self, x):
+    def stateful_outputs(self):
+        """Indices (into the returned list) of the sub-discriminators whose training-mode forward has a
+        side effect -- the spectral-norm power iteration of the first scale discriminator.  The outputs
+        of all the others depend only on (weights, input), so a trainer may reuse them while the weights
+        are unchanged (bin/train.py: the real-signal pass of the generator phase feeds the discriminator
+        phase)."""
+        subs = list(self.msd.discriminators) + list(self.mpd.discriminators)
+        return [i for i, d in enumerate(subs)
+                if any(getattr(m, "has_spectral_norm", False) for m in d.modules())]
+
+    def forward(self, x, only=None):
+        """``only``: optional list of sub-discriminator indices to evaluate (the other entries of the
+        returned list are None)."""
+        xs = []
+        xi = x
+        for _ in self.msd.discriminators:
+            xs.append(xi)
+            xi = self.msd.pooling(xi)
+        if only is not None:
+            subs = list(zip(self.msd.discriminators, xs)) + [(d, x) for d in self.mpd.discriminators]
+            outs = [None] * len(subs)
+            res = run_branches([(lambda f=subs[i][0], v=subs[i][1]: f(v)) for i in only], x.device,
+                               self.msd.branch_streams and len(only) > 1)
+            for i, r in zip(only, res):
+                outs[i] = r
+            return outs
         if self.msd.branch_streams:  # one fork over all 3 + 5 sub-discriminators
-            xs = []
-            xi = x
-            for _ in self.msd.discriminators:
-                xs.append(xi)
-                xi = self.msd.pooling(xi)
             fns = [(lambda f=f, v=v: f(v)) for f, v in zip(self.msd.discriminators, xs)]
             fns += [(lambda d=d: d(x)) for d in self.mpd.discriminators]
             return run_branches(fns, x.device, True)
