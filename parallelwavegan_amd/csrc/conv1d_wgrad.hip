@@ -7,9 +7,11 @@
 // exchanged).  GEMM view per (group, tap): rows = o, cols = i, reduction = (b, n):
 //   A[o][n]  <- G tile   (LDS, rotation-swizzled so that 32 rows hit 32 banks)
 //   B[n][i]  <- X tile   (LDS, odd row stride; every tap is a shifted read of the same tile)
-// One workgroup = 2x2 waves = 64 o x 64 i x TG taps, looping over its slice of the (b,n) range in
-// chunks of 32 columns with LDS-DMA double buffering; partial sums are combined with fp32
-// atomics into the torch-layout gradient (the caller zeroes it).
+// One workgroup = 2x2 waves = 64 o x 64 i x TG taps (or 32 x 32 with the taps split over the waves),
+// looping over its slice of the (b,n) range in chunks of 32/64/128 columns with LDS-DMA double
+// buffering.  Every slice writes a private slab in torch weight layout (plus, for plain convolutions,
+// the bias-gradient row sums of its G tiles); reduce_slabs_* adds the slabs in a fixed order:
+// deterministic, no atomics.
 #include "common.h"
 
 namespace pwg {
@@ -20,7 +22,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 struct WgArgs {
   const float* g;   // "output gradient" role   (B, CO, n_cols)
   const float* x;   // "input" role             (B, CI, x_len)
-  float* dw;        // (CO, CI/groups, K) torch layout, accumulated atomically
+  float* dw;        // slab base: (CO, CI/groups, K) torch layout per reduction slice
   int co_g, ci_g, groups;
   int k, k0_step;   // taps, taps per tap-group
   int stride, dil, pad, width;
