@@ -15,7 +15,7 @@ if [ -z "$PMC_ONLY" ]; then
 # object must agree with (same workload, eager launches = one dispatch per kernel)
 rocprofv3 --kernel-trace --stats -d $O/trace_infer -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-graph --no-train --no-latency > $O/trace_infer.log 2>&1
 python $R/tools/rocprof_summary.py $(ls $O/trace_infer/*.db | head -1) $O/infer_kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-graph --no-train --no-latency (HiFi-GAN V1 inference B=16x800 frames only: 2 warm-up + 5 timed + 3 event-profiled forwards = 10 x 78 conv launches)"
-tail -1 $O/trace_infer.log > $O/infer_bench.json
+grep "^{\"metric\"" $O/trace_infer.log | tail -1 > $O/infer_bench.json
 fi
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_$C -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-train --no-latency > $O/pmc_$C.log 2>&1
