@@ -184,8 +184,11 @@ __global__ __launch_bounds__(256, (TG > 7 ? 1 : 2)) void conv1d_wgrad_kernel(WgA
         }
       }
     } else {
+      // Edge chunk: the WHOLE row (XS - 1 floats = every position the MFMA loop can read) is written,
+      // with zeros past the data.  Columns beyond n_cols meet G = 0 in the contraction, but 0 * stale
+      // LDS content is NaN when that content happens to be a NaN/Inf bit pattern.
 #pragma unroll 1
-      for (int e0 = 0; e0 < L; e0 += 64) {
+      for (int e0 = 0; e0 < XS - 1; e0 += 64) {
         const int f = f0 + e0 + lane;
         const bool lane_ok = (unsigned)f < (unsigned)a.x_len && e0 + lane < L;
 #pragma unroll 1
