@@ -29,6 +29,27 @@ bool lds_limit_is_set(const void* kern, size_t bytes) {
   return false;
 }
 
+// ---- debugging aid: PWG_POISON_LDS=1 fills the LDS of every CU with NaN bit patterns before each
+// MFMA kernel launch, so that a result depending on stale LDS content (0 * unwritten tile element in a
+// contraction) fails deterministically instead of once in a while on a cold GPU ---------------------
+__global__ void poison_lds_kernel(float* sink) {
+  extern __shared__ float lds[];
+  for (int i = threadIdx.x; i < (160 * 1024 - 256) / 4; i += blockDim.x) lds[i] = __int_as_float(0x7fc00000);
+  __syncthreads();
+  if (sink && threadIdx.x == 0 && lds[17] == 1.0f) sink[0] = 1.f;
+}
+void maybe_poison_lds(hipStream_t stream) {
+  static const bool on = getenv("PWG_POISON_LDS") != nullptr;
+  if (!on) return;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(poison_lds_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    attr = true;
+  }
+  hipLaunchKernelGGL(poison_lds_kernel, dim3(1024), dim3(256), 160 * 1024 - 256, stream, (float*)nullptr);
+}
+
 // ---- per-launch event timing ------------------------------------------------------------
 struct ProfRec {
   const char* kernel;

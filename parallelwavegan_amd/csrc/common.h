@@ -58,6 +58,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_buffer_rsrc(const void
 // remembers the largest dynamic-LDS limit already configured per kernel (so that launches inside a
 // hipGraph capture never call hipFuncSetAttribute again)
 bool lds_limit_is_set(const void* kern, size_t bytes);
+// PWG_POISON_LDS=1 (debugging): NaN-fill every CU's LDS before an MFMA kernel launch (capi.hip)
+void maybe_poison_lds(hipStream_t stream);
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }

@@ -719,6 +719,7 @@ static int launch_conv(const ConvArgs& a0, const Geometry& g, int batch, int gro
   const double bytes = 4.0 * ((double)batch * groups * g.cin_g * a.t_in * a.width +
                               out_elems * (1 + (a.add1 != nullptr) + (a.add2 != nullptr)) +
                               (double)groups * g.k_phase * g.cin_g * g.m_g);
+  maybe_poison_lds(stream);
   {
     ProfScope prof(stream, DMA ? "conv1d_mfma_dma_kernel" : "conv1d_mfma_kernel", flops, bytes);
     hipLaunchKernelGGL(kern, grid, block, lds, stream, a);

@@ -486,6 +486,7 @@ static int launch_wgrad_mode(WgArgs a, const WgPlan& p, float* dw_out, float* wo
     if (db_out) a.db = workspace + a.slab_elems;
   }
   dim3 grid(p.splits, p.tiles, p.tap_groups);
+  maybe_poison_lds(stream);
   {
     ProfScope prof(stream, "conv1d_wgrad_kernel", flops, bytes);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
