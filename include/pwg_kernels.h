@@ -220,6 +220,33 @@ int pwg_stretch_conv_backward(const float* dy, const float* x, const float* w, f
                               int64_t rows, int32_t t_in, int32_t scale, int32_t kernel, int32_t pad_left,
                               void* stream);
 
+/* ---- StyleMelGAN pieces (layers/tade_res_block.py, models/style_melgan.py) ---- */
+/* torch.nn.InstanceNorm1d(affine=False) over `rows` = B*C rows of t samples (tade_res_block.py:27,66):
+ * y = (x - mean) / sqrt(var + eps) with the biased variance; mean / rstd (rows floats each) are kept
+ * for the backward: dx = rstd * (dy - mean(dy) - y * mean(dy * y)).                              */
+int pwg_instance_norm_forward(const float* x, float* y, float* mean, float* rstd, int64_t rows, int32_t t,
+                              float eps, void* stream);
+int pwg_instance_norm_backward(const float* dy, const float* y, const float* rstd, float* dx, int64_t rows,
+                               int32_t t, void* stream);
+/* torch.nn.Upsample(scale_factor, mode="nearest") along time (+ optional addend of the output shape,
+ * the `upsample(residual) + x` of tade_res_block.py:161): y[r][t] = x[r][t / scale] (+ add[r][t]). */
+int pwg_upsample_nearest_forward(const float* x, const float* add, float* y, int64_t rows, int32_t t_in,
+                                 int32_t scale, void* stream);
+int pwg_upsample_nearest_backward(const float* dy, float* dx, int64_t rows, int32_t t_in, int32_t scale,
+                                  void* stream);
+/* TADE modulation (tade_res_block.py:69-72): cg (B, 2C, t_in*scale), xn (B, C, t_in):
+ * y[b][c][t] = cg[b][c][t] * xn[b][c][t / scale] + cg[b][C + c][t].                              */
+int pwg_tade_modulate_forward(const float* xn, const float* cg, float* y, int32_t batch, int32_t channels,
+                              int32_t t_in, int32_t scale, void* stream);
+int pwg_tade_modulate_backward(const float* dy, const float* xn, const float* cg, float* dxn, float* dcg,
+                               int32_t batch, int32_t channels, int32_t t_in, int32_t scale, void* stream);
+/* Gated activation of TADEResBlock (tade_res_block.py:151-158): z (B, 2C, T) -> y (B, C, T),
+ * y = softmax_over_channels(z[:, :C]) * tanh(z[:, C:])  (use_softmax != 0) or sigmoid(.) * tanh(.). */
+int pwg_softmax_gate_forward(const float* z, float* y, int32_t batch, int32_t channels, int64_t t,
+                             int32_t use_softmax, void* stream);
+int pwg_softmax_gate_backward(const float* z, const float* dy, float* dz, int32_t batch, int32_t channels,
+                              int64_t t, int32_t use_softmax, void* stream);
+
 /* ---- training input assembly (bin/train.py:646-896 Collater, mel -> waveform branch) ---- */
 /* Random-crop batch from a device-resident corpus: audio / mel are the utterances concatenated
  * (mel row-major (frames, channels)), *_off their start offsets (elements / frames), audio_len the

@@ -612,3 +612,72 @@ def residual_pwg_discriminator(sd, x, layers=30, stacks=3, kernel_size=3, slope=
     skips = skips * math.sqrt(1.0 / layers)
     x = F.conv1d(F.leaky_relu(skips, slope), get_weight(sd, "last_conv_layers.1"), get_bias(sd, "last_conv_layers.1"))
     return F.conv1d(F.leaky_relu(x, slope), get_weight(sd, "last_conv_layers.3"), get_bias(sd, "last_conv_layers.3"))
+
+
+# ----------------------------------------------------------------------------
+# StyleMelGAN (layers/tade_res_block.py:11-161, models/style_melgan.py:18-362)
+# ----------------------------------------------------------------------------
+def tade_layer(sd, prefix, x, c, upsample_factor):
+    """``TADELayer.forward`` tade_res_block.py:53-73."""
+    x = F.instance_norm(x)  # InstanceNorm1d(affine=False), eps 1e-5
+    c = F.interpolate(c, scale_factor=upsample_factor, mode="nearest") if upsample_factor != 1 else c
+    k = get_weight(sd, prefix + ".aux_conv.0").shape[-1]
+    c = F.conv1d(c, get_weight(sd, prefix + ".aux_conv.0"), get_bias(sd, prefix + ".aux_conv.0"), padding=(k - 1) // 2)
+    cg = F.conv1d(c, get_weight(sd, prefix + ".gated_conv.0"), get_bias(sd, prefix + ".gated_conv.0"),
+                  padding=(k - 1) // 2)
+    cg1, cg2 = cg.split(cg.size(1) // 2, dim=1)
+    xu = F.interpolate(x, scale_factor=upsample_factor, mode="nearest") if upsample_factor != 1 else x
+    return cg1 * xu + cg2, c
+
+
+def tade_res_block(sd, prefix, x, c, upsample_factor, dilation=2, gated_function="softmax"):
+    """``TADEResBlock.forward`` tade_res_block.py:136-161."""
+    def gate(v):
+        va, vb = v.split(v.size(1) // 2, dim=1)
+        g = torch.softmax(va, dim=1) if gated_function == "softmax" else torch.sigmoid(va)
+        return g * torch.tanh(vb)
+
+    residual = x
+    x, c = tade_layer(sd, prefix + ".tade1", x, c, 1)
+    k = get_weight(sd, prefix + ".gated_conv1").shape[-1]
+    x = gate(F.conv1d(x, get_weight(sd, prefix + ".gated_conv1"), get_bias(sd, prefix + ".gated_conv1"),
+                      padding=(k - 1) // 2))
+    x, c = tade_layer(sd, prefix + ".tade2", x, c, upsample_factor)
+    x = gate(F.conv1d(x, get_weight(sd, prefix + ".gated_conv2"), get_bias(sd, prefix + ".gated_conv2"),
+                      dilation=dilation, padding=(k - 1) // 2 * dilation))
+    ru = F.interpolate(residual, scale_factor=upsample_factor, mode="nearest") if upsample_factor != 1 else residual
+    return ru + x, c
+
+
+def style_melgan_generator(sd, c, z, noise_upsample_scales=(11, 2, 2, 2), upsample_scales=(2, 2, 2, 2, 2, 2, 2, 2, 1),
+                           dilation=2, gated_function="softmax", noise_slope=0.2, **_unused):
+    """``StyleMelGANGenerator.forward`` models/style_melgan.py:123-143."""
+    x = z
+    for i, s in enumerate(noise_upsample_scales):
+        p = f"noise_upsample.{2 * i}"
+        x = F.leaky_relu(F.conv_transpose1d(x, get_weight(sd, p), get_bias(sd, p), stride=s, padding=s // 2 + s % 2,
+                                            output_padding=s % 2), noise_slope)
+    for i, s in enumerate(upsample_scales):
+        x, c = tade_res_block(sd, f"blocks.{i}", x, c, s, dilation, gated_function)
+    k = get_weight(sd, "output_conv.0").shape[-1]
+    return torch.tanh(F.conv1d(x, get_weight(sd, "output_conv.0"), get_bias(sd, "output_conv.0"), padding=(k - 1) // 2))
+
+
+def style_melgan_discriminator(sd, x, starts, repeats=2, window_sizes=(512, 1024, 2048, 4096),
+                               pqmf_params=((1, None, None, None), (2, 62, 0.26700, 9.0), (4, 62, 0.14200, 9.0),
+                                            (8, 62, 0.07949, 9.0)), discriminator_params=None, **_unused):
+    """``StyleMelGANDiscriminator.forward`` models/style_melgan.py:307-337 with the window start indices
+    (``np.random.randint`` draws of the reference, in call order) given explicitly."""
+    dp = dict(discriminator_params or {})
+    outs = []
+    it = iter(starts)
+    for _ in range(repeats):
+        for idx, (ws, pq) in enumerate(zip(window_sizes, pqmf_params)):
+            s = next(it)
+            x_ = x[:, :, s: s + ws]
+            if idx != 0:
+                x_ = pqmf_analysis(x_, *pq)
+            outs.append(melgan_discriminator(sd, f"discriminators.{idx}", x_, kernel_sizes=dp.get("kernel_sizes", (5, 3)),
+                                             downsample_scales=dp.get("downsample_scales", (4, 4, 4, 1)),
+                                             slope=dp.get("nonlinear_activation_params", {}).get("negative_slope", 0.2)))
+    return outs

@@ -74,6 +74,14 @@ SIGNATURES = {
     "pwg_act_backward": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _f32, _vp]),
     "pwg_add3_div": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _vp]),
     "pwg_wave_to_pcm16": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
+    "pwg_instance_norm_forward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
+    "pwg_instance_norm_backward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "pwg_upsample_nearest_forward": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "pwg_upsample_nearest_backward": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
+    "pwg_tade_modulate_forward": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "pwg_tade_modulate_backward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "pwg_softmax_gate_forward": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i64, _i32, _vp]),
+    "pwg_softmax_gate_backward": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp]),
     "pwg_gather_crop": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                                        _vp]),
     "pwg_normalize_transpose": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),

@@ -416,6 +416,177 @@ __global__ void add3_div_kernel(const float* a, const float* b, const float* c, 
   }
 }
 
+// ---- StyleMelGAN pieces (layers/tade_res_block.py) ------------------------------------------------
+// InstanceNorm1d (affine = False, biased variance, eps): one workgroup per (batch, channel) row.
+__global__ __launch_bounds__(256) void instance_norm_fwd_kernel(const float* x, float* y, float* mean, float* rstd,
+                                                                int t, float eps) {
+  __shared__ float red[4];
+  const float* xr = x + (long)blockIdx.x * t;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < t; i += 256) s += xr[i];
+  const float mu = block_sum_256(s, red) / t;
+  __syncthreads();
+  float v = 0.f;
+  for (int i = threadIdx.x; i < t; i += 256) {
+    const float d = xr[i] - mu;
+    v += d * d;
+  }
+  const float rs = rsqrtf(block_sum_256(v, red) / t + eps);
+  float* yr = y + (long)blockIdx.x * t;
+  for (int i = threadIdx.x; i < t; i += 256) yr[i] = (xr[i] - mu) * rs;
+  if (threadIdx.x == 0) {
+    mean[blockIdx.x] = mu;
+    rstd[blockIdx.x] = rs;
+  }
+}
+// dx = rstd * (dy - mean(dy) - xhat * mean(dy * xhat)),  xhat = y
+__global__ __launch_bounds__(256) void instance_norm_bwd_kernel(const float* dy, const float* y, const float* rstd,
+                                                                float* dx, int t) {
+  __shared__ float red[4];
+  const long base = (long)blockIdx.x * t;
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < t; i += 256) {
+    a += dy[base + i];
+    b += dy[base + i] * y[base + i];
+  }
+  const float ma = block_sum_256(a, red) / t;
+  __syncthreads();
+  const float mb = block_sum_256(b, red) / t;
+  const float rs = rstd[blockIdx.x];
+  for (int i = threadIdx.x; i < t; i += 256) dx[base + i] = rs * (dy[base + i] - ma - y[base + i] * mb);
+}
+// nearest upsampling along time (+ optional addend of the upsampled shape): y[r][t] = x[r][t / s] (+ add[r][t])
+__global__ void upsample_nearest_fwd_kernel(const float* x, const float* add, float* y, long rows, int t_in, int s) {
+  const int t_out = t_in * s;
+  const long n = rows * t_out;
+  GRID_STRIDE(i, n) {
+    const long r = i / t_out;
+    const int t = (int)(i - r * t_out);
+    float v = x[r * t_in + t / s];
+    if (add) v += add[i];
+    y[i] = v;
+  }
+}
+__global__ void upsample_nearest_bwd_kernel(const float* dy, float* dx, long rows, int t_in, int s) {
+  const long n = rows * t_in;
+  GRID_STRIDE(i, n) {
+    const long r = i / t_in;
+    const int q = (int)(i - r * t_in);
+    const float* g = dy + r * (long)t_in * s + (long)q * s;
+    float acc = 0.f;
+    for (int j = 0; j < s; ++j) acc += g[j];
+    dx[i] = acc;
+  }
+}
+// TADE modulation (tade_res_block.py:66-73): y[b][c][t] = cg[b][c][t] * xn[b][c][t/s] + cg[b][C+c][t]
+__global__ void tade_modulate_fwd_kernel(const float* xn, const float* cg, float* y, int batch, int channels, int t_in,
+                                         int s) {
+  const int t_out = t_in * s;
+  const long n = (long)batch * channels * t_out;
+  GRID_STRIDE(i, n) {
+    const int t = (int)(i % t_out);
+    const long r = i / t_out;  // b * C + c
+    const int c = (int)(r % channels);
+    const long b = r / channels;
+    const long g1 = ((b * 2 * channels + c) * (long)t_out) + t;
+    y[i] = cg[g1] * xn[r * t_in + t / s] + cg[g1 + (long)channels * t_out];
+  }
+}
+// dcg (B, 2C, T*s) and dxn (B, C, T): dcg1 = dy * up(xn), dcg2 = dy, dxn[q] = sum_j dy[qs+j] * cg1[qs+j]
+__global__ void tade_modulate_bwd_cg_kernel(const float* dy, const float* xn, float* dcg, int batch, int channels,
+                                            int t_in, int s) {
+  const int t_out = t_in * s;
+  const long n = (long)batch * channels * t_out;
+  GRID_STRIDE(i, n) {
+    const int t = (int)(i % t_out);
+    const long r = i / t_out;
+    const int c = (int)(r % channels);
+    const long b = r / channels;
+    const long g1 = ((b * 2 * channels + c) * (long)t_out) + t;
+    const float g = dy[i];
+    dcg[g1] = g * xn[r * t_in + t / s];
+    dcg[g1 + (long)channels * t_out] = g;
+  }
+}
+__global__ void tade_modulate_bwd_x_kernel(const float* dy, const float* cg, float* dxn, int batch, int channels,
+                                           int t_in, int s) {
+  const int t_out = t_in * s;
+  const long n = (long)batch * channels * t_in;
+  GRID_STRIDE(i, n) {
+    const int q = (int)(i % t_in);
+    const long r = i / t_in;
+    const int c = (int)(r % channels);
+    const long b = r / channels;
+    const float* g = dy + r * (long)t_out + (long)q * s;
+    const float* m = cg + ((b * 2 * channels + c) * (long)t_out) + (long)q * s;
+    float acc = 0.f;
+    for (int j = 0; j < s; ++j) acc += g[j] * m[j];
+    dxn[i] = acc;
+  }
+}
+// gated activation of TADEResBlock (tade_res_block.py:151-158): z (B, 2C, T) -> y (B, C, T)
+//   softmax: y = softmax_c(z[:, :C]) * tanh(z[:, C:])      sigmoid: y = sigmoid(z[:, :C]) * tanh(z[:, C:])
+// one thread per (b, t) column, coalesced along t
+__global__ void softmax_gate_fwd_kernel(const float* z, float* y, int batch, int channels, long t, int use_softmax) {
+  const long n = (long)batch * t;
+  GRID_STRIDE(i, n) {
+    const long b = i / t;
+    const long tt = i - b * t;
+    const float* za = z + (b * 2 * channels) * t + tt;
+    const float* zb = za + (long)channels * t;
+    float* yo = y + (b * channels) * t + tt;
+    if (use_softmax) {
+      float mx = -INFINITY;
+      for (int c = 0; c < channels; ++c) mx = fmaxf(mx, za[(long)c * t]);
+      float den = 0.f;
+      for (int c = 0; c < channels; ++c) den += expf(za[(long)c * t] - mx);
+      for (int c = 0; c < channels; ++c) yo[(long)c * t] = expf(za[(long)c * t] - mx) / den * tanhf(zb[(long)c * t]);
+    } else {
+      for (int c = 0; c < channels; ++c)
+        yo[(long)c * t] = 1.f / (1.f + expf(-za[(long)c * t])) * tanhf(zb[(long)c * t]);
+    }
+  }
+}
+__global__ void softmax_gate_bwd_kernel(const float* z, const float* dy, float* dz, int batch, int channels, long t,
+                                        int use_softmax) {
+  const long n = (long)batch * t;
+  GRID_STRIDE(i, n) {
+    const long b = i / t;
+    const long tt = i - b * t;
+    const float* za = z + (b * 2 * channels) * t + tt;
+    const float* zb = za + (long)channels * t;
+    const float* g = dy + (b * channels) * t + tt;
+    float* da = dz + (b * 2 * channels) * t + tt;
+    float* db = da + (long)channels * t;
+    if (use_softmax) {
+      float mx = -INFINITY;
+      for (int c = 0; c < channels; ++c) mx = fmaxf(mx, za[(long)c * t]);
+      float den = 0.f;
+      for (int c = 0; c < channels; ++c) den += expf(za[(long)c * t] - mx);
+      float dot = 0.f;  // sum_c dp_c * p_c with dp = dy * tanh(zb)
+      for (int c = 0; c < channels; ++c) {
+        const float p = expf(za[(long)c * t] - mx) / den;
+        dot += g[(long)c * t] * tanhf(zb[(long)c * t]) * p;
+      }
+      for (int c = 0; c < channels; ++c) {
+        const float p = expf(za[(long)c * t] - mx) / den;
+        const float th = tanhf(zb[(long)c * t]);
+        const float gy = g[(long)c * t];
+        da[(long)c * t] = p * (gy * th - dot);
+        db[(long)c * t] = gy * p * (1.f - th * th);
+      }
+    } else {
+      for (int c = 0; c < channels; ++c) {
+        const float sg = 1.f / (1.f + expf(-za[(long)c * t]));
+        const float th = tanhf(zb[(long)c * t]);
+        const float gy = g[(long)c * t];
+        da[(long)c * t] = gy * th * sg * (1.f - sg);
+        db[(long)c * t] = gy * sg * (1.f - th * th);
+      }
+    }
+  }
+}
+
 // pcm[i] = (int16) rint(clamp(x[i], -1, 1) * 32767)   (the PCM_16 write of bin/decode.py:235-243)
 __global__ void wave_to_pcm16_kernel(const float* x, short* pcm, long n) {
   GRID_STRIDE(i, n) {
@@ -726,5 +897,84 @@ extern "C" int pwg_gather_crop(const float* audio, const int64_t* audio_off, con
   ProfScope prof((hipStream_t)stream, "gather_crop_kernel", 0, 8.0 * n);
   LAUNCH1D(gather_crop_kernel, n, stream, audio, (const long*)audio_off, (const long*)audio_len, mel,
            (const long*)mel_off, utt, start, y, c, batch, steps, hop, frames_ctx, acw, channels);
+  return PWG_OK;
+}
+
+// ---- StyleMelGAN pieces ---------------------------------------------------------------------------
+extern "C" int pwg_instance_norm_forward(const float* x, float* y, float* mean, float* rstd, int64_t rows, int32_t t,
+                                         float eps, void* stream) {
+  PWG_REQUIRE(x && y && mean && rstd, PWG_ERR_NULL, "instance_norm_forward: NULL pointer");
+  PWG_REQUIRE(rows > 0 && t > 0, PWG_ERR_BAD_SHAPE, "instance_norm: bad shape");
+  ProfScope prof((hipStream_t)stream, "instance_norm_fwd_kernel", 0, 12.0 * rows * t);
+  hipLaunchKernelGGL(instance_norm_fwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, y, mean, rstd,
+                     t, eps);
+  PWG_CHECK_LAUNCH("instance_norm_forward");
+  return PWG_OK;
+}
+
+extern "C" int pwg_instance_norm_backward(const float* dy, const float* y, const float* rstd, float* dx, int64_t rows,
+                                          int32_t t, void* stream) {
+  PWG_REQUIRE(dy && y && rstd && dx, PWG_ERR_NULL, "instance_norm_backward: NULL pointer");
+  PWG_REQUIRE(rows > 0 && t > 0, PWG_ERR_BAD_SHAPE, "instance_norm: bad shape");
+  hipLaunchKernelGGL(instance_norm_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, dy, y, rstd, dx,
+                     t);
+  PWG_CHECK_LAUNCH("instance_norm_backward");
+  return PWG_OK;
+}
+
+extern "C" int pwg_upsample_nearest_forward(const float* x, const float* add, float* y, int64_t rows, int32_t t_in,
+                                            int32_t scale, void* stream) {
+  PWG_REQUIRE(x && y, PWG_ERR_NULL, "upsample_nearest_forward: NULL pointer");
+  PWG_REQUIRE(rows > 0 && t_in > 0 && scale > 0, PWG_ERR_BAD_SHAPE, "upsample_nearest: bad shape");
+  const long n = rows * (long)t_in * scale;
+  LAUNCH1D(upsample_nearest_fwd_kernel, n, stream, x, add, y, (long)rows, t_in, scale);
+  return PWG_OK;
+}
+
+extern "C" int pwg_upsample_nearest_backward(const float* dy, float* dx, int64_t rows, int32_t t_in, int32_t scale,
+                                             void* stream) {
+  PWG_REQUIRE(dy && dx, PWG_ERR_NULL, "upsample_nearest_backward: NULL pointer");
+  PWG_REQUIRE(rows > 0 && t_in > 0 && scale > 0, PWG_ERR_BAD_SHAPE, "upsample_nearest: bad shape");
+  LAUNCH1D(upsample_nearest_bwd_kernel, rows * (long)t_in, stream, dy, dx, (long)rows, t_in, scale);
+  return PWG_OK;
+}
+
+extern "C" int pwg_tade_modulate_forward(const float* xn, const float* cg, float* y, int32_t batch, int32_t channels,
+                                         int32_t t_in, int32_t scale, void* stream) {
+  PWG_REQUIRE(xn && cg && y, PWG_ERR_NULL, "tade_modulate_forward: NULL pointer");
+  PWG_REQUIRE(batch > 0 && channels > 0 && t_in > 0 && scale > 0, PWG_ERR_BAD_SHAPE, "tade_modulate: bad shape");
+  const long n = (long)batch * channels * t_in * scale;
+  LAUNCH1D(tade_modulate_fwd_kernel, n, stream, xn, cg, y, batch, channels, t_in, scale);
+  return PWG_OK;
+}
+
+extern "C" int pwg_tade_modulate_backward(const float* dy, const float* xn, const float* cg, float* dxn, float* dcg,
+                                          int32_t batch, int32_t channels, int32_t t_in, int32_t scale, void* stream) {
+  PWG_REQUIRE(dy && xn && cg && (dxn || dcg), PWG_ERR_NULL, "tade_modulate_backward: NULL pointer");
+  PWG_REQUIRE(batch > 0 && channels > 0 && t_in > 0 && scale > 0, PWG_ERR_BAD_SHAPE, "tade_modulate: bad shape");
+  if (dcg) {
+    const long n = (long)batch * channels * t_in * scale;
+    LAUNCH1D(tade_modulate_bwd_cg_kernel, n, stream, dy, xn, dcg, batch, channels, t_in, scale);
+  }
+  if (dxn) {
+    const long n = (long)batch * channels * t_in;
+    LAUNCH1D(tade_modulate_bwd_x_kernel, n, stream, dy, cg, dxn, batch, channels, t_in, scale);
+  }
+  return PWG_OK;
+}
+
+extern "C" int pwg_softmax_gate_forward(const float* z, float* y, int32_t batch, int32_t channels, int64_t t,
+                                        int32_t use_softmax, void* stream) {
+  PWG_REQUIRE(z && y, PWG_ERR_NULL, "softmax_gate_forward: NULL pointer");
+  PWG_REQUIRE(batch > 0 && channels > 0 && t > 0, PWG_ERR_BAD_SHAPE, "softmax_gate: bad shape");
+  LAUNCH1D(softmax_gate_fwd_kernel, (long)batch * t, stream, z, y, batch, channels, (long)t, use_softmax);
+  return PWG_OK;
+}
+
+extern "C" int pwg_softmax_gate_backward(const float* z, const float* dy, float* dz, int32_t batch, int32_t channels,
+                                         int64_t t, int32_t use_softmax, void* stream) {
+  PWG_REQUIRE(z && dy && dz, PWG_ERR_NULL, "softmax_gate_backward: NULL pointer");
+  PWG_REQUIRE(batch > 0 && channels > 0 && t > 0, PWG_ERR_BAD_SHAPE, "softmax_gate: bad shape");
+  LAUNCH1D(softmax_gate_bwd_kernel, (long)batch * t, stream, z, dy, dz, batch, channels, (long)t, use_softmax);
   return PWG_OK;
 }

@@ -328,6 +328,119 @@ class StretchConvFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------
+# StyleMelGAN element-wise stages (layers/tade_res_block.py of the reference)
+# ---------------------------------------------------------------------------------------------
+class InstanceNormFn(torch.autograd.Function):
+    """torch.nn.InstanceNorm1d(affine=False): per (batch, channel) row statistics over time."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        x = _c(x)
+        _require_device(x)
+        t = x.shape[-1]
+        rows = x.numel() // t
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+        _lib.check(_L().pwg_instance_norm_forward(_ptr(x), _ptr(y), _ptr(mean), _ptr(rstd), rows, t, float(eps),
+                                                  _stream()), "instance_norm_forward")
+        ctx.save_for_backward(y, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, rstd = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        t = y.shape[-1]
+        _lib.check(_L().pwg_instance_norm_backward(_ptr(dy), _ptr(y), _ptr(rstd), _ptr(dx), y.numel() // t, t,
+                                                   _stream()), "instance_norm_backward")
+        return dx, None
+
+
+class UpsampleNearestFn(torch.autograd.Function):
+    """y = nearest_upsample(x, scale) (+ add): x (..., T) -> (..., T * scale)."""
+
+    @staticmethod
+    def forward(ctx, x, scale, add=None):
+        x = _c(x)
+        add = None if add is None else _c(add)
+        _require_device(x, add)
+        t = x.shape[-1]
+        rows = x.numel() // t
+        y = torch.empty(x.shape[:-1] + (t * scale,), device=x.device, dtype=torch.float32)
+        _lib.check(_L().pwg_upsample_nearest_forward(_ptr(x), _ptr(add), _ptr(y), rows, t, int(scale), _stream()),
+                   "upsample_nearest_forward")
+        ctx.cfg = (rows, t, int(scale), tuple(x.shape), add is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        rows, t, scale, shape, has_add = ctx.cfg
+        dy = _c(dy)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(shape, device=dy.device, dtype=torch.float32)
+            _lib.check(_L().pwg_upsample_nearest_backward(_ptr(dy), _ptr(dx), rows, t, scale, _stream()),
+                       "upsample_nearest_backward")
+        return dx, None, (dy if has_add and ctx.needs_input_grad[2] else None)
+
+
+class TadeModulateFn(torch.autograd.Function):
+    """y = cg[:, :C] * nearest_upsample(xn, scale) + cg[:, C:]   (xn (B, C, T), cg (B, 2C, T * scale))."""
+
+    @staticmethod
+    def forward(ctx, xn, cg, scale):
+        xn, cg = _c(xn), _c(cg)
+        _require_device(xn, cg)
+        b, c, t = xn.shape
+        assert cg.shape == (b, 2 * c, t * scale), (tuple(cg.shape), (b, 2 * c, t * scale))
+        y = torch.empty((b, c, t * scale), device=xn.device, dtype=torch.float32)
+        _lib.check(_L().pwg_tade_modulate_forward(_ptr(xn), _ptr(cg), _ptr(y), b, c, t, int(scale), _stream()),
+                   "tade_modulate_forward")
+        ctx.save_for_backward(xn, cg)
+        ctx.scale = int(scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xn, cg = ctx.saved_tensors
+        dy = _c(dy)
+        b, c, t = xn.shape
+        dxn = torch.empty_like(xn) if ctx.needs_input_grad[0] else None
+        dcg = torch.empty_like(cg) if ctx.needs_input_grad[1] else None
+        _lib.check(_L().pwg_tade_modulate_backward(_ptr(dy), _ptr(xn), _ptr(cg), _ptr(dxn), _ptr(dcg), b, c, t,
+                                                   ctx.scale, _stream()), "tade_modulate_backward")
+        return dxn, dcg, None
+
+
+class SoftmaxGateFn(torch.autograd.Function):
+    """(B, 2C, T) -> (B, C, T): softmax over channels (or sigmoid) of the first half * tanh of the second."""
+
+    @staticmethod
+    def forward(ctx, z, use_softmax):
+        z = _c(z)
+        _require_device(z)
+        b, c2, t = z.shape
+        y = torch.empty((b, c2 // 2, t), device=z.device, dtype=torch.float32)
+        _lib.check(_L().pwg_softmax_gate_forward(_ptr(z), _ptr(y), b, c2 // 2, t, int(bool(use_softmax)), _stream()),
+                   "softmax_gate_forward")
+        ctx.save_for_backward(z)
+        ctx.use_softmax = int(bool(use_softmax))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (z,) = ctx.saved_tensors
+        dy = _c(dy)
+        b, c2, t = z.shape
+        dz = torch.empty_like(z)
+        _lib.check(_L().pwg_softmax_gate_backward(_ptr(z), _ptr(dy), _ptr(dz), b, c2 // 2, t, ctx.use_softmax, _stream()),
+                   "softmax_gate_backward")
+        return dz, None
+
+
+# ---------------------------------------------------------------------------------------------
 # spectral-loss pieces
 # ---------------------------------------------------------------------------------------------
 class FrameFoldFn(torch.autograd.Function):

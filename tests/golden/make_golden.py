@@ -375,7 +375,46 @@ def causal_variants(name, seed):
     print(name, {k: (v.shape, float(np.abs(v).max())) for k, v in out.items()})
 
 
+def style_melgan(name, seed):
+    """StyleMelGAN: tiny generators (softmax / sigmoid gate), the default generator (88 frames) and the
+    random-window discriminator (numpy-seeded window positions, stored)."""
+    import parallel_wavegan.models as RM
+
+    out = {}
+    with torch.no_grad():
+        for key, cfg in (("tiny", synth.STYLE_MELGAN_TINY), ("tiny_sigmoid", synth.STYLE_MELGAN_TINY_SIGMOID)):
+            g = RM.StyleMelGANGenerator(**cfg).eval()
+            g.load_state_dict(synth.synth_state_dict(g.state_dict(), seed=seed, g_scale=1.1))
+            z = synth.synth_input("z", (2, cfg["in_channels"], 5), seed=seed)
+            c = synth.synth_input("c", (2, 80, 20), seed=seed)
+            out[key] = g(c, z).numpy()
+        g = RM.StyleMelGANGenerator().eval()
+        # (gain 0.8: at 1.1 the 9-block default net is chaotic at random init -- a 1e-6 relative input
+        # change moves the output by 3e-2 -- which would test rounding noise, not the implementation)
+        g.load_state_dict(synth.synth_state_dict(g.state_dict(), seed=seed + 1, g_scale=0.8))
+        z = synth.synth_input("z", (1, 128, 1), seed=seed + 1)
+        c = synth.synth_input("c", (1, 80, 88), seed=seed + 1)
+        y = g(c, z)
+        out["default_head"] = y[..., :4096].numpy()
+        out["default_stats"] = _stats(y)
+        d = RM.StyleMelGANDiscriminator(**synth.STYLE_MELGAN_D).eval()
+        d.load_state_dict(synth.synth_state_dict(d.state_dict(), seed=seed + 2, g_scale=1.2, skip=synth.PQMF_BUFFERS),
+                          strict=False)
+        x = 0.5 * synth.synth_input("wave", (2, 1, 8192), seed=seed + 2)
+        np.random.seed(seed)
+        outs = d(x)
+        np.random.seed(seed)
+        starts = [np.random.randint(8192 - ws) for _ in range(d.repeats) for ws in d.window_sizes]
+        out["d_starts"] = np.array(starts)
+        out["d_logits"] = np.stack([o[-1].numpy() for o in outs])          # (8, 2, 1, T'') equal lengths
+        out["d_feat_stats"] = np.stack([np.stack([_stats(f) for f in o]) for o in outs])
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), meta=np.array([seed]), **out)
+    print(name, {k: getattr(v, "shape", None) for k, v in out.items()}, float(np.abs(out["tiny"]).max()),
+          float(np.abs(out["default_head"]).max()), float(np.abs(out["d_logits"]).max()))
+
+
 JOBS = {
+    "style_melgan": lambda: style_melgan("style_melgan", 95),
     "causal_variants": lambda: causal_variants("causal_variants", 91),
     "hifigan_v1_g": lambda: hifigan_generator("hifigan_v1_g", synth.HIFIGAN_V1, 2, 32, 11),
     "hifigan_v1_libritts_g": lambda: hifigan_generator("hifigan_v1_libritts_g", synth.HIFIGAN_V1_LIBRITTS, 1, 28, 12),

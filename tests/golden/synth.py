@@ -123,3 +123,10 @@ MELGAN_CAUSAL = dict(in_channels=80, out_channels=1, kernel_size=7, channels=64,
 PWG_CAUSAL = dict(layers=6, stacks=2, aux_context_window=2, use_causal_conv=True,
                   upsample_params={"upsample_scales": [4, 4]})
 RESIDUAL_PWG_D = dict(layers=6, stacks=2, residual_channels=32, gate_channels=64, skip_channels=32)
+
+# ---- StyleMelGAN
+STYLE_MELGAN_TINY = dict(in_channels=16, aux_channels=80, channels=32, out_channels=1, kernel_size=9, dilation=2,
+                         noise_upsample_scales=[2, 2], upsample_scales=[2, 2, 2, 1], gated_function="softmax")
+STYLE_MELGAN_TINY_SIGMOID = dict(STYLE_MELGAN_TINY, gated_function="sigmoid", kernel_size=5)
+STYLE_MELGAN_D = dict(repeats=2)
+PQMF_BUFFERS = ("analysis_filter", "synthesis_filter", "updown_filter")  # fixed filters, not synthesised

@@ -97,3 +97,30 @@ def test_logmel_numpy_oracle_matches_torch_stft_formulation():
         want = np.log10(np.maximum(1e-10, spec @ basis.astype(np.float64).T))
         assert got.shape == want.shape == (1 + len(audio) // hop, 80)
         assert np.abs(got - want).max() < 1e-8
+
+
+def test_style_melgan_oracle_matches_reference_golden():
+    """StyleMelGAN generator (TADE blocks) and random-window discriminator."""
+    import numpy as np
+
+    from parallelwavegan_amd.models import StyleMelGANDiscriminator, StyleMelGANGenerator
+
+    gold = load_golden("style_melgan")
+    seed = int(gold["meta"][0])
+    with torch.no_grad():
+        for key, cfg in (("tiny", synth.STYLE_MELGAN_TINY), ("tiny_sigmoid", synth.STYLE_MELGAN_TINY_SIGMOID)):
+            sd = synth_for(StyleMelGANGenerator(**cfg), seed, 1.1)
+            z = synth.synth_input("z", (2, cfg["in_channels"], 5), seed=seed)
+            c = synth.synth_input("c", (2, 80, 20), seed=seed)
+            assert max_abs(torch_cpu.style_melgan_generator(sd, c, z, **cfg), gold[key]) < 1e-5, key
+        sd = synth_for(StyleMelGANGenerator(), seed + 1, 0.8)
+        y = torch_cpu.style_melgan_generator(sd, synth.synth_input("c", (1, 80, 88), seed=seed + 1),
+                                             synth.synth_input("z", (1, 128, 1), seed=seed + 1))
+        assert y.shape == (1, 1, 88 * 256)
+        assert max_abs(y[..., :4096], gold["default_head"]) < 2e-5
+        d = StyleMelGANDiscriminator(**synth.STYLE_MELGAN_D)
+        sd = synth.synth_state_dict(d.state_dict(), seed=seed + 2, g_scale=1.2, skip=synth.PQMF_BUFFERS)
+        x = 0.5 * synth.synth_input("wave", (2, 1, 8192), seed=seed + 2)
+        outs = torch_cpu.style_melgan_discriminator(sd, x, [int(s) for s in gold["d_starts"]], **synth.STYLE_MELGAN_D)
+        logits = np.stack([o[-1].numpy() for o in outs])
+        assert max_abs(logits, gold["d_logits"]) < 1e-5
