@@ -247,6 +247,16 @@ int pwg_softmax_gate_forward(const float* z, float* y, int32_t batch, int32_t ch
 int pwg_softmax_gate_backward(const float* z, const float* dy, float* dz, int32_t batch, int32_t channels,
                               int64_t t, int32_t use_softmax, void* stream);
 
+/* ---- UHiFiGAN pieces (models/uhifigan.py) ---- */
+/* One operand of torch.cat(dim=1) (uhifigan.py:286): y (batch, c_dst, t)[:, c_off : c_off + c_src] = x
+ * (batch, c_src, t); reverse != 0 copies that slice of y back into x (the concatenation's backward). */
+int pwg_copy_channels(float* x, float* y, int32_t batch, int32_t c_src, int32_t c_dst, int32_t c_off,
+                      int64_t t, int32_t reverse, void* stream);
+/* torch.nn.Dropout in training mode (uhifigan.py:86,130): y = x * keep / (1 - p) with a counter-based
+ * mask hash(seed, index) >= p * 2^32; calling it again with the same seed on the output gradient is
+ * the backward.  (Different random stream than torch's Philox: same distribution, other draws.)      */
+int pwg_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
+
 /* ---- training input assembly (bin/train.py:646-896 Collater, mel -> waveform branch) ---- */
 /* Random-crop batch from a device-resident corpus: audio / mel are the utterances concatenated
  * (mel row-major (frames, channels)), *_off their start offsets (elements / frames), audio_len the

@@ -681,3 +681,41 @@ def style_melgan_discriminator(sd, x, starts, repeats=2, window_sizes=(512, 1024
                                              downsample_scales=dp.get("downsample_scales", (4, 4, 4, 1)),
                                              slope=dp.get("nonlinear_activation_params", {}).get("negative_slope", 0.2)))
     return outs
+
+
+# ----------------------------------------------------------------------------
+# UHiFiGAN (models/uhifigan.py:261-297; eval mode: dropout is the identity)
+# ----------------------------------------------------------------------------
+def uhifigan_generator(sd, c, excitation, kernel_size=7, downsample_scales=(8, 8, 2, 2),
+                       downsample_kernel_sizes=(16, 16, 4, 4), upsample_scales=(8, 8, 2, 2),
+                       upsample_kernel_sizes=(16, 16, 4, 4), resblock_kernel_sizes=(3, 7, 11),
+                       resblock_dilations=((1, 3, 5), (1, 3, 5), (1, 3, 5)), use_additional_convs=True, slope=0.1,
+                       **_unused):
+    """``UHiFiGANGenerator.forward`` (f0 is unused by the reference's forward)."""
+    nb = len(resblock_kernel_sizes)
+
+    def mrf(prefix, i, x):
+        cs = 0.0
+        for j in range(nb):
+            cs = cs + hifigan_resblock(sd, f"{prefix}.{i * nb + j}", x, resblock_kernel_sizes[j], resblock_dilations[j],
+                                       slope, use_additional_convs)
+        return cs / nb
+
+    hidden = F.leaky_relu(F.conv1d(excitation, get_weight(sd, "input_conv.0"), get_bias(sd, "input_conv.0"),
+                                   padding=(kernel_size - 1) // 2), slope)
+    residuals = []
+    for i, s in enumerate(downsample_scales):
+        hidden = mrf("downsamples_mrf", i, hidden)
+        p = f"downsamples.{i}.0"
+        hidden = F.leaky_relu(F.conv1d(hidden, get_weight(sd, p), get_bias(sd, p), stride=s, padding=s // 2 + s % 2), slope)
+        residuals.append(hidden)
+    residuals.reverse()
+    h = F.conv1d(c, get_weight(sd, "hidden_conv"), get_bias(sd, "hidden_conv"), padding=(kernel_size - 1) // 2)
+    for i, s in enumerate(upsample_scales):
+        h = torch.cat((h, residuals[i]), dim=1)
+        p = f"upsamples.{i}.1"
+        h = F.conv_transpose1d(F.leaky_relu(h, slope), get_weight(sd, p), get_bias(sd, p), stride=s,
+                               padding=s // 2 + s % 2, output_padding=s % 2)
+        h = mrf("upsamples_mrf", i, h)
+    p = "output_conv.1"
+    return torch.tanh(F.conv1d(F.leaky_relu(h, 0.01), get_weight(sd, p), get_bias(sd, p), padding=(kernel_size - 1) // 2))

@@ -587,6 +587,37 @@ __global__ void softmax_gate_bwd_kernel(const float* z, const float* dy, float* 
   }
 }
 
+// ---- UHiFiGAN pieces (models/uhifigan.py) ---------------------------------------------------------
+// y[b][c_off + c][t] = x[b][c][t] for c < c_src (y has c_dst channels): the two halves of torch.cat(dim=1);
+// reverse = true copies the slice of y back into x (the backward of the concatenation)
+__global__ void copy_channels_kernel(float* x, float* y, int batch, int c_src, int c_dst, int c_off, long t,
+                                     int reverse) {
+  const long n = (long)batch * c_src * t;
+  GRID_STRIDE(i, n) {
+    const long tt = i % t;
+    const long r = i / t;
+    const int c = (int)(r % c_src);
+    const long b = r / c_src;
+    const long j = (b * c_dst + c_off + c) * t + tt;
+    if (reverse) x[i] = y[j];
+    else y[j] = x[i];
+  }
+}
+// torch.nn.Dropout (training): keep with probability 1 - p, scale kept values by 1 / (1 - p).  The mask
+// comes from a counter-based hash of (seed, element index), so backward regenerates it from the seed.
+__device__ __forceinline__ unsigned hash_u32(unsigned long long v) {
+  v ^= v >> 33;
+  v *= 0xff51afd7ed558ccdULL;
+  v ^= v >> 33;
+  v *= 0xc4ceb9fe1a85ec53ULL;
+  v ^= v >> 33;
+  return (unsigned)v;
+}
+__global__ void dropout_kernel(const float* x, float* y, long n, float p, float scale, unsigned long long seed) {
+  const unsigned thr = (unsigned)((double)p * 4294967296.0);  // drop when hash < thr
+  GRID_STRIDE(i, n) y[i] = hash_u32(seed * 0x9E3779B97F4A7C15ULL + (unsigned long long)i) >= thr ? x[i] * scale : 0.f;
+}
+
 // pcm[i] = (int16) rint(clamp(x[i], -1, 1) * 32767)   (the PCM_16 write of bin/decode.py:235-243)
 __global__ void wave_to_pcm16_kernel(const float* x, short* pcm, long n) {
   GRID_STRIDE(i, n) {
@@ -976,5 +1007,22 @@ extern "C" int pwg_softmax_gate_backward(const float* z, const float* dy, float*
   PWG_REQUIRE(z && dy && dz, PWG_ERR_NULL, "softmax_gate_backward: NULL pointer");
   PWG_REQUIRE(batch > 0 && channels > 0 && t > 0, PWG_ERR_BAD_SHAPE, "softmax_gate: bad shape");
   LAUNCH1D(softmax_gate_bwd_kernel, (long)batch * t, stream, z, dy, dz, batch, channels, (long)t, use_softmax);
+  return PWG_OK;
+}
+
+// ---- UHiFiGAN pieces ------------------------------------------------------------------------------
+extern "C" int pwg_copy_channels(float* x, float* y, int32_t batch, int32_t c_src, int32_t c_dst, int32_t c_off,
+                                 int64_t t, int32_t reverse, void* stream) {
+  PWG_REQUIRE(x && y, PWG_ERR_NULL, "copy_channels: NULL pointer");
+  PWG_REQUIRE(batch > 0 && c_src > 0 && c_off >= 0 && c_off + c_src <= c_dst && t > 0, PWG_ERR_BAD_SHAPE,
+              "copy_channels: bad shape");
+  LAUNCH1D(copy_channels_kernel, (long)batch * c_src * t, stream, x, y, batch, c_src, c_dst, c_off, (long)t, reverse);
+  return PWG_OK;
+}
+
+extern "C" int pwg_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream) {
+  PWG_REQUIRE(x && y, PWG_ERR_NULL, "dropout: NULL pointer");
+  PWG_REQUIRE(n > 0 && p >= 0.f && p < 1.f, PWG_ERR_BAD_SHAPE, "dropout: bad arguments");
+  LAUNCH1D(dropout_kernel, (long)n, stream, x, y, (long)n, p, 1.f / (1.f - p), (unsigned long long)seed);
   return PWG_OK;
 }

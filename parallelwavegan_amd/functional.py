@@ -441,6 +441,62 @@ class SoftmaxGateFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------
+# UHiFiGAN pieces
+# ---------------------------------------------------------------------------------------------
+class ConcatChannelsFn(torch.autograd.Function):
+    """torch.cat((a, b), dim=1) for (B, C, T) tensors as two strided copies."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        _require_device(a, b)
+        bsz, ca, t = a.shape
+        cb = b.shape[1]
+        assert b.shape[0] == bsz and b.shape[2] == t, (tuple(a.shape), tuple(b.shape))
+        y = torch.empty((bsz, ca + cb, t), device=a.device, dtype=torch.float32)
+        for src, off in ((a, 0), (b, ca)):
+            _lib.check(_L().pwg_copy_channels(_ptr(src), _ptr(y), bsz, src.shape[1], ca + cb, off, t, 0, _stream()),
+                       "copy_channels")
+        ctx.cfg = (bsz, ca, cb, t)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        bsz, ca, cb, t = ctx.cfg
+        dy = _c(dy)
+        outs = []
+        for i, (c, off) in enumerate(((ca, 0), (cb, ca))):
+            if not ctx.needs_input_grad[i]:
+                outs.append(None)
+                continue
+            d = torch.empty((bsz, c, t), device=dy.device, dtype=torch.float32)
+            _lib.check(_L().pwg_copy_channels(_ptr(d), _ptr(dy), bsz, c, ca + cb, off, t, 1, _stream()), "copy_channels")
+            outs.append(d)
+        return tuple(outs)
+
+
+class DropoutFn(torch.autograd.Function):
+    """Training-mode dropout with a counter-based mask (regenerated from the seed in backward)."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x = _c(x)
+        _require_device(x)
+        y = torch.empty_like(x)
+        _lib.check(_L().pwg_dropout(_ptr(x), _ptr(y), x.numel(), float(p), int(seed), _stream()), "dropout")
+        ctx.cfg = (float(p), int(seed))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed = ctx.cfg
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        _lib.check(_L().pwg_dropout(_ptr(dy), _ptr(dx), dy.numel(), p, seed, _stream()), "dropout")
+        return dx, None, None
+
+
+# ---------------------------------------------------------------------------------------------
 # spectral-loss pieces
 # ---------------------------------------------------------------------------------------------
 class FrameFoldFn(torch.autograd.Function):

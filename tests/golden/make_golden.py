@@ -413,7 +413,23 @@ def style_melgan(name, seed):
           float(np.abs(out["default_head"]).max()), float(np.abs(out["d_logits"]).max()))
 
 
+def uhifigan(name, seed):
+    """UHiFiGAN generator in eval mode (dropout off): c (2, 80, 24), excitation (2, 1, 192)."""
+    import parallel_wavegan.models as RM
+
+    g = RM.UHiFiGANGenerator(**synth.UHIFIGAN_TINY).eval()
+    gs = 0.6  # keeps the tanh output away from saturation
+    g.load_state_dict(synth.synth_state_dict(g.state_dict(), seed=seed, g_scale=gs))
+    c = synth.synth_input("c", (2, 80, 24), seed=seed)
+    e = synth.synth_input("excitation", (2, 1, 24 * 8), seed=seed)
+    with torch.no_grad():
+        y = g(c, None, e)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), meta=np.array([seed]), g_scale=np.float64(gs), y=y.numpy())
+    print(name, tuple(y.shape), float(y.abs().max()))
+
+
 JOBS = {
+    "uhifigan": lambda: uhifigan("uhifigan", 97),
     "style_melgan": lambda: style_melgan("style_melgan", 95),
     "causal_variants": lambda: causal_variants("causal_variants", 91),
     "hifigan_v1_g": lambda: hifigan_generator("hifigan_v1_g", synth.HIFIGAN_V1, 2, 32, 11),

@@ -130,3 +130,9 @@ STYLE_MELGAN_TINY = dict(in_channels=16, aux_channels=80, channels=32, out_chann
 STYLE_MELGAN_TINY_SIGMOID = dict(STYLE_MELGAN_TINY, gated_function="sigmoid", kernel_size=5)
 STYLE_MELGAN_D = dict(repeats=2)
 PQMF_BUFFERS = ("analysis_filter", "synthesis_filter", "updown_filter")  # fixed filters, not synthesised
+
+# ---- UHiFiGAN: a small configuration (factor 4 * 2 = 8 samples per frame)
+# (the decoder mirrors the encoder: upsample scales are the downsample scales reversed)
+UHIFIGAN_TINY = dict(in_channels=80, out_channels=1, channels=16, kernel_size=7, downsample_scales=(4, 2),
+                     downsample_kernel_sizes=(8, 4), upsample_scales=(2, 4), upsample_kernel_sizes=(4, 8),
+                     resblock_kernel_sizes=(3, 7), resblock_dilations=[(1, 3, 5), (1, 3)], dropout=0.3)

@@ -124,3 +124,16 @@ def test_style_melgan_oracle_matches_reference_golden():
         outs = torch_cpu.style_melgan_discriminator(sd, x, [int(s) for s in gold["d_starts"]], **synth.STYLE_MELGAN_D)
         logits = np.stack([o[-1].numpy() for o in outs])
         assert max_abs(logits, gold["d_logits"]) < 1e-5
+
+
+def test_uhifigan_oracle_matches_reference_golden():
+    from parallelwavegan_amd.models import UHiFiGANGenerator
+
+    gold = load_golden("uhifigan")
+    seed = int(gold["meta"][0])
+    sd = synth_for(UHiFiGANGenerator(**synth.UHIFIGAN_TINY), seed, float(gold["g_scale"]))
+    c = synth.synth_input("c", (2, 80, 24), seed=seed)
+    e = synth.synth_input("excitation", (2, 1, 24 * 8), seed=seed)
+    with torch.no_grad():
+        y = torch_cpu.uhifigan_generator(sd, c, e, **synth.UHIFIGAN_TINY)
+    assert max_abs(y, gold["y"]) < 1e-5
