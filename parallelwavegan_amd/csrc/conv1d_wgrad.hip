@@ -184,11 +184,8 @@ __global__ __launch_bounds__(256, (TG > 7 ? 1 : 2)) void conv1d_wgrad_kernel(WgA
         }
       }
     } else {
-      // Edge chunk: the WHOLE row (XS - 1 floats = every position the MFMA loop can read) is written,
-      // with zeros past the data.  Columns beyond n_cols meet G = 0 in the contraction, but 0 * stale
-      // LDS content is NaN when that content happens to be a NaN/Inf bit pattern.
 #pragma unroll 1
-      for (int e0 = 0; e0 < XS - 1; e0 += 64) {
+      for (int e0 = 0; e0 < L; e0 += 64) {
         const int f = f0 + e0 + lane;
         const bool lane_ok = (unsigned)f < (unsigned)a.x_len && e0 + lane < L;
 #pragma unroll 1
@@ -197,6 +194,16 @@ __global__ __launch_bounds__(256, (TG > 7 ? 1 : 2)) void conv1d_wgrad_kernel(WgA
           const unsigned off = (lane_ok && i0 + r < a.ci_g) ? (unsigned)(rowbase + f) * 4u : OOB;
           __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr_t)(xs + r * XS + e0), 4, off, 0, 0, 0);
         }
+      }
+      // An edge chunk needs fewer columns than the MFMA loop reads (it always walks all TT columns): the
+      // rest of the row is zero-filled.  Those columns meet G = 0 in the contraction, but 0 * stale LDS
+      // content is NaN whenever that content happens to be a NaN/Inf bit pattern (seen as a rare
+      // failure on a cold GPU; tools/probes/wgrad_stale_lds.py reproduces it).
+#pragma unroll 1
+      for (int e0 = (L + 63) & ~63; e0 < XS - 1; e0 += 64) {
+#pragma unroll 1
+        for (int r = wave; r < BT; r += 4)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr_t)(xs + r * XS + e0), 4, OOB, 0, 0, 0);
       }
     }
   };
@@ -219,6 +226,14 @@ __global__ __launch_bounds__(256, (TG > 7 ? 1 : 2)) void conv1d_wgrad_kernel(WgA
     const float* xt[TG];
 #pragma unroll
     for (int t = 0; t < TG; ++t) xt[t] = xrow + toff[t] + (S1 ? lhi : 0);
+    // MODE 2 state of the next load_ops call: column n = n0 + lhi, its in-row position w2 and tile offset xo2
+    int w2 = 0, xo2 = 0;
+    if (MODE == 2) {
+      const int n = n0 + lhi;
+      const int h = n / W;
+      w2 = n - h * W;
+      xo2 = (h - h0) * a.stride * W + w2;
+    }
     // operands of one reduction step (2 columns): 1 G value + TG X values per lane
     auto load_ops = [&](int step, float& av, float(&bv)[TG]) {
       const int cb = step >> 4;  // 32-column block of columns (2*step, 2*step+1)
@@ -231,9 +246,16 @@ __global__ __launch_bounds__(256, (TG > 7 ? 1 : 2)) void conv1d_wgrad_kernel(WgA
       } else if (MODE == 3) {
         xo = (2 * step + lhi) * a.stride;
       } else {
-        const int n = n0 + 2 * step + lhi;
-        const int h = n / W;
-        xo = (h - h0) * a.stride * W + (n - h * W);
+        // (k,1) Conv2d: column n = h * W + w lives at (h - h0) * stride * W + w of the tile.  The calls
+        // walk the steps in order, so (w, xo) are carried: +2 columns per step, one conditional wrap
+        // (W >= 2) instead of an integer division per step.
+        xo = xo2;
+        w2 += 2;
+        xo2 += 2;
+        if (w2 >= W) {
+          w2 -= W;
+          xo2 += (a.stride - 1) * W;
+        }
       }
 #pragma unroll
       for (int t = 0; t < TG; ++t) bv[t] = xt[t][xo];
@@ -420,7 +442,11 @@ static WgPlan wgrad_plan(int co_g, int ci_g, int groups, int k, int stride, int 
     int best = 1 << 30;
     p.tg = 1;
     for (int tg = 1; tg <= 7; ++tg) {  // ties go to the smaller (higher-occupancy, no padded taps) group
-      const int cost = ceil_div(k, tg) * (tg + 2);
+      // far-apart taps (period 11 flattened: dilation 11) widen the shared X tile; past 80 KB only one
+      // workgroup fits a CU, which costs more than re-staging the tile for a second tap group
+      int xs;
+      const size_t lds = wgrad_lds(false, false, tg, 32, stride, dil, width, k, &xs);
+      const int cost = ceil_div(k, tg) * (tg + 2) * (lds > 80 * 1024 ? 3 : 2);
       if (cost < best) {
         best = cost;
         p.tg = tg;
