@@ -455,19 +455,38 @@ static WgPlan wgrad_plan(int co_g, int ci_g, int groups, int k, int stride, int 
     p.taps_block = p.tg;
   }
   const int bt = p.small ? 32 : 64;
-  const int ntaps_max = k < p.taps_block ? k : p.taps_block;
-  p.win = stride == 1 && width == 1 && (ntaps_max - 1) * dil > 96;  // taps far apart: per-tap windows
-  // longest chunk whose double-buffered tiles keep two workgroups per CU (<= 80 KB), at most ~n_cols
-  p.tt = 32;
-  for (int tt = p.small ? 128 : 32; tt >= 32; tt >>= 1) {
-    int xs;
-    if (tt > 32 && tt > n_cols) continue;
-    if (wgrad_lds(p.small, p.win, p.taps_block, tt, stride, dil, width, k, &xs) <= 80 * 1024) {
-      p.tt = tt;
-      break;
+  // Many far-apart taps (e.g. k = 41 with dilation 5) can exceed the LDS even with per-tap windows:
+  // fall back to fewer taps per workgroup (more tap groups) until the tiles fit.
+  static const int small_tgs[] = {11, 6, 4, 3, 2, 1};
+  for (;;) {
+    const int ntaps_max = k < p.taps_block ? k : p.taps_block;
+    p.win = stride == 1 && width == 1 && (ntaps_max - 1) * dil > 96;  // taps far apart: per-tap windows
+    // longest chunk whose double-buffered tiles keep two workgroups per CU (<= 80 KB), at most ~n_cols
+    p.tt = 32;
+    for (int tt = p.small ? 128 : 32; tt >= 32; tt >>= 1) {
+      int xs;
+      if (tt > 32 && tt > n_cols) continue;
+      if (wgrad_lds(p.small, p.win, p.taps_block, tt, stride, dil, width, k, &xs) <= 80 * 1024) {
+        p.tt = tt;
+        break;
+      }
+    }
+    p.lds = wgrad_lds(p.small, p.win, p.taps_block, p.tt, stride, dil, width, k, &p.xs_stride);
+    if (p.lds <= 160 * 1024 || p.tg == 1) break;
+    if (p.small) {
+      int next = 1;
+      for (int v : small_tgs)
+        if (v < p.tg) {
+          next = v;
+          break;
+        }
+      p.tg = next;
+      p.taps_block = 4 * p.tg;
+    } else {
+      p.tg -= 1;
+      p.taps_block = p.tg;
     }
   }
-  p.lds = wgrad_lds(p.small, p.win, p.taps_block, p.tt, stride, dil, width, k, &p.xs_stride);
   p.chunks_per_item = ceil_div(n_cols, p.tt);
   p.chunks_total = p.chunks_per_item * batch;
   p.tap_groups = ceil_div(k, p.taps_block);
