@@ -50,6 +50,29 @@ def run(n_cases, seed):
             y_ref = F.conv_transpose1d(xa, w, bias, stride=stride, padding=pad, output_padding=out_pad, groups=groups)
             desc = ops.make_conv_desc(b, cin, cout, t, t_out, k, stride, 1, pad, groups, transposed=True,
                                       pre_act="leaky_relu" if slope is not None else None, pre_slope=slope or 0.0)
+        elif rng.rand() < 0.3:
+            # (k, 1) Conv2d over (rows, width): the period-discriminator pattern, incl. long reductions over
+            # few columns (split-K candidates)
+            width = int(rng.choice([2, 3, 5, 7, 11]))
+            cin = int(rng.choice([1, 32, 128, 512, 1024]))
+            cout = int(rng.choice([1, 32, 128, 1024]))
+            groups = 1
+            k = int(rng.choice([3, 5]))
+            stride = int(rng.choice([1, 3]))
+            pad = (k - 1) // 2
+            h = int(rng.choice([4, 10, 21, 51, 90]))
+            h_out = (h + 2 * pad - k) // stride + 1
+            if h_out <= 0:
+                continue
+            b = int(rng.choice([1, 2, 4]))
+            x = torch.randn(b, cin, h, width, generator=g, requires_grad=True)
+            w = (torch.randn(cout, cin, k, 1, generator=g) / (cin * k) ** 0.5).requires_grad_()
+            bias = torch.randn(cout, generator=g, requires_grad=True)
+            xa = F.leaky_relu(x, slope) if slope is not None else x
+            y_ref = F.conv2d(xa, w, bias, stride=(stride, 1), padding=(pad, 0))
+            desc = ops.make_conv_desc(b, cin, cout, h, h_out, k, stride, 1, pad, 1, width=width,
+                                      pre_act="leaky_relu" if slope is not None else None, pre_slope=slope or 0.0)
+            t = h
         else:
             k = int(rng.choice([1, 2, 3, 5, 7, 9, 11, 15, 41]))
             stride = int(rng.choice([1, 1, 1, 2, 3, 4]))
@@ -69,12 +92,16 @@ def run(n_cases, seed):
         dy = torch.randn(y_ref.shape, generator=g)
         y_ref.backward(dy)
         xd, wd, bd, dyd = (v.detach().to(dev).contiguous() for v in (x, w, bias, dy))
+        if x.dim() == 4:  # device side works on (B, C, rows * width)
+            xd, dyd = xd.reshape(b, cin, -1), dyd.reshape(b, cout, -1)
         tag = (f"case {case}: tr={int(transposed)} B={b} Cin={cin} Cout={cout} T={t}->{y_ref.shape[-1]} k={k} "
                f"s={stride} g={groups} slope={slope}")
         try:
             y = ops.conv1d_forward(desc, xd, ops.pack_weight(desc, wd), bd)
             dx = ops.conv1d_backward_data(desc, dyd, ops.pack_weight_bwd(desc, wd), xd)
             dw, db = ops.conv1d_backward_weight(desc, xd, dyd, tuple(w.shape))
+            if x.dim() == 4:
+                y, dx = y.reshape(y_ref.shape), dx.reshape(x.shape)
         except RuntimeError as e:
             if "unsupported" in str(e).lower() or "dilation with stride" in str(e):
                 continue
