@@ -434,7 +434,9 @@ static WgPlan wgrad_plan(int co_g, int ci_g, int groups, int k, int stride, int 
   p.small = co_g <= 32 || ci_g <= 32;
   if (p.small) {
     const int per_wave = ceil_div(k, 4);
-    p.tg = per_wave <= 1 ? 1 : per_wave <= 2 ? 2 : per_wave <= 3 ? 3 : per_wave <= 4 ? 4 : per_wave <= 6 ? 6 : 11;
+    // at most 4 accumulators per wave: with 6 or 11 (k = 41: all taps in one workgroup) the kernel drops
+    // to one wave per SIMD and runs 1.5x slower than three tap groups of 16 taps (tools/bench_wgrad.py)
+    p.tg = per_wave <= 1 ? 1 : per_wave <= 2 ? 2 : per_wave <= 3 ? 3 : 4;
     p.taps_block = 4 * p.tg;
   } else {
     // taps per workgroup: every tap group costs its MFMAs (TG, padded taps included) plus a fixed
@@ -457,7 +459,7 @@ static WgPlan wgrad_plan(int co_g, int ci_g, int groups, int k, int stride, int 
   const int bt = p.small ? 32 : 64;
   // Many far-apart taps (e.g. k = 41 with dilation 5) can exceed the LDS even with per-tap windows:
   // fall back to fewer taps per workgroup (more tap groups) until the tiles fit.
-  static const int small_tgs[] = {11, 6, 4, 3, 2, 1};
+  static const int small_tgs[] = {4, 3, 2, 1};
   for (;;) {
     const int ntaps_max = k < p.taps_block ? k : p.taps_block;
     p.win = stride == 1 && width == 1 && (ntaps_max - 1) * dil > 96;  // taps far apart: per-tap windows
@@ -676,9 +678,7 @@ extern "C" int pwg_conv1d_backward_weight(const pwg_conv1d_desc* d_in, const flo
       case 1: WG_CASE(1, true);
       case 2: WG_CASE(2, true);
       case 3: WG_CASE(3, true);
-      case 4: WG_CASE(4, true);
-      case 6: WG_CASE(6, true);
-      default: WG_CASE(11, true);
+      default: WG_CASE(4, true);
     }
   }
 #undef WG_CASE
