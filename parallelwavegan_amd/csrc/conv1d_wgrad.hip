@@ -439,16 +439,20 @@ static WgPlan wgrad_plan(int co_g, int ci_g, int groups, int k, int stride, int 
     p.tg = per_wave <= 1 ? 1 : per_wave <= 2 ? 2 : per_wave <= 3 ? 3 : 4;
     p.taps_block = 4 * p.tg;
   } else {
-    // taps per workgroup: every tap group costs its MFMAs (TG, padded taps included) plus a fixed
-    // staging overhead worth about two taps
-    int best = 1 << 30;
+    // Taps per workgroup (tools/bench_wgrad.py sweep).  A tap group costs its MFMAs -- TG accumulators,
+    // padded taps included, slower per MFMA when the registers allow only 2 workgroups per CU (TG >= 6)
+    // -- plus the staging of its X tile, which is `stride` times wider for strided convolutions.  More
+    // groups also mean fewer reduction slices per group (fewer slabs).  k = 11 -> 4 groups of 3;
+    // k = 7 -> 7; k = 5 -> 5; k = 41 stride 4 -> 6 groups of 7.
+    float best = 1e30f;
     p.tg = 1;
-    for (int tg = 1; tg <= 7; ++tg) {  // ties go to the smaller (higher-occupancy, no padded taps) group
+    for (int tg = 1; tg <= 7; ++tg) {  // ties go to the smaller group
       // far-apart taps (period 11 flattened: dilation 11) widen the shared X tile; past 80 KB only one
       // workgroup fits a CU, which costs more than re-staging the tile for a second tap group
       int xs;
       const size_t lds = wgrad_lds(false, false, tg, 32, stride, dil, width, k, &xs);
-      const int cost = ceil_div(k, tg) * (tg + 2) * (lds > 80 * 1024 ? 3 : 2);
+      const float per_mfma = tg <= 3 ? 1.0f : tg <= 5 ? 1.05f : 1.25f;
+      const float cost = ceil_div(k, tg) * (tg * per_mfma + 0.5f * stride) * (lds > 80 * 1024 ? 1.5f : 1.0f);
       if (cost < best) {
         best = cost;
         p.tg = tg;
