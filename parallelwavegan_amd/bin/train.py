@@ -492,10 +492,12 @@ class Collater(object):
     Input: list of ``(audio[T], mel[T', C])`` numpy pairs (the dataset contract of SURVEY.md s2).
     Output: ``((z,) c), y`` with ``c`` (B, C, batch_max_frames + 2 * aux_context_window), ``y`` (B, 1,
     batch_max_steps) and, for Parallel WaveGAN (``use_noise_input``), ``z ~ N(0, 1)`` like ``y``.
+    With ``use_f0_and_excitation`` (UHiFiGAN) the items are ``(audio, mel, f0[T'], excitation[T', hop])``
+    and the inputs become ``(c, f0 (B, 1, F), excitation (B, 1, F * hop))`` cut with the same frame window.
     Utterances whose mel is not longer than the crop are dropped.  ``pin_memory=True`` returns pinned
     tensors so that the trainer's ``.to(device, non_blocking=True)`` overlaps the copy with compute.
-    The variants for F0/excitation, duration or global/local conditioning inputs belong to model
-    families outside the accelerated hot path and raise.
+    The variants for duration or global/local conditioning inputs belong to model families outside
+    the accelerated hot path and raise.
     """
 
     def __init__(self, batch_max_steps=20480, hop_size=256, aux_context_window=2, use_noise_input=False,
@@ -504,8 +506,11 @@ class Collater(object):
         import numpy as np
 
         self._np = np
-        if use_f0_and_excitation or use_duration or use_global_condition or use_local_condition or not use_aux_input:
-            raise NotImplementedError("only the mel -> waveform collation (configs C1-C5) is provided")
+        if use_duration or use_global_condition or use_local_condition or not use_aux_input:
+            raise NotImplementedError("only the mel -> waveform collation (configs C1-C5, UHiFiGAN) is provided")
+        if use_f0_and_excitation and use_noise_input:
+            raise NotImplementedError("noise input together with f0/excitation is not used by any model")
+        self.use_f0_and_excitation = use_f0_and_excitation
         if batch_max_steps % hop_size != 0:
             batch_max_steps -= batch_max_steps % hop_size
         self.hop_size = hop_size
@@ -518,27 +523,36 @@ class Collater(object):
         self.end_offset = -(self.batch_max_frames + aux_context_window)
         self.mel_threshold = self.batch_max_frames + 2 * aux_context_window
 
-    def _adjust_length(self, x, c):
+    def _adjust_length(self, x, c, *extra):
         np = self._np
         if len(x) < len(c) * self.hop_size:
             x = np.pad(x, (0, len(c) * self.hop_size - len(x)), mode="edge")
         assert len(x) == len(c) * self.hop_size, (len(x), len(c), self.hop_size)
-        return x, c
+        return (x, c) + tuple(extra)
 
     def __call__(self, batch):
         np = self._np
         items = [self._adjust_length(*b) for b in batch if len(b[1]) > self.mel_threshold]
         acw, frames = self.aux_context_window, self.batch_max_frames
-        ys, cs = [], []
-        for x, c in items:
-            start = np.random.randint(self.start_offset, len(c) + self.end_offset)
+        ys, cs, fs, es = [], [], [], []
+        # (all start frames are drawn first, item by item, as the reference does: same numpy stream)
+        starts = [np.random.randint(self.start_offset, len(it[1]) + self.end_offset) for it in items]
+        for it, start in zip(items, starts):
+            x, c = it[0], it[1]
             ys.append(x[start * self.hop_size: start * self.hop_size + self.batch_max_steps])
             cs.append(c[start - acw: start + frames + acw])
+            if self.use_f0_and_excitation:
+                fs.append(it[2][start - acw: start + frames + acw])
+                es.append(it[3][start - acw: start + frames + acw])
         y = torch.from_numpy(np.ascontiguousarray(np.stack(ys), dtype=np.float32)).unsqueeze(1)
         c = torch.from_numpy(np.ascontiguousarray(np.stack(cs), dtype=np.float32)).transpose(2, 1).contiguous()
         inputs = (c,)
         if self.use_noise_input:
             inputs = (torch.randn(y.size()),) + inputs
+        if self.use_f0_and_excitation:
+            f = torch.from_numpy(np.ascontiguousarray(np.stack(fs), dtype=np.float32)).unsqueeze(1)
+            e = torch.from_numpy(np.ascontiguousarray(np.stack(es), dtype=np.float32))
+            inputs = inputs + (f, e.reshape(e.shape[0], 1, -1))
         if self.pin_memory:
             y = y.pin_memory()
             inputs = tuple(t.pin_memory() for t in inputs)

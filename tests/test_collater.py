@@ -36,3 +36,38 @@ def test_collater_without_noise_and_length_fix():
     x, c = _utt(20, 256, rng)
     (cb,), y = col([(x[:-5], c)])  # short audio is edge-padded to frames * hop
     assert cb.shape == (1, 80, 10) and y.shape == (1, 1, 2560)
+
+
+def test_collater_matches_reference_collater():
+    """Same numpy seed -> the same batches as the reference's Collater (bin/train.py:646-896), for the
+    plain, the noise-input (PWG) and the f0/excitation (UHiFiGAN) variants.  Build container only."""
+    import pytest
+
+    from oracle import ref_shim
+
+    if not ref_shim.available():
+        pytest.skip("/root/reference is not present")
+    ref_shim.install()
+    from parallel_wavegan.bin.train import Collater as RefCollater
+
+    rng = np.random.default_rng(2)
+    hop = 64
+    items = []
+    for frames in (50, 33, 90, 41):
+        x, c = _utt(frames, hop, rng)
+        f0 = rng.standard_normal(frames).astype(np.float32)
+        ex = rng.standard_normal((frames, hop)).astype(np.float32)
+        items.append((x, c, f0, ex))
+    for kw, n in ((dict(), 2), (dict(use_noise_input=True), 2), (dict(use_f0_and_excitation=True), 4)):
+        args = dict(batch_max_steps=32 * hop, hop_size=hop, aux_context_window=2, **kw)
+        batch = [it[:n] for it in items]
+        np.random.seed(5)
+        torch.manual_seed(5)
+        want_in, want_y = RefCollater(**args)(batch)
+        np.random.seed(5)
+        torch.manual_seed(5)
+        got_in, got_y = Collater(**args)(batch)
+        assert torch.equal(got_y, want_y)
+        assert len(got_in) == len(want_in)
+        for a, b in zip(got_in, want_in):
+            assert a.shape == b.shape and torch.equal(a, b), kw
