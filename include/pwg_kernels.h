@@ -253,9 +253,11 @@ int pwg_softmax_gate_backward(const float* z, const float* dy, float* dz, int32_
 int pwg_copy_channels(float* x, float* y, int32_t batch, int32_t c_src, int32_t c_dst, int32_t c_off,
                       int64_t t, int32_t reverse, void* stream);
 /* torch.nn.Dropout in training mode (uhifigan.py:86,130): y = x * keep / (1 - p) with a counter-based
- * mask hash(seed, index) >= p * 2^32; calling it again with the same seed on the output gradient is
- * the backward.  (Different random stream than torch's Philox: same distribution, other draws.)      */
-int pwg_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
+ * mask hash(seed + *seed_dev, index) >= p * 2^32; calling it again with the same seeds on the output
+ * gradient is the backward.  seed_dev (optional device scalar) lets a captured hipGraph draw a new mask
+ * at every replay.  (Different random stream than torch's Philox: same distribution, other draws.)    */
+int pwg_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, const uint64_t* seed_dev,
+                void* stream);
 
 /* ---- training input assembly (bin/train.py:646-896 Collater, mel -> waveform branch) ---- */
 /* Random-crop batch from a device-resident corpus: audio / mel are the utterances concatenated

@@ -75,7 +75,7 @@ SIGNATURES = {
     "pwg_add3_div": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _vp]),
     "pwg_wave_to_pcm16": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
     "pwg_copy_channels": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i32, _vp]),
-    "pwg_dropout": (ctypes.c_int, [_vp, _vp, _i64, _f32, ctypes.c_uint64, _vp]),
+    "pwg_dropout": (ctypes.c_int, [_vp, _vp, _i64, _f32, ctypes.c_uint64, _vp, _vp]),
     "pwg_instance_norm_forward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "pwg_instance_norm_backward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "pwg_upsample_nearest_forward": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),

@@ -613,7 +613,9 @@ __device__ __forceinline__ unsigned hash_u32(unsigned long long v) {
   v ^= v >> 33;
   return (unsigned)v;
 }
-__global__ void dropout_kernel(const float* x, float* y, long n, float p, float scale, unsigned long long seed) {
+__global__ void dropout_kernel(const float* x, float* y, long n, float p, float scale, unsigned long long seed,
+                               const unsigned long long* seed_dev) {
+  if (seed_dev) seed += *seed_dev;  // device-resident part of the seed (advances between hipGraph replays)
   const unsigned thr = (unsigned)((double)p * 4294967296.0);  // drop when hash < thr
   GRID_STRIDE(i, n) y[i] = hash_u32(seed * 0x9E3779B97F4A7C15ULL + (unsigned long long)i) >= thr ? x[i] * scale : 0.f;
 }
@@ -1020,9 +1022,11 @@ extern "C" int pwg_copy_channels(float* x, float* y, int32_t batch, int32_t c_sr
   return PWG_OK;
 }
 
-extern "C" int pwg_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream) {
+extern "C" int pwg_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, const uint64_t* seed_dev,
+                           void* stream) {
   PWG_REQUIRE(x && y, PWG_ERR_NULL, "dropout: NULL pointer");
   PWG_REQUIRE(n > 0 && p >= 0.f && p < 1.f, PWG_ERR_BAD_SHAPE, "dropout: bad arguments");
-  LAUNCH1D(dropout_kernel, (long)n, stream, x, y, (long)n, p, 1.f / (1.f - p), (unsigned long long)seed);
+  LAUNCH1D(dropout_kernel, (long)n, stream, x, y, (long)n, p, 1.f / (1.f - p), (unsigned long long)seed,
+           (const unsigned long long*)seed_dev);
   return PWG_OK;
 }

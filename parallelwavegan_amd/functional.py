@@ -476,15 +476,19 @@ class ConcatChannelsFn(torch.autograd.Function):
 
 
 class DropoutFn(torch.autograd.Function):
-    """Training-mode dropout with a counter-based mask (regenerated from the seed in backward)."""
+    """Training-mode dropout with a counter-based mask (regenerated from the seeds in backward).
+    ``seed_dev``: optional int64 device scalar added to the host seed inside the kernel, so that a
+    captured hipGraph draws a fresh mask at every replay."""
 
     @staticmethod
-    def forward(ctx, x, p, seed):
+    def forward(ctx, x, p, seed, seed_dev=None):
         x = _c(x)
         _require_device(x)
         y = torch.empty_like(x)
-        _lib.check(_L().pwg_dropout(_ptr(x), _ptr(y), x.numel(), float(p), int(seed), _stream()), "dropout")
+        sp = None if seed_dev is None else ctypes.c_void_p(seed_dev.data_ptr())
+        _lib.check(_L().pwg_dropout(_ptr(x), _ptr(y), x.numel(), float(p), int(seed), sp, _stream()), "dropout")
         ctx.cfg = (float(p), int(seed))
+        ctx.seed_dev = seed_dev
         return y
 
     @staticmethod
@@ -492,8 +496,9 @@ class DropoutFn(torch.autograd.Function):
         p, seed = ctx.cfg
         dy = _c(dy)
         dx = torch.empty_like(dy)
-        _lib.check(_L().pwg_dropout(_ptr(dy), _ptr(dx), dy.numel(), p, seed, _stream()), "dropout")
-        return dx, None, None
+        sp = None if ctx.seed_dev is None else ctypes.c_void_p(ctx.seed_dev.data_ptr())
+        _lib.check(_L().pwg_dropout(_ptr(dy), _ptr(dx), dy.numel(), p, seed, sp, _stream()), "dropout")
+        return dx, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------

@@ -21,19 +21,24 @@ __all__ = ["UHiFiGANGenerator"]
 
 
 class _Dropout(torch.nn.Module):
-    """torch.nn.Dropout stand-in (no parameters): identity in eval mode, HIP dropout kernel in training."""
+    """torch.nn.Dropout stand-in (no parameters, no state-dict entries): identity in eval mode, HIP
+    dropout kernel in training.  The mask seed is (host seed) + (a device counter that the forward
+    advances), so eager steps and hipGraph replays both draw a new mask every call."""
 
     def __init__(self, p):
         super().__init__()
         self.p = float(p)
-        self._calls = 0
+        self._counter = None  # int64 device scalar, created lazily on the input's device
 
     def forward(self, x):
         if not self.training or self.p == 0.0:
             return x
-        self._calls += 1
-        seed = (int(torch.initial_seed()) * 1000003 + id(self) % 65521 + self._calls * 7919) & ((1 << 63) - 1)
-        return Fn.DropoutFn.apply(x, self.p, seed)
+        if self._counter is None or self._counter.device != x.device:
+            self._counter = torch.zeros(1, dtype=torch.int64, device=x.device)
+        used = self._counter.clone()  # the value this call (and its backward) uses
+        self._counter += 7919           # plumbing: advance the device counter for the next call / replay
+        seed = (int(torch.initial_seed()) * 1000003 + id(self) % 65521) & ((1 << 62) - 1)
+        return Fn.DropoutFn.apply(x, self.p, seed, used)
 
     def extra_repr(self):
         return f"p={self.p}"

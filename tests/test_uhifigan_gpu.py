@@ -66,4 +66,21 @@ def test_dropout_and_concat_kernels(device):
     with torch.no_grad():
         y_eval = g.eval()(c, None, e)
         y_train = g.train()(c, None, e)
+        y_train2 = g(c, None, e)
     assert torch.isfinite(y_train).all() and not torch.equal(y_eval, y_train)
+    assert not torch.equal(y_train, y_train2)  # a new mask per call
+    # the mask also changes between replays of a captured hipGraph (device-resident seed counter)
+    from parallelwavegan_amd.models.uhifigan import _Dropout
+
+    drop = _Dropout(0.5).train()
+    xs = torch.ones(4096, device=device)
+    drop(xs)  # creates the counter outside the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ys = drop(xs)
+    graph.replay()
+    m1 = (ys != 0).clone()
+    graph.replay()
+    m2 = (ys != 0).clone()
+    assert 0.4 < m1.float().mean().item() < 0.6 and not torch.equal(m1, m2)
