@@ -186,7 +186,9 @@ class Trainer(object):
     def _graph_ok(self):
         cfg = self.config
         return (cfg.get("use_hip_graph", False)
-                and cfg.get("generator_grad_norm", -1) <= 0 and cfg.get("discriminator_grad_norm", -1) <= 0)
+                and cfg.get("generator_grad_norm", -1) <= 0 and cfg.get("discriminator_grad_norm", -1) <= 0
+                # models that take host-side random decisions per call (StyleMelGAN's random windows)
+                and all(getattr(self._module(k), "hip_graph_safe", True) for k in ("generator", "discriminator")))
 
     def _phases(self):
         cfg = self.config

@@ -132,6 +132,9 @@ class StyleMelGANDiscriminator(torch.nn.Module, _NormMixin):
     """Random-window discriminators on PQMF sub-bands (style_melgan.py:243-362).  Window positions are
     drawn with ``np.random.randint`` exactly like the reference (same draws for the same numpy seed)."""
 
+    # the window positions are chosen on the host at every call: a captured hipGraph would freeze them
+    hip_graph_safe = False
+
     def __init__(self, repeats=2, window_sizes=[512, 1024, 2048, 4096],
                  pqmf_params=[[1, None, None, None], [2, 62, 0.26700, 9.0], [4, 62, 0.14200, 9.0],
                               [8, 62, 0.07949, 9.0]],
