@@ -1,0 +1,64 @@
+"""GPU: the Trainer drives the StyleMelGAN and UHiFiGAN families end to end (forward, losses, backward,
+fused Adam) -- finite losses, parameters move, StyleMelGAN stays out of hipGraph capture (random windows)."""
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from parallelwavegan_amd import losses, models, optimizers
+from parallelwavegan_amd.bin.train import Trainer
+from tests.golden import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(device, gtype, g, d, batch, n_steps=3, use_graph=False):
+    model = {"generator": g.to(device), "discriminator": d.to(device)}
+    criterion = {"gen_adv": losses.GeneratorAdversarialLoss(), "dis_adv": losses.DiscriminatorAdversarialLoss(),
+                 "stft": losses.MultiResolutionSTFTLoss(fft_sizes=[256, 512], hop_sizes=[32, 64], win_lengths=[128, 256]).to(device)}
+    opt = {k: optimizers.Adam(model[k].parameters(), lr=1e-4, betas=(0.5, 0.9)) for k in model}
+    sched = {k: optimizers.lr_scheduler.StepLR(opt[k], step_size=10 ** 6, gamma=0.5) for k in model}
+    config = dict(generator_type=gtype, generator_params={"out_channels": 1}, use_stft_loss=True,
+                  use_subband_stft_loss=False, use_mel_loss=False, use_feat_match_loss=False, lambda_aux=1.0,
+                  lambda_adv=1.0, generator_grad_norm=-1, discriminator_grad_norm=-1,
+                  generator_train_start_steps=0, discriminator_train_start_steps=0, train_max_steps=100,
+                  save_interval_steps=10 ** 9, eval_interval_steps=10 ** 9, log_interval_steps=10 ** 9,
+                  distributed=False, rank=0, outdir=tempfile.mkdtemp(), progress=False, use_hip_graph=use_graph,
+                  graph_warmup_steps=1)
+    tr = Trainer(steps=1, epochs=0, data_loader={"train": [batch], "dev": [batch]}, sampler={"train": None, "dev": None},
+                 model=model, criterion=criterion, optimizer=opt, scheduler=sched, config=config, device=device)
+    tr.tqdm = None
+    before = [p.detach().clone() for p in g.parameters()]
+    for _ in range(n_steps):
+        tr._train_step(batch)
+    tr._flush_pending()
+    assert all(np.isfinite(v) for v in tr.total_train_loss.values()), dict(tr.total_train_loss)
+    assert any(not torch.equal(a, b) for a, b in zip(before, g.parameters()))
+    return tr
+
+
+def test_style_melgan_training_steps(device):
+    np.random.seed(0)
+    # the generator draws z of length 1, so a batch holds exactly noise_upsample_factor = 16 frames (x256)
+    cfg = dict(synth.STYLE_MELGAN_TINY, noise_upsample_scales=[4, 4], upsample_scales=[4, 4, 4, 4])
+    g = models.StyleMelGANGenerator(**cfg)
+    d = models.StyleMelGANDiscriminator(repeats=1, window_sizes=[128, 256, 512, 1024])
+    gen = torch.Generator().manual_seed(0)
+    c = torch.randn(2, 80, 16, generator=gen).to(device)
+    y = (0.3 * torch.randn(2, 1, 16 * 256, generator=gen)).to(device)
+    tr = _run(device, "StyleMelGANGenerator", g, d, ((c,), y), use_graph=True)
+    assert not tr._graphs  # the random-window discriminator opts out of capture
+
+
+def test_uhifigan_training_steps(device):
+    g = models.UHiFiGANGenerator(**synth.UHIFIGAN_TINY)
+    d = models.ParallelWaveGANDiscriminator(layers=4, conv_channels=16)
+    gen = torch.Generator().manual_seed(1)
+    frames = 256
+    c = torch.randn(2, 80, frames, generator=gen).to(device)
+    f0 = torch.rand(2, 1, frames, generator=gen).to(device)
+    e = torch.randn(2, 1, frames * 8, generator=gen).to(device)
+    y = (0.3 * torch.randn(2, 1, frames * 8, generator=gen)).to(device)
+    tr = _run(device, "UHiFiGANGenerator", g, d, ((c, f0, e), y), use_graph=True)
+    assert len(tr._graphs) == 1  # dropout inside a captured step (device-resident mask seed)
