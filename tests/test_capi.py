@@ -51,3 +51,49 @@ def test_ops_refuse_cpu_tensors():
     d = ops.make_conv_desc(1, 4, 4, 8, 8, 3, pad_left=1)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.conv1d_forward(d, torch.zeros(1, 4, 8), torch.zeros(16 * 32 * 3))
+
+
+def test_models_and_losses_have_no_cpu_path():
+    """The product path never computes on the host: every model family, the losses and the optimizers
+    raise on CPU tensors instead of falling back to ATen."""
+    import torch
+
+    from parallelwavegan_amd import losses, models, optimizers
+
+    g = models.HiFiGANGenerator(channels=16, upsample_scales=(2, 2), upsample_kernel_sizes=(4, 4),
+                                resblock_kernel_sizes=(3,), resblock_dilations=[(1,)])
+    cases = [
+        lambda: g(torch.zeros(1, 80, 8)),
+        lambda: models.ParallelWaveGANDiscriminator(layers=3, conv_channels=8)(torch.zeros(1, 1, 64)),
+        lambda: models.MelGANGenerator(channels=32, upsample_scales=[2, 2], stacks=1)(torch.zeros(1, 80, 8)),
+        lambda: models.StyleMelGANGenerator(in_channels=8, channels=16, noise_upsample_scales=[2],
+                                            upsample_scales=[2, 1])(torch.zeros(1, 80, 2), torch.zeros(1, 8, 1)),
+        lambda: models.UHiFiGANGenerator(channels=8, downsample_scales=(2,), downsample_kernel_sizes=(4,),
+                                         upsample_scales=(2,), upsample_kernel_sizes=(4,), resblock_kernel_sizes=(3,),
+                                         resblock_dilations=[(1,)])(torch.zeros(1, 80, 4), None, torch.zeros(1, 1, 8)),
+        lambda: losses.MultiResolutionSTFTLoss()(torch.zeros(1, 4096), torch.zeros(1, 4096)),
+        lambda: losses.MelSpectrogramLoss()(torch.zeros(1, 1, 4096), torch.zeros(1, 1, 4096)),
+    ]
+    for fn in cases:
+        with pytest.raises(RuntimeError, match="no CPU fallback|MI355X"):
+            fn()
+    p = torch.nn.Parameter(torch.zeros(4))
+    p.grad = torch.ones(4)
+    with pytest.raises(RuntimeError, match="no CPU fallback|MI355X"):
+        optimizers.Adam([p]).step()
+
+
+def test_workspace_queries_answer_without_a_gpu():
+    """Split-reduction workspaces are sized from the descriptor alone (caller-owned scratch)."""
+    import ctypes
+
+    from parallelwavegan_amd import _lib
+
+    big = ops.make_conv_desc(16, 128, 128, 51200, 51200, 11, pad_left=5)            # fills the chip: no slices
+    few = ops.make_conv_desc(16, 1024, 1024, 32, 32, 5, pad_left=2)                 # long reduction, 32 columns
+    l = _lib.lib()
+    assert l.pwg_conv1d_forward_workspace_floats(ctypes.byref(big)) == 0
+    n = l.pwg_conv1d_forward_workspace_floats(ctypes.byref(few))
+    assert n > 0 and n % (16 * 1024 * 32) == 0
+    assert l.pwg_conv1d_backward_data_workspace_floats(ctypes.byref(few)) > 0
+    assert l.pwg_conv1d_backward_weight_workspace_floats(ctypes.byref(big)) > 0
