@@ -56,7 +56,18 @@ def _worker(rank, world, port, out):
     (model(x_all[rank]).sum() * 0 + params[0].sum()).backward()
     red.finish()
     zero_ok = float(red.flat_grads[params[-1]].abs().max()) == 0.0
-    out[rank] = (err, none_left, zero_ok, len(red.buckets))
+    params[-1].requires_grad_(True)
+    # deferred mode (what a hipGraph capture / replay uses): hooks only fill the buckets, finish() launches
+    # nothing, exchange_all() performs the collectives -> same averaged gradients as the hook mode
+    red.defer = True
+    red.prepare()
+    torch.nn.functional.mse_loss(model(x_all[rank]), y_all[rank]).backward()
+    red.finish()
+    local_only = max((red.flat_grads[p] * scale - g0).abs().max().item() for p, g0 in zip(params, grads))
+    red.defer = False
+    red.exchange_all()
+    err_deferred = max((red.flat_grads[p] * scale - g0).abs().max().item() for p, g0 in zip(params, grads))
+    out[rank] = (err, none_left, zero_ok, len(red.buckets), local_only, err_deferred)
     dist.destroy_process_group()
 
 
@@ -72,6 +83,8 @@ def test_grad_reducer_world_size_2():
         p.join(120)
         assert p.exitcode == 0
     for r in range(2):
-        err, none_left, zero_ok, nb = out[r]
+        err, none_left, zero_ok, nb, local_only, err_deferred = out[r]
         assert err <= 1e-6, err
         assert none_left and zero_ok and nb >= 2
+        assert local_only > 1e-4        # before exchange_all the buckets hold this rank's gradients only
+        assert err_deferred <= 1e-6, err_deferred
