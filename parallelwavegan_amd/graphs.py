@@ -10,11 +10,19 @@ import torch
 
 class GraphedInference:
     """Capture ``model.forward`` for fixed input shapes; ``__call__`` copies the new inputs into the
-    static buffers and replays.  One graph per distinct input shape (cached)."""
+    static buffers and replays.  One graph per distinct input shape (cached).
+
+    The capture records the kernels that read the packed weight images of that moment: after the
+    parameters change (``load_state_dict``, an optimizer step) call :meth:`reset` so that the next
+    call captures again."""
 
     def __init__(self, model, warmup=2):
         self.model = model
         self.warmup = warmup
+        self._graphs = {}
+
+    def reset(self):
+        """Drop the captured graphs (parameters changed)."""
         self._graphs = {}
 
     def _capture(self, inputs):
