@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark: HiFi-GAN V1 (22.05 kHz) generator inference RTF^-1
-(audio samples / second) on MI355X, plus the same-box CPU baseline.
+(audio samples / second) on MI355X, the training steps/s of BASELINE configs C2 / C3 / C4,
+and the same-box CPU baseline.
 
 Contract (one JSON line on stdout from rank 0):
   python bench.py --gpus N --steps K --warmup W
@@ -9,7 +10,12 @@ synthetic mel frames (B utterances x F frames, mel ~ N(0,1), random-init weights
 of the V1 architecture, weight norm removed as bin/decode.py does).  N > 1 runs
 one replica per GPU on its own batch (utterances are independent: "replicas
 only", no data-path collective) -> weak scaling; value = total samples / max
-time over ranks.
+time over ranks.  The training measurements shard minibatches (data parallel,
+RCCL gradient all-reduce).
+
+``--gpus N`` with N > 1 and no launcher environment (WORLD_SIZE unset) re-launches this
+script once per GPU through parallelwavegan_amd.distributed.launch; under
+``python -m torch.distributed.run`` (the driver's way) the ranks are used as given.
 """
 import argparse
 import json
@@ -22,14 +28,21 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-HIFIGAN_V1 = dict(
-    in_channels=80, out_channels=1, channels=512, kernel_size=7, upsample_scales=[8, 8, 2, 2],
-    upsample_kernel_sizes=[16, 16, 4, 4], resblock_kernel_sizes=[3, 7, 11],
-    resblock_dilations=[[1, 3, 5], [1, 3, 5], [1, 3, 5]], use_additional_convs=True, bias=True,
-    nonlinear_activation="LeakyReLU", nonlinear_activation_params={"negative_slope": 0.1}, use_weight_norm=True,
-)
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 HBM_PEAK_GBS = 8000.0
+CONF_DIR = os.path.join(ROOT, "tests", "fixtures", "conf")
+# BASELINE.json configs[1..3] -> the reference recipe each is quoted on (tests/fixtures/make_conf.py)
+TRAIN_CONFIGS = {"c2": "parallel_wavegan.v1", "c3": "hifigan.v1", "c4": "multi_band_melgan.v2"}
+# SURVEY.md s8d: fwd = 1x, bwd = 2x, incl. the second no-grad G pass and the no-grad D(real) pass:
+# per item 4 * G(32 frames) + 10 * D(8192 samples)  (what the REFERENCE executes per C3 step)
+C3_REFERENCE_GFLOP_PER_ITEM = 4 * 19.65 + 10 * 12.08
+
+
+def load_conf(name):
+    import yaml
+
+    with open(os.path.join(CONF_DIR, name + ".yaml")) as f:
+        return yaml.load(f, Loader=yaml.Loader)
 
 
 def hifigan_macs_per_sample(cfg):
@@ -51,14 +64,17 @@ def hifigan_macs_per_sample(cfg):
     return macs
 
 
-def cpu_baseline(budget_s=12.0):
-    """The oracle (torch CPU restatement of the reference's ATen call sequence) timed on this
-    box's host cores: B=1, 100 mel frames per call (bin/decode.py is utterance-at-a-time)."""
+# ------------------------------------------------------------------------------------------------
+# CPU baselines (the oracle = torch-CPU restatement of the reference's ATen call sequence; the
+# reference package itself does not exist on the GPU box, hence kind "port")
+# ------------------------------------------------------------------------------------------------
+def cpu_baseline(g_params, budget_s=12.0):
+    """B=1, 100 mel frames per call (bin/decode.py is utterance-at-a-time)."""
     from oracle import torch_cpu
     from parallelwavegan_amd.models import HiFiGANGenerator
 
     cores = os.cpu_count() or 1
-    g = HiFiGANGenerator(**HIFIGAN_V1)
+    g = HiFiGANGenerator(**g_params)
     g.remove_weight_norm()
     sd = {k: v.detach() for k, v in g.state_dict().items()}
     frames = 100
@@ -66,7 +82,7 @@ def cpu_baseline(budget_s=12.0):
 
     def once():
         t0 = time.time()
-        y = torch_cpu.hifigan_generator(sd, c, **HIFIGAN_V1)
+        y = torch_cpu.hifigan_generator(sd, c, **g_params)
         return time.time() - t0, y
 
     with torch.no_grad():
@@ -89,47 +105,28 @@ def cpu_baseline(budget_s=12.0):
         "unit": "samples/s",
         "cores": torch.get_num_threads(),
         "kind": "port",
-        "sample": f"oracle.torch_cpu.hifigan_generator, B=1 x {frames} frames, best of {n} calls, "
-                  f"{nthreads} of {cores} host threads (fastest of {sorted(probe)})",
+        "sample": f"oracle.torch_cpu.hifigan_generator (torch-CPU restatement of the reference's ATen sequence, "
+                  f"pinned to reference fixtures; not the reference package, which is absent on this box), "
+                  f"B=1 x {frames} frames, best of {n} calls, {nthreads} of {cores} host threads "
+                  f"(fastest of {sorted(probe)})",
     }
 
 
-
-HIFIGAN_V1_D = dict(
-    scales=3, scale_downsample_pooling="AvgPool1d",
-    scale_downsample_pooling_params=dict(kernel_size=4, stride=2, padding=2),
-    scale_discriminator_params=dict(in_channels=1, out_channels=1, kernel_sizes=[15, 41, 5, 3], channels=128,
-                                    max_downsample_channels=1024, max_groups=16, bias=True,
-                                    downsample_scales=[4, 4, 4, 4, 1], nonlinear_activation="LeakyReLU",
-                                    nonlinear_activation_params=dict(negative_slope=0.1)),
-    follow_official_norm=True, periods=[2, 3, 5, 7, 11],
-    period_discriminator_params=dict(in_channels=1, out_channels=1, kernel_sizes=[5, 3], channels=32,
-                                     downsample_scales=[3, 3, 3, 3, 1], max_downsample_channels=1024, bias=True,
-                                     nonlinear_activation="LeakyReLU",
-                                     nonlinear_activation_params=dict(negative_slope=0.1), use_weight_norm=True,
-                                     use_spectral_norm=False),
-)
-MEL_LOSS = dict(fs=22050, fft_size=1024, hop_size=256, win_length=None, window="hann", num_mels=80, fmin=0,
-                fmax=11025, log_base=None)
-# SURVEY.md s8d: fwd = 1x, bwd = 2x, incl. the second no-grad G pass and the no-grad D(real) pass:
-# per item 4 * G(32 frames) + 10 * D(8192 samples)
-TRAIN_GFLOP_PER_ITEM = 4 * 19.65 + 10 * 12.08
-
-
-def cpu_train_baseline(budget_steps=2):
-    """oracle.train_step (torch CPU restatement of Trainer._train_step) on a B=2 slice of the
-    same workload; reported as steps/s scaled to the full batch of 16."""
+def cpu_train_baseline(conf, budget_steps=2):
+    """oracle.train_step (torch CPU restatement of Trainer._train_step) on a B=2 slice of the C3 batch.
+    Reported as an UPPER BOUND on full-batch steps/s: per-step time is assumed linear in the batch."""
     from oracle.train_step import HiFiGANTrainState
     from parallelwavegan_amd.models import HiFiGANGenerator, HiFiGANMultiScaleMultiPeriodDiscriminator
 
     cores = os.cpu_count() or 1
     nthreads = min(cores, 32)
     torch.set_num_threads(nthreads)
-    g = HiFiGANGenerator(**HIFIGAN_V1)
-    d = HiFiGANMultiScaleMultiPeriodDiscriminator(**HIFIGAN_V1_D)
+    g = HiFiGANGenerator(**conf["generator_params"])
+    d = HiFiGANMultiScaleMultiPeriodDiscriminator(**conf["discriminator_params"])
     st = HiFiGANTrainState({k: v.detach() for k, v in g.state_dict().items()},
-                           {k: v.detach() for k, v in d.state_dict().items()}, HIFIGAN_V1, HIFIGAN_V1_D, MEL_LOSS)
-    b = 2
+                           {k: v.detach() for k, v in d.state_dict().items()}, conf["generator_params"],
+                           conf["discriminator_params"], conf["mel_loss_params"])
+    b, full = 2, conf["batch_size"]
     c, y = torch.randn(b, 80, 32), 0.3 * torch.randn(b, 1, 8192)
     st.step(c, y)  # warm-up
     t0 = time.time()
@@ -137,65 +134,78 @@ def cpu_train_baseline(budget_steps=2):
         st.step(c, y)
     dt = (time.time() - t0) / budget_steps
     return {
-        "value": 1.0 / (dt * 16 / b),
-        "unit": "steps/s (B=16 x 8192, extrapolated linearly from B=2)",
+        "value": 1.0 / (dt * full / b),
+        "unit": f"steps/s at B={full} x 8192 -- a BOUND: measured at B={b} and scaled by {full // b}x, not run at full batch",
         "cores": nthreads,
         "kind": "port",
-        "sample": f"oracle.train_step.HiFiGANTrainState.step, B={b} x 8192 samples, {budget_steps} timed steps "
-                  f"({dt:.2f} s each), {nthreads} of {cores} host threads",
+        "sample": f"oracle.train_step.HiFiGANTrainState.step (restatement of the reference Trainer._train_step), "
+                  f"B={b} x 8192 samples, {budget_steps} timed steps ({dt:.2f} s each), {nthreads} of {cores} host threads",
     }
 
 
-def bench_train(args, dev, rank, world, dist):
-    """HiFi-GAN V1 LJSpeech training step (configs[2] / C3): B=16 x 8192 samples per GPU, both the
-    generator and the discriminator phase active, mel loss + adversarial + feature matching, Adam."""
+# ------------------------------------------------------------------------------------------------
+# training steps/s of one BASELINE config
+# ------------------------------------------------------------------------------------------------
+def synthetic_batch(conf, batch, dev, rank):
+    gen = torch.Generator(device="cpu").manual_seed(200 + rank)
+    t, hop = conf["batch_max_steps"], conf["hop_size"]
+    gp = conf["generator_params"]
+    acw = gp.get("aux_context_window", 0)
+    c = torch.randn(batch, conf["num_mels"], t // hop + 2 * acw, generator=gen).to(dev)
+    y = (0.3 * torch.randn(batch, 1, t, generator=gen)).to(dev)
+    if conf.get("generator_type", "ParallelWaveGANGenerator") == "ParallelWaveGANGenerator":
+        return ((torch.randn(batch, 1, t, generator=gen).to(dev), c), y)  # Collater(use_noise_input=True)
+    return ((c,), y)
+
+
+def bench_train(args, tag, dev, rank, world, dist, steps, warmup, detail=True):
+    """``steps`` timed optimisation steps (generator AND discriminator phase active) of the recipe
+    ``TRAIN_CONFIGS[tag]`` at its own batch size / segment length per GPU, everything built by
+    ``build_from_config`` from the reference YAML."""
     import tempfile
 
-    from parallelwavegan_amd import losses, ops, optimizers
+    from parallelwavegan_amd import ops
     from parallelwavegan_amd.bin.train import Trainer
-    from parallelwavegan_amd.models import HiFiGANGenerator, HiFiGANMultiScaleMultiPeriodDiscriminator
+    from parallelwavegan_amd.utils import build_from_config
 
+    name = TRAIN_CONFIGS[tag]
+    conf = load_conf(name)
     torch.manual_seed(4321)
-    model = {"generator": HiFiGANGenerator(**HIFIGAN_V1).to(dev),
-             "discriminator": HiFiGANMultiScaleMultiPeriodDiscriminator(**HIFIGAN_V1_D).to(dev)}
-    criterion = {
-        "gen_adv": losses.GeneratorAdversarialLoss(average_by_discriminators=False),
-        "dis_adv": losses.DiscriminatorAdversarialLoss(average_by_discriminators=False),
-        "mel": losses.MelSpectrogramLoss(**MEL_LOSS).to(dev),
-        "feat_match": losses.FeatureMatchLoss(average_by_discriminators=False, average_by_layers=False,
-                                              include_final_outputs=False),
-    }
-    opt = {k: optimizers.Adam(model[k].parameters(), lr=2.0e-4, betas=(0.5, 0.9), weight_decay=0.0)
-           for k in ("generator", "discriminator")}
-    sched = {k: optimizers.lr_scheduler.MultiStepLR(opt[k], gamma=0.5, milestones=[200000, 400000, 600000, 800000])
-             for k in ("generator", "discriminator")}
-    steps, warmup = args.train_steps, args.train_warmup
-    config = dict(generator_type="HiFiGANGenerator", generator_params=HIFIGAN_V1, use_stft_loss=False,
-                  use_subband_stft_loss=False, use_mel_loss=True, use_feat_match_loss=True, lambda_aux=45.0,
-                  lambda_adv=1.0, lambda_feat_match=2.0, generator_grad_norm=-1, discriminator_grad_norm=-1,
-                  generator_train_start_steps=0, discriminator_train_start_steps=0,
-                  train_max_steps=10 ** 9, save_interval_steps=10 ** 9, eval_interval_steps=10 ** 9,
-                  log_interval_steps=10 ** 9, distributed=world > 1, rank=rank, outdir=tempfile.mkdtemp(),
-                  progress=False, use_hip_graph=not args.no_graph, graph_warmup_steps=2,
-                  reuse_real_discriminator_pass=os.environ.get("PWG_REUSE_REAL", "1") == "1")
-    gen = torch.Generator(device="cpu").manual_seed(200 + rank)
-    b, t = args.train_batch, 8192
-    c = torch.randn(b, 80, t // 256, generator=gen).to(dev)
-    y = (0.3 * torch.randn(b, 1, t, generator=gen)).to(dev)
-    batch = ((c,), y)
+    model, criterion, opt, sched = build_from_config(conf, dev)
+    b = args.train_batch if (tag == "c3" and args.train_batch) else conf["batch_size"]
+    # both phases active from the first step (steady state of the recipe after discriminator_train_start_steps)
+    conf.update(generator_train_start_steps=0, discriminator_train_start_steps=0, train_max_steps=10 ** 9,
+                save_interval_steps=10 ** 9, eval_interval_steps=10 ** 9, log_interval_steps=10 ** 9,
+                distributed=world > 1, rank=rank, outdir=tempfile.mkdtemp(), progress=False,
+                use_hip_graph=not args.no_graph, graph_warmup_steps=2,
+                reuse_real_discriminator_pass=os.environ.get("PWG_REUSE_REAL", "1") == "1")
+    batch = synthetic_batch(conf, b, dev, rank)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(n):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            tr._train_step(batch)
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = tt.item()
+        return el
+
     # hipGraph replay of the step (data parallel: graphs cut at the gradient exchanges); should the
     # capture fail on some stack, every rank sees the same exception and the run continues eagerly
-    for use_graph in ([True, False] if config["use_hip_graph"] else [False]):
-        config["use_hip_graph"] = use_graph
+    for use_graph in ([True, False] if conf["use_hip_graph"] else [False]):
+        conf["use_hip_graph"] = use_graph
         tr = Trainer(steps=1, epochs=0, data_loader={"train": [batch], "dev": [batch]},
                      sampler={"train": None, "dev": None}, model=model, criterion=criterion, optimizer=opt,
-                     scheduler=sched, config=config, device=dev)
+                     scheduler=sched, config=conf, device=dev)
         tr.tqdm = None
         try:
             for _ in range(warmup):
@@ -208,40 +218,45 @@ def bench_train(args, dev, rank, world, dist):
                   file=sys.stderr, flush=True)
             for r in (tr.reducers or {}).values():
                 r.remove()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        tr._train_step(batch)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = tt.item()
+    elapsed = timed(steps)
+    # exposed communication = step time with the gradient all-reduces minus step time without them
+    # (same graphs, same kernels; the ranks' parameters drift apart afterwards, which timing ignores)
+    dist_info = None
+    if tr.reducers:
+        for r in tr.reducers.values():
+            r.skip_comm = True
+        t_nocomm = timed(steps)
+        for r in tr.reducers.values():
+            r.skip_comm = False
+        dist_info = {
+            "backend": dist.get_backend(),
+            "exchanged_MB_per_step": {k: round(r.bytes / 1e6, 1) for k, r in tr.reducers.items()},
+            "exchange_groups": {k: len(r.groups) for k, r in tr.reducers.items()},
+            "buckets": {k: len(r.buckets) for k, r in tr.reducers.items()},
+            "ms_per_step_without_collectives": t_nocomm / steps * 1e3,
+        }
     tr._flush_pending()
     finite = all(v == v and abs(v) != float("inf") for v in tr.total_train_loss.values())
-    out = None
     # one more (eager) step with per-kernel event timing; every rank runs it -- a data-parallel step
     # contains collectives -- but only rank 0 reports
-    tr.config["use_hip_graph"] = False
-    for m in model.values():  # serial launches: concurrent branches would inflate each kernel's event time
-        for sub in m.modules():
-            if hasattr(sub, "branch_streams"):
-                sub.branch_streams = False
-    with ops.profile() as prof:
-        tr._train_step(batch)
+    prof = None
+    if detail:
+        tr.config["use_hip_graph"] = False
+        for m in model.values():  # serial launches: concurrent branches would inflate each kernel's event time
+            for sub in m.modules():
+                if hasattr(sub, "branch_streams"):
+                    sub.branch_streams = False
+        with ops.profile() as prof:
+            tr._train_step(batch)
+    out = None
     if rank == 0:
-        tot_ms = sum(v["ms"] for v in prof.results.values())
-        kern = {k: {"ms_per_step": round(v["ms"], 3), "launches": v["launches"],
-                    "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
-                    "GBps_algorithmic": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
-                for k, v in sorted(prof.results.items(), key=lambda kv: -kv[1]["ms"])}
-        flops_step = TRAIN_GFLOP_PER_ITEM * 1e9 * b
+        ms = elapsed / steps * 1e3
         out = {
-            "metric": "HiFi-GAN V1 LJSpeech training steps/s (G+D phases, B=16 x 8192 per GPU)",
+            "config": f"{tag}: {name} (egs/ljspeech/voc1/conf), B={b} x {conf['batch_max_steps']} samples per GPU, "
+                      f"generator + discriminator phase, {conf.get('generator_optimizer_type', 'RAdam')}",
             "value": steps / elapsed,
             "unit": "steps/s",
-            "ms_per_step": elapsed / steps * 1e3,
+            "ms_per_step": ms,
             "steps": steps,
             "warmup": warmup,
             "batch_per_gpu": b,
@@ -251,15 +266,94 @@ def bench_train(args, dev, rank, world, dist):
             "parallelism": f"dp{world}" if world > 1 else "single",
             "hip_graph": bool(tr._graphs),
             "losses_finite": finite,
-            "algorithmic_TFLOP_per_step_per_gpu": flops_step / 1e12,
-            "achieved_TFLOPs_per_gpu": flops_step / (elapsed / steps) / 1e12,
-            "frac_of_fp32_matrix_peak": flops_step / (elapsed / steps) / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
-            "kernel_time_ms_per_step": round(tot_ms, 3),
-            "kernels": kern,
         }
+        if dist_info is not None:
+            dist_info["exposed_comm_ms"] = ms - dist_info["ms_per_step_without_collectives"]
+            out["dist"] = dist_info
+            out["exposed_comm_ms"] = dist_info["exposed_comm_ms"]
+        if prof is not None:
+            tot_ms = sum(v["ms"] for v in prof.results.values())
+            executed = sum(v["flops"] for v in prof.results.values())
+            mfma_ms = sum(v["ms"] for v in prof.results.values() if v["flops"])
+            out["kernel_time_ms_per_step"] = round(tot_ms, 3)
+            out["conv_launches_per_step"] = int(sum(v["launches"] for k, v in prof.results.items() if "conv1d" in k))
+            out["launches_per_step"] = int(sum(v["launches"] for v in prof.results.values()))
+            # EXECUTED flops: what the MFMA kernels of one step really computed (the engine skips the
+            # discriminator weight gradients of the generator phase and the second D(real) pass)
+            out["executed_TFLOP_per_step_per_gpu"] = executed / 1e12
+            out["executed_TFLOPs_per_gpu"] = executed / (ms * 1e-3) / 1e12
+            out["executed_frac_of_fp32_matrix_peak"] = executed / (ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS
+            out["mfma_kernels_TFLOPs_while_running"] = executed / (mfma_ms * 1e-3) / 1e12 if mfma_ms else None
+            if tag == "c3":
+                ref = C3_REFERENCE_GFLOP_PER_ITEM * 1e9 * b
+                out["reference_TFLOP_per_step_per_gpu"] = ref / 1e12
+                out["reference_flop_TFLOPs_per_gpu"] = ref / (ms * 1e-3) / 1e12
+                out["reference_flop_frac_of_fp32_matrix_peak"] = ref / (ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS
+            out["kernels"] = {
+                k: {"ms_per_step": round(v["ms"], 3), "launches": v["launches"],
+                    "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
+                    "GBps_algorithmic": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
+                for k, v in sorted(prof.results.items(), key=lambda kv: -kv[1]["ms"])}
     for r in (tr.reducers or {}).values():
         r.remove()
+    del tr, model, criterion, opt, sched
+    torch.cuda.empty_cache()
     return out
+
+
+def bench_pwg_inference(dev, steps=10, warmup=3, batch=16, frames=400):
+    """BASELINE configs[0]/[1] generator: Parallel WaveGAN.v1 forward (noise + mel -> waveform), as a
+    resident batch (graph replay) and as the single 80x100 mel of test_parallel_wavegan.py."""
+    from parallelwavegan_amd import ops
+    from parallelwavegan_amd.graphs import GraphedInference
+    from parallelwavegan_amd.models import ParallelWaveGANGenerator
+
+    conf = load_conf("parallel_wavegan.v1")
+    gp = conf["generator_params"]
+    torch.manual_seed(99)
+    g = ParallelWaveGANGenerator(**gp)
+    g.remove_weight_norm()
+    g = g.to(dev).eval()
+    acw, hop = gp["aux_context_window"], conf["hop_size"]
+    out = {}
+    for tag, (b, f, n) in {"batch": (batch, frames, steps), "B1_F100": (1, 100, 20)}.items():
+        c = torch.randn(b, gp["aux_channels"], f + 2 * acw).to(dev)
+        z = torch.randn(b, 1, f * hop).to(dev)
+        run = GraphedInference(g)
+        with torch.no_grad():
+            for _ in range(warmup):
+                y = run(z, c)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                y = run(z, c)
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        assert torch.isfinite(y).all()
+        out[tag] = {"batch": b, "frames": f, "ms": dt * 1e3, "samples_per_s": b * f * hop / dt}
+        if tag == "batch":
+            with ops.profile() as prof, torch.no_grad():
+                g(z, c)
+            fl = sum(v["flops"] for v in prof.results.values())
+            out[tag]["MFLOP_per_sample_executed"] = fl / (b * f * hop) / 1e6
+            out[tag]["TFLOPs"] = fl / dt / 1e12
+            out[tag]["frac_of_fp32_matrix_peak"] = fl / dt / 1e12 / FP32_MATRIX_PEAK_TFLOPS
+            out[tag]["kernels"] = {k: {"ms": round(v["ms"], 3), "launches": v["launches"],
+                                       "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None}
+                                   for k, v in sorted(prof.results.items(), key=lambda kv: -kv[1]["ms"])}
+        del run
+    out["config"] = "c1/c2 generator: parallel_wavegan.v1, fp32, weight norm removed, hipGraph replay"
+    del g
+    torch.cuda.empty_cache()
+    return out
+
+
+def self_launch(args):
+    """``python bench.py --gpus N`` without a launcher: one rank per GPU through the package's launcher."""
+    from parallelwavegan_amd.distributed import launch
+
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    return launch.spawn(cmd, args.gpus, master_addr="127.0.0.1", master_port=0)
 
 
 def main():
@@ -270,37 +364,48 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="utterances per step per GPU")
     ap.add_argument("--frames", type=int, default=800, help="mel frames per utterance (800 = 9.3 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-train", action="store_true", help="skip the training-step measurement")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step measurements")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-utterance latency runs")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip BASELINE configs C1 (PWG inference), C2 and C4 (training); C3 is always measured")
     ap.add_argument("--train-steps", type=int, default=50)
     ap.add_argument("--train-warmup", type=int, default=10, help=">= 3 so that the hipGraph capture is not timed")
     ap.add_argument("--no-graph", action="store_true", help="run the training step eagerly (no hipGraph replay)")
-    ap.add_argument("--train-batch", type=int, default=16)
+    ap.add_argument("--train-batch", type=int, default=0, help="override the C3 batch per GPU (default: the recipe's 16)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    n_dev = max(torch.cuda.device_count(), 1)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # "nccl" is RCCL on ROCm; PWG_DIST_BACKEND=gloo lets two ranks share one GPU for smoke tests
-        dist.init_process_group(os.environ.get("PWG_DIST_BACKEND", "nccl"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
+        # "nccl" is RCCL on ROCm.  RCCL refuses two ranks on one device, so when there are fewer GPUs
+        # than ranks (single-GPU smoke run of the multi-rank path) the collectives go through gloo.
+        backend = os.environ.get("PWG_DIST_BACKEND", "nccl" if n_dev >= world else "gloo")
+        dist.init_process_group(backend)
+    dev = torch.device("cuda", local_rank % n_dev)
     torch.cuda.set_device(dev)
 
     from parallelwavegan_amd import ops
     from parallelwavegan_amd.models import HiFiGANGenerator
 
+    c3 = load_conf("hifigan.v1")
+    g_params = c3["generator_params"]
     torch.manual_seed(1234)
-    g = HiFiGANGenerator(**HIFIGAN_V1)
+    g = HiFiGANGenerator(**g_params)
     g.remove_weight_norm()  # as bin/decode.py:147
     g = g.to(dev).eval()
     gen = torch.Generator(device="cpu").manual_seed(100 + rank)
-    c = torch.randn(args.batch, 80, args.frames, generator=gen).to(dev)
+    c_host = torch.randn(args.batch, 80, args.frames, generator=gen)
+    c = c_host.to(dev)
     samples_per_step = args.batch * args.frames * g.upsample_factor
 
     def barrier():
@@ -329,6 +434,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
+    # ---- parity of THIS workload: utterances 0 and B-1 of the timed batch against the oracle
+    parity = None
+    if rank == 0:
+        from oracle import torch_cpu
+
+        sd = {k: v.detach().cpu() for k, v in g.state_dict().items()}
+        idx = sorted({0, args.batch - 1})
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))
+        with torch.no_grad():
+            ref = torch_cpu.hifigan_generator(sd, c_host[idx], **g_params)
+        err = (y[idx].cpu() - ref).abs().max().item()
+        parity = {"max_abs_vs_oracle": err, "utterances_checked": idx, "oracle_abs_max": ref.abs().max().item(),
+                  "tolerance": 1e-4, "ok": err <= 1e-4}
+
     # ---- dominant-kernel roofline: HIP events recorded inside the library on the launch stream
     # around every kernel of `prof_steps` further steps (pwg_prof_*, include/pwg_kernels.h)
     roofline = None
@@ -340,15 +459,17 @@ def main():
         name, r = max(prof.results.items(), key=lambda kv: kv[1]["ms"])
         achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
         traffic, traffic_src = None, None
-        pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-        if os.path.exists(pmc_file) and args.batch == 16 and args.frames == 800:
-            # HBM bytes per launch of this kernel on THIS workload, from separate rocprofv3 --pmc passes
-            # (FETCH_SIZE, WRITE_SIZE; KiB units; read side calibrated on a known byte count) --
-            # counters cannot be read from inside the process, so the committed summary is cited
-            with open(pmc_file) as f:
-                pmc = json.load(f)
-            if pmc.get("kernel") == name:
-                traffic, traffic_src = pmc["hbm_bytes_per_launch"], "profiles/r01_pmc_hbm_traffic.json"
+        for pmc_name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+            pmc_file = os.path.join(ROOT, "profiles", pmc_name)
+            if os.path.exists(pmc_file) and args.batch == 16 and args.frames == 800:
+                # HBM bytes per launch of this kernel on THIS workload, from separate rocprofv3 --pmc passes
+                # (FETCH_SIZE, WRITE_SIZE; KiB units; read side calibrated on a known byte count) --
+                # counters cannot be read from inside the process, so the committed summary is cited
+                with open(pmc_file) as f:
+                    pmc = json.load(f)
+                if pmc.get("kernel") == name:
+                    traffic, traffic_src = pmc["hbm_bytes_per_launch"], "profiles/" + pmc_name
+                    break
         roofline = {
             "kernel": name,
             "bound": "mfma",
@@ -364,6 +485,8 @@ def main():
             "algorithmic_bytes_per_launch": r["bytes"] / r["launches"],
             "algorithmic_GBps": r["bytes"] / (r["ms"] * 1e-3) / 1e9,
             "kernel_ms_per_step": r["ms"] / prof_steps,
+            "kernel_ms_note": "serial event timing of eager launches; the timed region replays a hipGraph whose "
+                              "MRF branches overlap, so it can be ~1% shorter than this sum",
             "share_of_step_kernel_time": r["ms"] / sum(v["ms"] for v in prof.results.values()),
         }
 
@@ -390,7 +513,21 @@ def main():
         g.branch_streams = False
     del y, run
     torch.cuda.empty_cache()
-    train = None if args.no_train else bench_train(args, dev, rank, world, dist)
+
+    train, configs = None, {}
+    if not args.no_train:
+        train = bench_train(args, "c3", dev, rank, world, dist, args.train_steps, args.train_warmup)
+        if not args.no_extra_configs:
+            for tag in ("c2", "c4"):
+                try:
+                    configs[tag + "_train"] = bench_train(args, tag, dev, rank, world, dist, 10, 5)
+                except Exception as e:  # noqa: BLE001  (extra evidence must never take the headline line down)
+                    configs[tag + "_train"] = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0 and not args.no_extra_configs:
+        try:
+            configs["c1_pwg_inference"] = bench_pwg_inference(dev)
+        except Exception as e:  # noqa: BLE001
+            configs["c1_pwg_inference"] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         value = samples_per_step * world * args.steps / elapsed
@@ -418,17 +555,21 @@ def main():
             },
             "rtf": 22050.0 / value,
             "hip_graph": not args.no_graph,
+            "parity": parity,
             "latency": latency,
             "roofline": roofline,
         }
         if train is not None:
             out["train"] = train
+        if configs:
+            out["configs"] = configs
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(g_params)
             if train is not None:
-                train["cpu_baseline"] = cpu_train_baseline()
+                train["cpu_baseline"] = cpu_train_baseline(load_conf("hifigan.v1"))
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -327,12 +327,40 @@ int pwg_log_clamp_backward(const float* x, const float* dy, float* dx, int64_t n
 /*   stft_loss.py:61), 3 (a-c)^2 (F.mse_loss against a constant: adversarial_loss.py */
 /*   :54-58,113-123), 4 a.  workspace: >= 512 floats.                                */
 /* ------------------------------------------------------------------------- */
-enum { PWG_RED_ABS_DIFF = 0, PWG_RED_SQ_DIFF = 1, PWG_RED_SQ = 2, PWG_RED_SQ_DIFF_CONST = 3, PWG_RED_SUM = 4 };
+/*   5 -min(a-1, 0) and 6 -min(-a-1, 0): the hinge terms of DiscriminatorAdversarialLoss            */
+/*   (adversarial_loss.py:119-123; ties of the min get gradient 1/2 like torch.minimum).            */
+enum { PWG_RED_ABS_DIFF = 0, PWG_RED_SQ_DIFF = 1, PWG_RED_SQ = 2, PWG_RED_SQ_DIFF_CONST = 3, PWG_RED_SUM = 4,
+       PWG_RED_HINGE_REAL = 5, PWG_RED_HINGE_FAKE = 6 };
 int pwg_reduce_forward(const float* a, const float* b, float c, int64_t n, int32_t mode, float scale,
                        float* out, float* workspace, void* stream);
 /* da = gout[0] * scale * dterm/da (db = -da); gout is a DEVICE scalar.            */
 int pwg_reduce_backward(const float* a, const float* b, float c, int64_t n, int32_t mode, float scale,
                         const float* gout, float* da, float* db, void* stream);
+
+/* Multi-tensor form: the Python loops over discriminators x layers of FeatureMatchLoss.forward
+ * (feat_match_loss.py:36-54) and of the adversarial losses (adversarial_loss.py:30-47,79-104) as ONE
+ * launch pair:  out[slot] (+)= sum_items scale_item * sum_i term_mode(a_i, b_i | c).
+ * `items` is a HOST array (<= PWG_RED_MAX_ITEMS entries; it is copied into the kernel arguments, so
+ * a captured hipGraph keeps its own copy); workspace: pwg_multi_reduce_workspace_floats() floats.
+ * accumulate != 0 adds to out[] (more than PWG_RED_MAX_ITEMS tensors = several calls).
+ * Backward: da = gout[slot] * scale * dterm/da and db = -da into the items' da / db (NULL = skip). */
+#define PWG_RED_MAX_ITEMS 64
+typedef struct pwg_red_item {
+  const float* a;
+  const float* b;  /* second operand of the diff modes, else NULL                    */
+  float* da;       /* backward only: gradient w.r.t. a (NULL = not needed)           */
+  float* db;       /* backward only: gradient w.r.t. b (NULL = not needed)           */
+  int64_t n;       /* elements                                                       */
+  int32_t mode;    /* PWG_RED_*                                                      */
+  int32_t slot;    /* which output scalar this item adds to                          */
+  float scale;     /* e.g. 1/n for a mean, times the averaging weights               */
+  float c;         /* constant of PWG_RED_SQ_DIFF_CONST                              */
+} pwg_red_item;
+size_t pwg_multi_reduce_workspace_floats(const pwg_red_item* items, int32_t n_items);
+int pwg_multi_reduce_forward(const pwg_red_item* items, int32_t n_items, int32_t n_slots, float* out,
+                             int32_t accumulate, float* workspace, void* stream);
+int pwg_multi_reduce_backward(const pwg_red_item* items, int32_t n_items, int32_t n_slots, const float* gout,
+                              void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Fused multi-tensor optimizer steps over a device table of chunks            */

@@ -295,23 +295,28 @@ def mel_spectrogram_loss(y_hat, y, **params):
     return F.l1_loss(mel_spectrogram(y_hat, **params), mel_spectrogram(y, **params))
 
 
-def generator_adversarial_loss(outputs, average_by_discriminators=True):
-    """``GeneratorAdversarialLoss.forward`` (mse) losses/adversarial_loss.py:29-58."""
+def generator_adversarial_loss(outputs, average_by_discriminators=True, loss_type="mse"):
+    """``GeneratorAdversarialLoss.forward`` losses/adversarial_loss.py:29-58 (mse :54-55, hinge :57-58)."""
     loss = 0.0
     for i, o in enumerate(outputs):
         o = o[-1] if isinstance(o, (list, tuple)) else o
-        loss = loss + F.mse_loss(o, torch.ones_like(o))
+        loss = loss + (F.mse_loss(o, torch.ones_like(o)) if loss_type == "mse" else -o.mean())
     return loss / (i + 1) if average_by_discriminators else loss
 
 
-def discriminator_adversarial_loss(outputs_hat, outputs, average_by_discriminators=True):
-    """``DiscriminatorAdversarialLoss.forward`` (mse) losses/adversarial_loss.py:80-123."""
+def discriminator_adversarial_loss(outputs_hat, outputs, average_by_discriminators=True, loss_type="mse"):
+    """``DiscriminatorAdversarialLoss.forward`` losses/adversarial_loss.py:80-123 (mse :113-117,
+    hinge :119-123: -mean(min(x - 1, 0)) on real, -mean(min(-x - 1, 0)) on generated)."""
     real, fake = 0.0, 0.0
     for i, (oh, o) in enumerate(zip(outputs_hat, outputs)):
         if isinstance(oh, (list, tuple)):
             oh, o = oh[-1], o[-1]
-        real = real + F.mse_loss(o, torch.ones_like(o))
-        fake = fake + F.mse_loss(oh, torch.zeros_like(oh))
+        if loss_type == "mse":
+            real = real + F.mse_loss(o, torch.ones_like(o))
+            fake = fake + F.mse_loss(oh, torch.zeros_like(oh))
+        else:
+            real = real - torch.mean(torch.min(o - 1, torch.zeros_like(o)))
+            fake = fake - torch.mean(torch.min(-oh - 1, torch.zeros_like(oh)))
     if average_by_discriminators:
         real, fake = real / (i + 1), fake / (i + 1)
     return real, fake
@@ -346,8 +351,10 @@ def pwg_upsample(sd, c, upsample_scales=(4, 4, 4, 4), prefix="upsample_net"):
     return c.squeeze(1)
 
 
-def pwg_generator(sd, z, c, layers=30, stacks=3, kernel_size=3, upsample_params=None, **_unused):
-    """``ParallelWaveGANGenerator.forward`` models/parallel_wavegan.py:144-173 (dropout = 0)."""
+def pwg_generator(sd, z, c, layers=30, stacks=3, kernel_size=3, upsample_params=None, dropout_masks=None, **_unused):
+    """``ParallelWaveGANGenerator.forward`` models/parallel_wavegan.py:144-173.  ``dropout_masks``: optional
+    per-layer multipliers (kept / (1 - p) or 0) standing in for ``F.dropout`` on the dilated conv's input
+    (layers/residual_block.py:114-116; the residual path keeps the undropped x)."""
     scales = (upsample_params or {}).get("upsample_scales", (4, 4, 4, 4))
     c = pwg_upsample(sd, c, scales)
     assert c.size(-1) == z.size(-1)
@@ -358,7 +365,8 @@ def pwg_generator(sd, z, c, layers=30, stacks=3, kernel_size=3, upsample_params=
         p = f"conv_layers.{l}"
         d = 2 ** (l % per_stack)
         residual = x
-        h = F.conv1d(x, get_weight(sd, p + ".conv"), get_bias(sd, p + ".conv"), dilation=d,
+        xin = x if dropout_masks is None else x * dropout_masks[l]
+        h = F.conv1d(xin, get_weight(sd, p + ".conv"), get_bias(sd, p + ".conv"), dilation=d,
                      padding=(kernel_size - 1) // 2 * d)
         xa, xb = h.split(h.size(1) // 2, dim=1)
         a = F.conv1d(c, get_weight(sd, p + ".conv1x1_aux"))

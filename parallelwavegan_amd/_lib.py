@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libpwgkernels.so")
 
 PWG_ACT_NONE, PWG_ACT_LEAKY_RELU, PWG_ACT_TANH, PWG_ACT_RELU = 0, 1, 2, 3
 PWG_PAD_ZERO, PWG_PAD_REFLECT, PWG_PAD_REPLICATE = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class ConvDesc(ctypes.Structure):
@@ -39,6 +39,24 @@ class ConvDesc(ctypes.Structure):
         ("out_div", ctypes.c_float),
     ]
 
+
+class RedItem(ctypes.Structure):
+    """Mirror of ``pwg_red_item`` (include/pwg_kernels.h)."""
+
+    _fields_ = [
+        ("a", ctypes.c_void_p),
+        ("b", ctypes.c_void_p),
+        ("da", ctypes.c_void_p),
+        ("db", ctypes.c_void_p),
+        ("n", ctypes.c_int64),
+        ("mode", ctypes.c_int32),
+        ("slot", ctypes.c_int32),
+        ("scale", ctypes.c_float),
+        ("c", ctypes.c_float),
+    ]
+
+
+RED_MAX_ITEMS = 64
 
 _lib = None
 _vp = ctypes.c_void_p
@@ -106,6 +124,9 @@ SIGNATURES = {
     "pwg_log_clamp_backward": (ctypes.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _vp]),
     "pwg_reduce_forward": (ctypes.c_int, [_vp, _vp, _f32, _i64, _i32, _f32, _vp, _vp, _vp]),
     "pwg_reduce_backward": (ctypes.c_int, [_vp, _vp, _f32, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
+    "pwg_multi_reduce_workspace_floats": (ctypes.c_size_t, [ctypes.POINTER(RedItem), _i32]),
+    "pwg_multi_reduce_forward": (ctypes.c_int, [ctypes.POINTER(RedItem), _i32, _i32, _vp, _i32, _vp, _vp]),
+    "pwg_multi_reduce_backward": (ctypes.c_int, [ctypes.POINTER(RedItem), _i32, _i32, _vp, _vp]),
     "pwg_adam_step": (ctypes.c_int, [_vp, _i32, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
     "pwg_radam_step": (ctypes.c_int, [_vp, _i32, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
     "pwg_adam_step_dev": (ctypes.c_int, [_vp, _i32, _vp, _vp]),

@@ -72,10 +72,18 @@ class Trainer(object):
                     m.branch_streams = True
         self.reducers = None
         if config.get("distributed", False):
-            self.reducers = {k: GradReducer(list(self._module(k).parameters())) for k in ("generator", "discriminator")}
-            for k, r in self.reducers.items():
+            self.reducers = {}
+            for k in ("generator", "discriminator"):
                 m = self._module(k)
-                r.broadcast_parameters(list(m.parameters()) + list(m.buffers()))
+                # hipGraph mode replays the backward pass as one graph per exchange group, so that group
+                # k's all-reduce overlaps the replay of group k+1 (independent sub-discriminators)
+                groups = None
+                n_groups = int(config.get("ddp_grad_groups", 4))
+                if config.get("use_hip_graph", False) and n_groups > 1 and hasattr(m, "grad_groups"):
+                    groups = m.grad_groups(n_groups)
+                self.reducers[k] = GradReducer(list(m.parameters()), groups=groups,
+                                               bucket_bytes=int(config.get("ddp_bucket_bytes", 64 << 20)))
+                self.reducers[k].broadcast_parameters(list(m.parameters()) + list(m.buffers()))
 
     # ------------------------------------------------------------------ plumbing
     def _module(self, key):
@@ -123,8 +131,10 @@ class Trainer(object):
                 self.scheduler[k].load_state_dict(state_dict["scheduler"][k])
 
     def _log(self, name, value):
-        """Record a loss scalar without synchronising the host."""
-        self._pending.append((name, value.detach()))
+        """Record a loss scalar without synchronising the host (rank 0 only: the other ranks never
+        flush, bin/train.py:378 of this file's ``_train_epoch``)."""
+        if self.config.get("rank", 0) == 0:
+            self._pending.append((name, value.detach()))
 
     def _flush_pending(self):
         for entry in self._graphs.values():  # losses accumulated on the device by graph replays
@@ -151,8 +161,11 @@ class Trainer(object):
         return y_, y_mb_
 
     def _step_optimizer(self, key, loss):
-        """Generator: backward, [yield key = gradient-exchange point], clip, update.  The caller
-        completes the exchange at the yield (eagerly: RCCL calls are never captured in a hipGraph)."""
+        """Backward, [yield (key, group) = gradient-exchange point(s)], clip, update.  The caller
+        completes the exchange at the yields (eagerly: RCCL calls are never captured in a hipGraph).
+        While a hipGraph is being captured and the reducer has several exchange groups, the backward
+        pass is issued group by group (``inputs=`` restricted autograd calls over independent
+        sub-networks) with a yield after each, so that every group becomes its own graph segment."""
         cfg = self.config
         opt = self.optimizer[key]
         params = list(self._module(key).parameters())
@@ -161,9 +174,18 @@ class Trainer(object):
         reducer = self.reducers[key] if self.reducers else None
         if reducer is not None:
             reducer.prepare()
-        loss.backward()
+        if reducer is not None and self._capturing and len(reducer.groups) > 1:
+            last = len(reducer.groups) - 1
+            for gi, gparams in enumerate(reducer.groups):
+                inputs = [p for p in gparams if p.requires_grad]
+                if inputs:
+                    torch.autograd.backward(loss, inputs=inputs, retain_graph=gi < last)
+                yield (key, gi)
+        else:
+            loss.backward()
+            if reducer is not None:
+                yield (key, None)
         if reducer is not None:
-            yield key
             opt.grad_scale = 1.0 / reducer.world
             opt.flat_grads = reducer.flat_grads
             pairs = [(p, reducer.flat_grads[p]) for p in params]
@@ -186,7 +208,6 @@ class Trainer(object):
     def _graph_ok(self):
         cfg = self.config
         return (cfg.get("use_hip_graph", False)
-                and cfg.get("generator_grad_norm", -1) <= 0 and cfg.get("discriminator_grad_norm", -1) <= 0
                 # models that take host-side random decisions per call (StyleMelGAN's random windows)
                 and all(getattr(self._module(k), "hip_graph_safe", True) for k in ("generator", "discriminator")))
 
@@ -242,7 +263,7 @@ class Trainer(object):
                                     if self._pending else None)
                     segments.append((graph, exchange))
                     if exchange is not None:
-                        self.reducers[exchange].finish()  # eager: the capture step's own exchange
+                        self.reducers[exchange[0]].finish()  # capture pass: nothing ran, nothing to exchange
             finally:
                 self._capturing = False
                 for r in (self.reducers or {}).values():
@@ -257,17 +278,28 @@ class Trainer(object):
                 s.copy_(t, non_blocking=True)
         entry["y"].copy_(y, non_blocking=True)
         gen_on, disc_on = key[0]
-        scale = 1.0 / self.reducers["generator"].world if self.reducers else 1.0
-        if gen_on:
-            self.optimizer["generator"].grad_scale = scale
-            self.optimizer["generator"].prepare()
-        if disc_on:
-            self.optimizer["discriminator"].grad_scale = scale
-            self.optimizer["discriminator"].prepare()
+        for k, on in (("generator", gen_on), ("discriminator", disc_on)):
+            if not on:
+                continue
+            # with gradient clipping the captured step has already averaged the gradients (see _step_optimizer)
+            clipped = self.config.get(f"{k}_grad_norm", -1) > 0
+            self.optimizer[k].grad_scale = (1.0 / self.reducers[k].world) if (self.reducers and not clipped) else 1.0
+            self.optimizer[k].prepare()
+        for r in (self.reducers or {}).values():
+            r.begin_replay()
         for graph, exchange in entry["segments"]:
             graph.replay()
             if exchange is not None:
-                self.reducers[exchange].exchange_all()
+                # the segment filled this exchange group's buckets; its all-reduce runs on RCCL's stream
+                # while the next segment (the next group's backward) replays
+                k, gi = exchange
+                r = self.reducers[k]
+                if gi is None:
+                    r.exchange_all()
+                else:
+                    r.exchange_group(gi)
+                    if gi == len(r.groups) - 1:
+                        r.wait_all()
         from ..ops import bump_param_epoch
 
         bump_param_epoch()
@@ -293,12 +325,13 @@ class Trainer(object):
 
     def _device_step(self, x, y):
         """One optimisation step, eagerly: the gradient exchanges run where the step yields."""
-        for key in self._device_step_iter(x, y):
+        for key, _ in self._device_step_iter(x, y):
             self.reducers[key].finish()
 
     def _device_step_iter(self, x, y):
-        """Generator over the step's gradient-exchange points (yields "generator" / "discriminator"
-        after the respective backward when data parallel; yields nothing on a single GPU)."""
+        """Generator over the step's gradient-exchange points (yields ("generator" | "discriminator",
+        exchange group or None = all) after the respective backward when data parallel; yields nothing
+        on a single GPU)."""
         cfg = self.config
         disc_on = self.steps > cfg["discriminator_train_start_steps"]
         p_real = None  # discriminator outputs on the real signal, shared by the two phases

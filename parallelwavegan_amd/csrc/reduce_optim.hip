@@ -4,7 +4,8 @@
 
 namespace pwg {
 
-enum { RED_ABS_DIFF = 0, RED_SQ_DIFF = 1, RED_SQ = 2, RED_SQ_DIFF_CONST = 3, RED_SUM = 4 };
+enum { RED_ABS_DIFF = 0, RED_SQ_DIFF = 1, RED_SQ = 2, RED_SQ_DIFF_CONST = 3, RED_SUM = 4, RED_HINGE_REAL = 5,
+       RED_HINGE_FAKE = 6, RED_NUM_MODES = 7 };
 constexpr int RED_BLOCKS = 512;
 
 __device__ __forceinline__ float red_term(int mode, float a, float b, float c) {
@@ -13,7 +14,24 @@ __device__ __forceinline__ float red_term(int mode, float a, float b, float c) {
     case RED_SQ_DIFF: return (a - b) * (a - b);
     case RED_SQ: return a * a;
     case RED_SQ_DIFF_CONST: return (a - c) * (a - c);
+    case RED_HINGE_REAL: return -fminf(a - 1.f, 0.f);   // -min(x - 1, 0)   (adversarial_loss.py:119-120)
+    case RED_HINGE_FAKE: return -fminf(-a - 1.f, 0.f);  // -min(-x - 1, 0)  (adversarial_loss.py:122-123)
     default: return a;
+  }
+}
+// d term / d a  (for the diff modes d/db = -d/da); ties of the hinge's min(., 0) get 1/2 like torch.minimum
+__device__ __forceinline__ float red_dterm(int mode, float a, float b, float c) {
+  switch (mode) {
+    case RED_ABS_DIFF: {
+      const float d = a - b;
+      return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    }
+    case RED_SQ_DIFF: return 2.f * (a - b);
+    case RED_SQ: return 2.f * a;
+    case RED_SQ_DIFF_CONST: return 2.f * (a - c);
+    case RED_HINGE_REAL: return a < 1.f ? -1.f : (a == 1.f ? -0.5f : 0.f);
+    case RED_HINGE_FAKE: return a > -1.f ? 1.f : (a == -1.f ? 0.5f : 0.f);
+    default: return 1.f;
   }
 }
 
@@ -49,21 +67,65 @@ __global__ void reduce_backward_kernel(const float* a, const float* b, float c, 
                                        const float* gout, float* da, float* db) {
   const float gs = gout[0] * scale;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    float g;
-    const float av = a[i];
-    switch (mode) {
-      case RED_ABS_DIFF: {
-        const float d = av - b[i];
-        g = d > 0.f ? gs : (d < 0.f ? -gs : 0.f);
-        break;
-      }
-      case RED_SQ_DIFF: g = 2.f * (av - b[i]) * gs; break;
-      case RED_SQ: g = 2.f * av * gs; break;
-      case RED_SQ_DIFF_CONST: g = 2.f * (av - c) * gs; break;
-      default: g = gs;
-    }
+    const float g = gs * red_dterm(mode, a[i], b ? b[i] : 0.f, c);
     if (da) da[i] = g;
     if (db) db[i] = -g;
+  }
+}
+
+// ---- multi-tensor loss reductions: out[slot] = sum_items scale_item * sum_i term(a_i, b_i | c) ---------
+// The item table travels BY VALUE in the kernel arguments (<= 4 KiB), so a captured hipGraph holds it
+// inside the kernel node: no device table, no host staging buffer that a later step could overwrite.
+struct RedItems {
+  pwg_red_item it[PWG_RED_MAX_ITEMS];
+  int chunk_start[PWG_RED_MAX_ITEMS + 1];  // first chunk of item i (prefix sums), [n_items] = total chunks
+  int n_items;
+};
+constexpr int RED_CHUNK = 8192;  // elements per workgroup
+
+__device__ __forceinline__ int red_find_item(const RedItems& t, int chunk) {
+  int i = 0;
+  while (i + 1 < t.n_items && t.chunk_start[i + 1] <= chunk) ++i;
+  return i;
+}
+
+// stage 1: partial[chunk] = scale_item * sum over the chunk (fixed element order per thread, fixed tree)
+__global__ void __launch_bounds__(256) multi_reduce_stage1_kernel(const RedItems t, float* partial) {
+  __shared__ float red[4];
+  const int item = red_find_item(t, blockIdx.x);
+  const pwg_red_item it = t.it[item];
+  const long base = (long)(blockIdx.x - t.chunk_start[item]) * RED_CHUNK;
+  const long end = base + RED_CHUNK < it.n ? base + RED_CHUNK : it.n;
+  float s = 0.f;
+  for (long i = base + threadIdx.x; i < end; i += 256) s += red_term(it.mode, it.a[i], it.b ? it.b[i] : 0.f, it.c);
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s * it.scale;
+}
+// stage 2: one workgroup per output slot sums the partials of its items in chunk order
+__global__ void __launch_bounds__(256) multi_reduce_stage2_kernel(const RedItems t, const float* partial, float* out,
+                                                                  int accumulate) {
+  __shared__ float red[4];
+  const int slot = blockIdx.x;
+  float s = 0.f;
+  for (int i = 0; i < t.n_items; ++i) {
+    if (t.it[i].slot != slot) continue;
+    for (int c = t.chunk_start[i] + threadIdx.x; c < t.chunk_start[i + 1]; c += 256) s += partial[c];
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out[slot] = accumulate ? out[slot] + s : s;
+}
+// backward: da = gout[slot] * scale * dterm/da, db = -da (diff modes)
+__global__ void __launch_bounds__(256) multi_reduce_backward_kernel(const RedItems t, const float* gout) {
+  const int item = red_find_item(t, blockIdx.x);
+  const pwg_red_item it = t.it[item];
+  if (!it.da && !it.db) return;
+  const long base = (long)(blockIdx.x - t.chunk_start[item]) * RED_CHUNK;
+  const long end = base + RED_CHUNK < it.n ? base + RED_CHUNK : it.n;
+  const float gs = gout[it.slot] * it.scale;
+  for (long i = base + threadIdx.x; i < end; i += 256) {
+    const float g = gs * red_dterm(it.mode, it.a[i], it.b ? it.b[i] : 0.f, it.c);
+    if (it.da) it.da[i] = g;
+    if (it.db) it.db[i] = -g;
   }
 }
 
@@ -217,7 +279,7 @@ extern "C" int pwg_reduce_forward(const float* a, const float* b, float c, int64
                                   float* out, float* workspace, void* stream_) {
   PWG_REQUIRE(a && out && workspace, PWG_ERR_NULL, "reduce_forward: NULL pointer");
   PWG_REQUIRE((mode != RED_ABS_DIFF && mode != RED_SQ_DIFF) || b, PWG_ERR_NULL, "reduce_forward: mode needs b");
-  PWG_REQUIRE(n > 0 && mode >= 0 && mode <= 4, PWG_ERR_BAD_SHAPE, "reduce_forward: bad arguments");
+  PWG_REQUIRE(n > 0 && mode >= 0 && mode < RED_NUM_MODES, PWG_ERR_BAD_SHAPE, "reduce_forward: bad arguments");
   hipStream_t stream = (hipStream_t)stream_;
   long blocks = (n + 1023) / 1024;
   if (blocks > RED_BLOCKS) blocks = RED_BLOCKS;
@@ -231,7 +293,7 @@ extern "C" int pwg_reduce_forward(const float* a, const float* b, float c, int64
 extern "C" int pwg_reduce_backward(const float* a, const float* b, float c, int64_t n, int32_t mode, float scale,
                                    const float* gout, float* da, float* db, void* stream) {
   PWG_REQUIRE(a && gout && (da || db), PWG_ERR_NULL, "reduce_backward: NULL pointer");
-  PWG_REQUIRE(n > 0 && mode >= 0 && mode <= 4, PWG_ERR_BAD_SHAPE, "reduce_backward: bad arguments");
+  PWG_REQUIRE(n > 0 && mode >= 0 && mode < RED_NUM_MODES, PWG_ERR_BAD_SHAPE, "reduce_backward: bad arguments");
   long blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(reduce_backward_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, a, b, c, (long)n,
@@ -308,5 +370,68 @@ extern "C" int pwg_radam_step_dev(const void* chunks, int32_t n_chunks, const fl
   hipLaunchKernelGGL(radam_multi_dev_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream,
                      (const OptChunk*)chunks, hyper);
   PWG_CHECK_LAUNCH("radam_step_dev");
+  return PWG_OK;
+}
+
+// ---- multi-tensor reductions ---------------------------------------------------------------------
+static int red_build(const pwg_red_item* items, int32_t n_items, int32_t n_slots, RedItems* t, const char* what) {
+  PWG_REQUIRE(items, PWG_ERR_NULL, "%s: NULL item table", what);
+  PWG_REQUIRE(n_items > 0 && n_items <= PWG_RED_MAX_ITEMS && n_slots > 0, PWG_ERR_BAD_SHAPE,
+              "%s: need 1..%d items (got %d) and >= 1 slot", what, PWG_RED_MAX_ITEMS, n_items);
+  long chunks = 0;
+  for (int i = 0; i < n_items; ++i) {
+    const pwg_red_item& it = items[i];
+    PWG_REQUIRE(it.a, PWG_ERR_NULL, "%s: item %d has no operand", what, i);
+    PWG_REQUIRE(it.n > 0 && it.mode >= 0 && it.mode < RED_NUM_MODES && it.slot >= 0 && it.slot < n_slots,
+                PWG_ERR_BAD_SHAPE, "%s: item %d: bad n / mode / slot", what, i);
+    PWG_REQUIRE((it.mode != RED_ABS_DIFF && it.mode != RED_SQ_DIFF) || it.b, PWG_ERR_NULL,
+                "%s: item %d: mode %d needs a second operand", what, i, it.mode);
+    t->it[i] = it;
+    t->chunk_start[i] = (int)chunks;
+    chunks += (it.n + RED_CHUNK - 1) / RED_CHUNK;
+    PWG_REQUIRE(chunks < (1L << 30), PWG_ERR_BAD_SHAPE, "%s: too many elements", what);
+  }
+  t->chunk_start[n_items] = (int)chunks;
+  t->n_items = n_items;
+  return PWG_OK;
+}
+
+extern "C" size_t pwg_multi_reduce_workspace_floats(const pwg_red_item* items, int32_t n_items) {
+  if (!items || n_items <= 0) return 0;
+  size_t chunks = 0;
+  for (int i = 0; i < n_items; ++i) chunks += (size_t)((items[i].n + RED_CHUNK - 1) / RED_CHUNK);
+  return chunks;
+}
+
+extern "C" int pwg_multi_reduce_forward(const pwg_red_item* items, int32_t n_items, int32_t n_slots, float* out,
+                                        int32_t accumulate, float* workspace, void* stream_) {
+  RedItems t;
+  const int rc = red_build(items, n_items, n_slots, &t, "multi_reduce_forward");
+  if (rc != PWG_OK) return rc;
+  PWG_REQUIRE(out && workspace, PWG_ERR_NULL, "multi_reduce_forward: NULL pointer");
+  hipStream_t stream = (hipStream_t)stream_;
+  double bytes = 0;
+  for (int i = 0; i < n_items; ++i) bytes += 4.0 * items[i].n * (items[i].b ? 2 : 1);
+  ProfScope prof(stream, "multi_reduce_kernel", 0, bytes);
+  hipLaunchKernelGGL(multi_reduce_stage1_kernel, dim3(t.chunk_start[n_items]), dim3(256), 0, stream, t, workspace);
+  hipLaunchKernelGGL(multi_reduce_stage2_kernel, dim3(n_slots), dim3(256), 0, stream, t, (const float*)workspace, out,
+                     accumulate);
+  PWG_CHECK_LAUNCH("multi_reduce_forward");
+  return PWG_OK;
+}
+
+extern "C" int pwg_multi_reduce_backward(const pwg_red_item* items, int32_t n_items, int32_t n_slots,
+                                         const float* gout, void* stream_) {
+  RedItems t;
+  const int rc = red_build(items, n_items, n_slots, &t, "multi_reduce_backward");
+  if (rc != PWG_OK) return rc;
+  PWG_REQUIRE(gout, PWG_ERR_NULL, "multi_reduce_backward: NULL pointer");
+  hipStream_t stream = (hipStream_t)stream_;
+  double bytes = 0;
+  for (int i = 0; i < n_items; ++i)
+    bytes += 4.0 * items[i].n * ((items[i].b ? 2 : 1) + (items[i].da ? 1 : 0) + (items[i].db ? 1 : 0));
+  ProfScope prof(stream, "multi_reduce_backward_kernel", 0, bytes);
+  hipLaunchKernelGGL(multi_reduce_backward_kernel, dim3(t.chunk_start[n_items]), dim3(256), 0, stream, t, gout);
+  PWG_CHECK_LAUNCH("multi_reduce_backward");
   return PWG_OK;
 }

@@ -1,1 +1,1 @@
-from .reducer import GradReducer  # noqa: F401
+from .reducer import GradReducer, partition_modules  # noqa: F401

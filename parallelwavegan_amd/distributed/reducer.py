@@ -9,6 +9,16 @@ the exchange of the discriminator's 283 MB overlaps the rest of its backward pas
 optimizers then read the reduced gradients straight from the buckets (``flat_grads``) with the
 1/world_size averaging folded into the update kernel (``grad_scale``) -- no copy back.
 
+Collectives are always issued in bucket-index order (a complete bucket waits for its
+predecessors), whatever order the hooks fire in: every rank issues the same sequence even when
+the ranks execute the step differently (eager vs hipGraph replay, other stream interleaving).
+
+``groups``: optional partition of the parameters into *exchange groups*, in the order in which
+their gradients become available.  Buckets never straddle a group, so a caller that produces the
+gradients group by group -- the trainer's hipGraph mode replays the discriminator backward as one
+graph per group -- can start group k's all-reduce (:meth:`exchange_group`) while group k+1 is
+still being computed.
+
 Buckets are large (default 64 MiB): xGMI is a point-to-point mesh (7 links per GPU), so a
 collective is per-link bound and a few big messages beat many small ones.
 """
@@ -16,9 +26,29 @@ import torch
 import torch.distributed as dist
 
 
+def partition_modules(modules, n_groups):
+    """Exchange groups for :class:`GradReducer` from a list of independent sub-networks: contiguous runs
+    of ``modules`` with roughly equal parameter bytes; inside a group the parameters are listed in
+    reverse registration order (the order a backward pass produces their gradients)."""
+    sizes = [sum(p.numel() for p in m.parameters()) for m in modules]
+    n_groups = max(1, min(int(n_groups), len(modules)))
+    total, groups, cur, acc = float(sum(sizes)), [], [], 0.0
+    for i, (m, sz) in enumerate(zip(modules, sizes)):
+        cur.append(m)
+        acc += sz
+        left_modules, left_groups = len(modules) - i - 1, n_groups - len(groups) - 1
+        if left_groups > 0 and (acc >= total * (len(groups) + 1) / n_groups or left_modules <= left_groups):
+            groups.append(cur)
+            cur = []
+    if cur:
+        groups.append(cur)
+    return [[p for m in reversed(g) for p in reversed(list(m.parameters()))] for g in groups]
+
+
 class _Bucket:
-    def __init__(self, params, device):
+    def __init__(self, params, device, group):
         self.params = params
+        self.group = group
         self.offsets = {}
         n = 0
         for p in params:
@@ -28,29 +58,45 @@ class _Bucket:
         self.views = {p: self.flat[o:o + p.numel()].view_as(p) for p, o in self.offsets.items()}
         self.pending = len(params)
         self.work = None
+        self.launched = False
+        self.events = []  # one per hook copy of the current step (the copies may run on several streams)
 
 
 class GradReducer:
-    def __init__(self, params, bucket_bytes=64 << 20, process_group=None):
+    def __init__(self, params, bucket_bytes=64 << 20, process_group=None, groups=None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         params = [p for p in params]
         self.params = params
+        if groups is None:
+            groups = [list(reversed(params))]
+        else:
+            groups = [list(g) for g in groups if len(g)]
+            seen = {id(p) for g in groups for p in g}
+            assert len(seen) == sum(len(g) for g in groups), "a parameter appears in two exchange groups"
+            rest = [p for p in reversed(params) if id(p) not in seen]
+            if rest:
+                groups.append(rest)
+        self.groups = groups
         self.buckets = []
-        cur, cur_bytes = [], 0
-        for p in reversed(params):
-            cur.append(p)
-            cur_bytes += p.numel() * 4
-            if cur_bytes >= bucket_bytes:
-                self.buckets.append(_Bucket(cur, p.device))
-                cur, cur_bytes = [], 0
-        if cur:
-            self.buckets.append(_Bucket(cur, cur[0].device))
+        for gi, gparams in enumerate(groups):
+            cur, cur_bytes = [], 0
+            for p in gparams:
+                cur.append(p)
+                cur_bytes += p.numel() * 4
+                if cur_bytes >= bucket_bytes:
+                    self.buckets.append(_Bucket(cur, p.device, gi))
+                    cur, cur_bytes = [], 0
+            if cur:
+                self.buckets.append(_Bucket(cur, cur[0].device, gi))
         self.bucket_of = {p: b for b in self.buckets for p in b.params}
         self.flat_grads = {p: b.views[p] for b in self.buckets for p in b.params}
         self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in params]
         self.enabled = True
-        self.defer = False  # True while a hipGraph is being captured: hooks fill buckets, nothing is launched
+        self.defer = False  # True: hooks only fill the buckets (hipGraph capture / replay); the caller exchanges
+        self.skip_comm = False  # measurement aid: run the step without its collectives (bench: exposed time)
+        self._next = 0  # index of the next bucket to launch (collectives go out in bucket order)
+        self.bytes = sum(b.flat.numel() * 4 for b in self.buckets)
 
     def broadcast_parameters(self, tensors, src=0):
         """Rank 0's parameters and buffers become everyone's (as DDP does at wrap time)."""
@@ -63,7 +109,19 @@ class GradReducer:
         for b in self.buckets:
             b.pending = sum(1 for p in b.params if p.requires_grad)
             b.work = None
+            b.launched = False
+            b.events = []
             b.flat.zero_()  # parameters that receive no gradient this step contribute exactly 0
+        self._next = 0
+
+    def begin_replay(self):
+        """Host bookkeeping of :meth:`prepare` for a step whose kernels (incl. the bucket zero-fill and
+        the hook copies) are replayed from a captured hipGraph."""
+        for b in self.buckets:
+            b.pending = 0
+            b.work = None
+            b.launched = False
+        self._next = 0
 
     def _hook(self, p):
         if not self.enabled:
@@ -71,22 +129,54 @@ class GradReducer:
         b = self.bucket_of[p]
         b.views[p].copy_(p.grad)
         p.grad = None  # the bucket slot now owns this gradient
+        if not self.defer and b.flat.is_cuda:
+            # autograd runs this hook on the stream of the node that produced the gradient; with the
+            # sub-discriminators forked onto side streams one bucket is filled from several streams, and
+            # the collective (launched from whichever hook completes the bucket) must wait for all of them
+            ev = torch.cuda.Event()
+            ev.record()
+            b.events.append(ev)
         b.pending -= 1
-        if b.pending == 0:
-            self._launch(b)
+        if b.pending == 0 and not self.defer:
+            self._launch_ready()
 
-    def _launch(self, b):
-        if self.world > 1 and not self.defer:
+    def _all_reduce(self, b):
+        b.launched = True
+        if b.events:
+            cur = torch.cuda.current_stream(b.flat.device)
+            for ev in b.events:
+                cur.wait_event(ev)
+            b.events = []
+        if self.world > 1 and not self.skip_comm:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
+    def _launch_ready(self):
+        """Launch, in bucket order, every complete bucket whose predecessors have been launched."""
+        while self._next < len(self.buckets) and self.buckets[self._next].pending <= 0:
+            self._all_reduce(self.buckets[self._next])
+            self._next += 1
+
+    def exchange_group(self, gi):
+        """Start (asynchronously) the all-reduce of every bucket of exchange group ``gi``; groups must
+        be exchanged in index order.  hipGraph mode: the buckets were filled by the replayed graph
+        segment of this group, whose capture recorded the hook copies but no collective."""
+        for i, b in enumerate(self.buckets):
+            if b.group == gi and not b.launched:
+                assert i == self._next, "exchange groups out of order"
+                self._all_reduce(b)
+                self._next += 1
+
     def exchange_all(self):
-        """All-reduce every bucket now and wait (hipGraph mode: the buckets were filled by a replayed
-        graph, whose capture recorded the hook copies but no collective)."""
-        if self.world > 1:
-            works = [dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                     for b in self.buckets]
-            for w in works:
-                w.wait()
+        """All-reduce every bucket not yet launched and wait."""
+        for gi in range(len(self.groups)):
+            self.exchange_group(gi)
+        self.wait_all()
+
+    def wait_all(self):
+        for b in self.buckets:
+            if b.work is not None:
+                b.work.wait()
+                b.work = None
 
     def finish(self):
         """Wait for every exchange (parameters that received no gradient count as zero);
@@ -96,13 +186,9 @@ class GradReducer:
                 b.pending = 0
             return 1.0 / self.world
         for b in self.buckets:
-            if b.pending > 0:  # some parameters got no gradient: exchange the (zero-filled) rest
-                self._launch(b)
-                b.pending = 0
-        for b in self.buckets:
-            if b.work is not None:
-                b.work.wait()
-                b.work = None
+            b.pending = 0  # parameters without a gradient this step: their (zero-filled) slots go out as they are
+        self._launch_ready()
+        self.wait_all()
         return 1.0 / self.world
 
     def remove(self):

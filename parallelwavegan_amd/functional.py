@@ -577,7 +577,7 @@ class LogClampFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------
 # loss reductions
 # ---------------------------------------------------------------------------------------------
-RED = {"abs_diff": 0, "sq_diff": 1, "sq": 2, "sq_diff_const": 3, "sum": 4}
+RED = {"abs_diff": 0, "sq_diff": 1, "sq": 2, "sq_diff_const": 3, "sum": 4, "hinge_real": 5, "hinge_fake": 6}
 
 
 class ReduceFn(torch.autograd.Function):
@@ -611,6 +611,69 @@ class ReduceFn(torch.autograd.Function):
             _lib.check(_L().pwg_reduce_backward(_ptr(a), _ptr(b), const, a.numel(), mode, scale, _ptr(gout), _ptr(da),
                                                 _ptr(db), _stream()), "reduce_backward")
         return da, db, None, None, None
+
+
+class MultiReduceFn(torch.autograd.Function):
+    """(n_slots,) tensor  out[slot] = sum_items scale * sum_i term_mode(a_i, b_i | const)  over MANY tensors
+    with one launch pair (``pwg_multi_reduce_*``): the loops over discriminators x layers of the
+    feature-matching and adversarial losses as a single multi-tensor reduction.
+
+    ``spec``: list of ``(mode, scale, const, slot)`` per item; ``tensors``: a_0, b_0, a_1, b_1, ...
+    (``b_i`` None for the unary modes).  Deterministic: per-chunk partial sums, summed in item order."""
+
+    @staticmethod
+    def _items(spec, ops_, grads=None):
+        arr = (_lib.RedItem * len(spec))()
+        for i, (mode, scale, const, slot) in enumerate(spec):
+            a, b = ops_[2 * i], ops_[2 * i + 1]
+            it = arr[i]
+            it.a, it.b = a.data_ptr(), (None if b is None else b.data_ptr())
+            if grads is not None:
+                da, db = grads[2 * i], grads[2 * i + 1]
+                it.da, it.db = (None if da is None else da.data_ptr()), (None if db is None else db.data_ptr())
+            it.n, it.mode, it.slot, it.scale, it.c = a.numel(), RED[mode], int(slot), float(scale), float(const)
+        return arr
+
+    @staticmethod
+    def forward(ctx, spec, n_slots, *tensors):
+        assert len(tensors) == 2 * len(spec) and len(spec) > 0
+        ts = [None if t is None else _c(t) for t in tensors]
+        _require_device(*ts)
+        for i in range(len(spec)):
+            a, b = ts[2 * i], ts[2 * i + 1]
+            assert b is None or b.shape == a.shape, (tuple(a.shape), tuple(b.shape))
+        dev = ts[0].device
+        out = torch.empty(n_slots, device=dev, dtype=torch.float32)
+        for first in range(0, len(spec), _lib.RED_MAX_ITEMS):
+            sub = spec[first:first + _lib.RED_MAX_ITEMS]
+            items = MultiReduceFn._items(sub, ts[2 * first:2 * (first + len(sub))])
+            ws = torch.empty(max(1, _L().pwg_multi_reduce_workspace_floats(items, len(sub))), device=dev,
+                             dtype=torch.float32)
+            _lib.check(_L().pwg_multi_reduce_forward(items, len(sub), n_slots, _ptr(out), int(first > 0), _ptr(ws),
+                                                     _stream()), "multi_reduce_forward")
+        ctx.spec, ctx.n_slots = spec, n_slots
+        ctx.save_for_backward(*ts)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        ts = ctx.saved_tensors
+        spec = ctx.spec
+        gout = _c(gout)
+        grads = []
+        for i in range(len(spec)):
+            a, b = ts[2 * i], ts[2 * i + 1]
+            grads.append(torch.empty_like(a) if ctx.needs_input_grad[2 + 2 * i] else None)
+            grads.append(torch.empty_like(b) if (b is not None and ctx.needs_input_grad[3 + 2 * i]) else None)
+        for first in range(0, len(spec), _lib.RED_MAX_ITEMS):
+            sub = spec[first:first + _lib.RED_MAX_ITEMS]
+            sl = slice(2 * first, 2 * (first + len(sub)))
+            if all(g is None for g in grads[sl]):
+                continue
+            items = MultiReduceFn._items(sub, ts[sl], grads[sl])
+            _lib.check(_L().pwg_multi_reduce_backward(items, len(sub), ctx.n_slots, _ptr(gout), _stream()),
+                       "multi_reduce_backward")
+        return (None, None) + tuple(grads)
 
 
 def l1_mean(a, b):

@@ -9,6 +9,7 @@ from .conv import Conv1d as _Conv1d
 
 
 from .causal_conv import CausalConv1d  # noqa: E402  (depends on .conv only)
+from .dropout import Dropout as _Dropout  # noqa: E402
 
 
 class Conv1d(_Conv1d):
@@ -31,7 +32,7 @@ class Conv1d1x1(Conv1d):
 
 class WaveNetResidualBlock(torch.nn.Module):
     """Gated residual block of the PWG generator (layers/residual_block.py:43-140): dilated conv ->
-    + aux 1x1 -> tanh * sigmoid -> skip 1x1 and out 1x1 (+ residual) * sqrt(0.5).  Five launches:
+    + aux 1x1 -> tanh * sigmoid -> skip 1x1 and out 1x1 (+ residual) * sqrt(0.5).  Five launches (+1 for the dropout mask when ``dropout > 0`` in training):
     aux conv, dilated conv (+aux fused as addend), gate, skip conv (+running skip sum fused), out conv
     (+residual and the sqrt(0.5) scale fused)."""
 
@@ -39,6 +40,7 @@ class WaveNetResidualBlock(torch.nn.Module):
                  dropout=0.0, dilation=1, bias=True, use_causal_conv=False):
         super().__init__()
         self.dropout = dropout
+        self._drop = _Dropout(dropout)  # parameter-free: no state-dict entries
         self.use_causal_conv = use_causal_conv
         if use_causal_conv:
             # the reference pads (k-1)*d on both sides and drops the future part of the output
@@ -57,10 +59,9 @@ class WaveNetResidualBlock(torch.nn.Module):
     def forward(self, x, c, skips=None, skip_scale=1.0):
         """Returns (x_out, skips + s) -- the running skip sum is an addend of the skip conv's epilogue
         (``skip_scale`` is the final ``sqrt(1/layers)`` of the generator, applied by the last block)."""
-        if self.dropout > 0.0 and self.training:
-            raise NotImplementedError("dropout > 0 in training has no gfx950 kernel (the YAML configs use 0.0)")
         aux = self.conv1x1_aux(c) if (c is not None and self.conv1x1_aux is not None) else None
-        z = self.conv(x, add1=aux)
+        # F.dropout on the dilated conv's input only; the residual path keeps x (residual_block.py:114-116)
+        z = self.conv(self._drop(x), add1=aux)
         g = Fn.GateFn.apply(z)
         s = self.conv1x1_skip(g, add1=skips, out_mul=skip_scale)
         x = self.conv1x1_out(g, add1=x, out_mul=math.sqrt(0.5))

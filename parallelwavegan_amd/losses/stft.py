@@ -44,7 +44,11 @@ class STFTMagnitude(torch.nn.Module):
         self.taps = int(math.ceil(win_length / hop_size))
         off = (fft_size - win_length) // 2  # torch pads the window to n_fft, centred
         self.frame_offset = off
-        win = _window(window, win_length) if window is not None else np.ones(win_length)
+        if isinstance(window, (np.ndarray, torch.Tensor)):  # explicit window samples (losses.stft_loss.stft)
+            win = np.asarray(window.detach().cpu() if isinstance(window, torch.Tensor) else window, dtype=np.float64)
+            assert win.shape == (win_length,), (win.shape, win_length)
+        else:
+            win = _window(window, win_length) if window is not None else np.ones(win_length)
         n = np.arange(self.taps * hop_size)
         valid = n < win_length
         w = np.where(valid, win[np.minimum(n, win_length - 1)], 0.0)

@@ -5,10 +5,21 @@ from .. import functional as Fn
 from .stft import STFTMagnitude
 
 
+_STFT_CACHE = {}
+
+
 def stft(x, fft_size, hop_size, win_length, window):
-    """Magnitude spectrogram (B, #frames, fft_size // 2 + 1) of x (B, T); ``window`` is the window
-    tensor of the reference signature and must be a (periodic) Hann window of ``win_length``."""
-    mod = STFTMagnitude(fft_size, hop_size, win_length, "hann").to(x.device)
+    """Magnitude spectrogram (B, #frames, fft_size // 2 + 1) of x (B, T) (losses/stft_loss.py:16-40);
+    ``window`` is the window TENSOR of the reference signature (any ``win_length`` samples) or a
+    window name.  The windowed DFT basis is built once per (sizes, window values)."""
+    if isinstance(window, torch.Tensor):
+        wkey = window.detach().cpu().numpy().tobytes()
+    else:
+        wkey = window
+    key = (fft_size, hop_size, win_length, wkey, str(x.device))
+    mod = _STFT_CACHE.get(key)
+    if mod is None:
+        mod = _STFT_CACHE[key] = STFTMagnitude(fft_size, hop_size, win_length, window).to(x.device)
     return mod(x).transpose(2, 1)
 
 

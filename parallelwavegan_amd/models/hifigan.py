@@ -404,6 +404,15 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
         self.msd.branch_streams = bool(value)
         self.mpd.branch_streams = bool(value)
 
+    def grad_groups(self, n_groups):
+        """Exchange groups for data-parallel training (distributed.GradReducer): the 3 + 5 sub-discriminators
+        share no parameters, so their backward passes can be issued -- and their gradients exchanged --
+        group by group.  Periods first: the scale discriminators' 1/2 and 1/4-rate passes are the
+        cheapest, which keeps the last (not overlappable) exchange next to the least compute."""
+        from ..distributed import partition_modules
+
+        return partition_modules(list(self.mpd.discriminators) + list(self.msd.discriminators), n_groups)
+
     def stateful_outputs(self):
         """Indices (into the returned list) of the sub-discriminators whose training-mode forward has a
         side effect -- the spectral-norm power iteration of the first scale discriminator.  The outputs

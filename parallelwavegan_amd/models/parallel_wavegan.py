@@ -9,14 +9,18 @@ import torch
 from .. import functional as Fn
 from ..layers import upsample
 from ..layers.activation import FusedActivation
+from ..layers.conv import Conv1d as _AnyConv1d
 from ..layers.residual_block import Conv1d, Conv1d1x1
 from ..layers.residual_block import WaveNetResidualBlock as ResidualBlock
 from ..layers.upsample import Conv2d as UpsampleConv2d
 
 
 def _norm_modules(module):
+    # every Conv1d / Conv2d of the tree, as the reference's ``isinstance(m, torch.nn.Conv1d) or ... Conv2d``
+    # (models/parallel_wavegan.py:187-195): includes the convolutions of a MelGAN upsampler, not its
+    # transposed convolutions
     for m in module.modules():
-        if isinstance(m, (Conv1d, UpsampleConv2d)):
+        if isinstance(m, (_AnyConv1d, UpsampleConv2d)):
             yield m
 
 
@@ -51,10 +55,17 @@ class ParallelWaveGANGenerator(torch.nn.Module, _WeightNormMixin):
             upsample_params = dict(upsample_params)
             upsample_params.update({"use_causal_conv": use_causal_conv})
             if upsample_net == "MelGANGenerator":
-                raise NotImplementedError("upsample_net=MelGANGenerator is not used by configs C1-C5")
-            if upsample_net == "ConvInUpsampleNetwork":
-                upsample_params.update({"aux_channels": aux_channels, "aux_context_window": aux_context_window})
-            self.upsample_net = getattr(upsample, upsample_net)(**upsample_params)
+                # a MelGAN generator as the mel upsampler (models/parallel_wavegan.py:90-98 of the reference):
+                # its out_channels must equal aux_channels; weight norm is applied once, by this model
+                assert aux_context_window == 0
+                from .melgan import MelGANGenerator
+
+                upsample_params.update({"use_weight_norm": False, "use_final_nonlinear_activation": False})
+                self.upsample_net = MelGANGenerator(**upsample_params)
+            else:
+                if upsample_net == "ConvInUpsampleNetwork":
+                    upsample_params.update({"aux_channels": aux_channels, "aux_context_window": aux_context_window})
+                self.upsample_net = getattr(upsample, upsample_net)(**upsample_params)
             self.upsample_factor = int(np.prod(upsample_params["upsample_scales"]))
         else:
             self.upsample_net = None

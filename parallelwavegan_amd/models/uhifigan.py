@@ -15,33 +15,10 @@ import torch
 from .. import functional as Fn
 from ..layers.activation import FusedActivation
 from ..layers.conv import Conv1d, ConvTranspose1d
+from ..layers.dropout import Dropout as _Dropout
 from ..layers.residual_block import HiFiGANResidualBlock as ResidualBlock
 
 __all__ = ["UHiFiGANGenerator"]
-
-
-class _Dropout(torch.nn.Module):
-    """torch.nn.Dropout stand-in (no parameters, no state-dict entries): identity in eval mode, HIP
-    dropout kernel in training.  The mask seed is (host seed) + (a device counter that the forward
-    advances), so eager steps and hipGraph replays both draw a new mask every call."""
-
-    def __init__(self, p):
-        super().__init__()
-        self.p = float(p)
-        self._counter = None  # int64 device scalar, created lazily on the input's device
-
-    def forward(self, x):
-        if not self.training or self.p == 0.0:
-            return x
-        if self._counter is None or self._counter.device != x.device:
-            self._counter = torch.zeros(1, dtype=torch.int64, device=x.device)
-        used = self._counter.clone()  # the value this call (and its backward) uses
-        self._counter += 7919           # plumbing: advance the device counter for the next call / replay
-        seed = (int(torch.initial_seed()) * 1000003 + id(self) % 65521) & ((1 << 62) - 1)
-        return Fn.DropoutFn.apply(x, self.p, seed, used)
-
-    def extra_repr(self):
-        return f"p={self.p}"
 
 
 def _each_conv(module):

@@ -28,6 +28,20 @@ def _capturing():
     return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
 
 
+def _reserve(pool, rows):
+    """Eager steps keep one pinned (rows, 6) int64 buffer in ``pool`` for the next hipGraph capture."""
+    if not pool or pool[-1].shape[0] < rows:
+        pool.append(torch.zeros((rows, 6), dtype=torch.int64).pin_memory())
+
+
+def _take_reserved(pool, rows):
+    for i in range(len(pool) - 1, -1, -1):
+        if pool[i].shape[0] >= rows:
+            return pool.pop(i)
+    raise RuntimeError("no pinned staging buffer is reserved for this capture: run one eager step of the same "
+                       "shapes before capturing the step in a hipGraph")
+
+
 class _FusedBase(torch.optim.Optimizer):
     _entry = None  # name of the C entry point
 
@@ -35,7 +49,7 @@ class _FusedBase(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self.grad_scale = 1.0
         self.flat_grads = None
-        self._dev = {}  # group index -> dict(hyper_dev, hyper_pin, table_pin, table_dev, n_chunks)
+        self._dev = {}  # group index -> dict(hyper_dev, table_dev, table_key, n_chunks, graph_tables)
         self._active = {}  # group index -> set of parameters that had a gradient at the last step()
 
     # ---- per-parameter state (torch-compatible layout)
@@ -75,13 +89,21 @@ class _FusedBase(torch.optim.Optimizer):
     def _slot(self, gi, device):
         d = self._dev.get(gi)
         if d is None:
-            d = dict(hyper_dev=torch.zeros(8, device=device, dtype=torch.float32),
-                     hyper_pin=torch.zeros(8, dtype=torch.float32).pin_memory(), table_pin=None, table_dev=None,
-                     n_chunks=0)
+            d = dict(hyper_dev=torch.zeros(8, device=device, dtype=torch.float32), table_dev=None, table_key=None,
+                     n_chunks=0, graph_tables=[], reserve=[])
             self._dev[gi] = d
         return d
 
     def _table(self, d, entries, device):
+        """Device table of 64 Ki-element chunks for this launch.
+
+        Host staging never outlives its copy: every upload goes through a FRESH pinned tensor (torch's
+        caching host allocator does not recycle a pinned block while a copy that reads it is pending),
+        so a host that runs several steps ahead of the device cannot overwrite a table whose upload has
+        not happened yet.  While a hipGraph is being captured the upload becomes a memcpy node that
+        re-reads its pinned source at every replay; that source is owned by this capture
+        (``graph_tables``) and never written again, so later eager steps or further captures (other
+        batch shapes) cannot redirect an already captured optimizer launch to stale gradient memory."""
         rows = []
         for p, g, m, v, vmax in entries:
             n = p.numel()
@@ -91,14 +113,23 @@ class _FusedBase(torch.optim.Optimizer):
                 b = off * 4
                 rows.append((pp + b, gp + b, mp + b, vp + b, (xp + b) if xp else 0, min(CHUNK, n - off)))
         arr = np.asarray(rows, dtype=np.int64)
-        if d["table_pin"] is None or d["table_pin"].shape[0] < arr.shape[0]:
-            if _capturing():
-                raise RuntimeError("the optimizer's chunk table must be sized before graph capture "
-                                   "(run one eager step first)")
-            d["table_pin"] = torch.zeros((arr.shape[0], 6), dtype=torch.int64).pin_memory()
-        d["table_pin"][: arr.shape[0]].copy_(torch.from_numpy(arr))
-        d["table_dev"] = d["table_pin"][: arr.shape[0]].to(device, non_blocking=True)
-        d["n_chunks"] = arr.shape[0]
+        capturing = _capturing()
+        if capturing:
+            # pinned memory cannot be allocated while a stream is capturing: take a buffer that an earlier
+            # eager step set aside for exactly this purpose (and that nothing else ever writes)
+            pin = _take_reserved(d["reserve"], arr.shape[0])
+            pin[: arr.shape[0]].copy_(torch.from_numpy(arr))
+            dev = pin[: arr.shape[0]].to(device, non_blocking=True)
+            d["graph_tables"].append((pin, dev))  # keep the memcpy node's source and target alive, untouched
+            return dev, arr.shape[0]
+        _reserve(d["reserve"], arr.shape[0])
+        key = hash(arr.tobytes())
+        if key == d["table_key"] and d["table_dev"] is not None:
+            return d["table_dev"], d["n_chunks"]  # same pointers as the previous eager step: table still valid
+        pin = torch.from_numpy(arr).pin_memory()
+        dev = pin.to(device, non_blocking=True)
+        d["table_dev"], d["table_key"], d["n_chunks"] = dev, key, arr.shape[0]
+        return dev, arr.shape[0]
 
     # ---- to be provided by subclasses
     def _hyper(self, group, t):
@@ -128,8 +159,9 @@ class _FusedBase(torch.optim.Optimizer):
                 raise RuntimeError("fused optimizers need one common step count per parameter group")
             d = self._slot(gi, dev)
             h = self._hyper(group, steps.pop())
-            d["hyper_pin"].copy_(torch.tensor(h + [float(self.grad_scale)], dtype=torch.float32))
-            d["hyper_dev"].copy_(d["hyper_pin"], non_blocking=True)
+            # fresh pinned staging per step (see _table): a pending upload is never overwritten by a later step
+            pin = torch.tensor(h + [float(self.grad_scale)], dtype=torch.float32).pin_memory()
+            d["hyper_dev"].copy_(pin, non_blocking=True)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -152,9 +184,9 @@ class _FusedBase(torch.optim.Optimizer):
             for p, g in pairs:
                 st = self._state_for(p, self._amsgrad(group))
                 entries.append((p, g, st["exp_avg"], st["exp_avg_sq"], st.get("max_exp_avg_sq")))
-            self._table(d, entries, pairs[0][0].device)
+            table, n_chunks = self._table(d, entries, pairs[0][0].device)
             fn = getattr(lib, self._entry)
-            _lib.check(fn(ctypes.c_void_p(d["table_dev"].data_ptr()), d["n_chunks"],
+            _lib.check(fn(ctypes.c_void_p(table.data_ptr()), n_chunks,
                           ctypes.c_void_p(d["hyper_dev"].data_ptr()), _stream()), self._entry)
         # parameters changed behind torch's back: invalidate the packed-weight caches of THESE parameters
         # (the other model's images -- e.g. the discriminator's during the generator step -- stay valid)
@@ -217,7 +249,17 @@ def clip_grad_norm_(params_and_grads, max_norm):
         n, gp = g.numel(), g.data_ptr()
         for off in range(0, n, CHUNK):
             rows.append((gp + off * 4, gp + off * 4, 0, 0, 0, min(CHUNK, n - off)))
-    table = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev)
+    arr = np.asarray(rows, dtype=np.int64)
+    capturing = _capturing()
+    pool = _CLIP_RESERVE.setdefault(tuple(g.numel() for g in grads), [])  # one pool per parameter set (G, D)
+    if capturing:
+        pin = _take_reserved(pool, arr.shape[0])  # see _FusedBase._table
+        pin[: arr.shape[0]].copy_(torch.from_numpy(arr))
+        table = pin[: arr.shape[0]].to(dev, non_blocking=True)
+        _GRAPH_KEEP.append(pin)  # the captured memcpy node re-reads it at every replay
+    else:
+        _reserve(pool, arr.shape[0])
+        table = torch.from_numpy(arr).pin_memory().to(dev, non_blocking=True)  # fresh staging per call
     out = torch.empty(2, device=dev, dtype=torch.float32)
     ws = torch.empty(len(rows), device=dev, dtype=torch.float32)
     _lib.check(_lib.lib().pwg_clip_grad_norm(ctypes.c_void_p(table.data_ptr()), len(rows), float(max_norm),
@@ -225,3 +267,7 @@ def clip_grad_norm_(params_and_grads, max_norm):
                                              _stream()), "clip_grad_norm")
     out._keep = table
     return out
+
+
+_GRAPH_KEEP = []
+_CLIP_RESERVE = {}

@@ -1,4 +1,5 @@
-"""Inference constructor and stats IO (drop-in subset of parallel_wavegan.utils.utils)."""
+"""Inference constructor, training-object factory and stats IO (drop-in subset of
+parallel_wavegan.utils.utils plus the object construction of parallel_wavegan.bin.train.main)."""
 import logging
 import os
 
@@ -61,3 +62,83 @@ def load_model(checkpoint, config=None, stats=None):
         model.pqmf = PQMF(**pqmf_params)
     logging.info(f"Loaded {generator_type} from {checkpoint}.")
     return model
+
+
+def build_from_config(config, device="cpu", only=None):
+    """Everything ``Trainer`` needs, built from a reference training YAML (already parsed into a dict):
+    ``(model, criterion, optimizer, scheduler)`` -- each a dict with the keys of the reference's
+    ``main()`` (/root/reference/parallel_wavegan/bin/train.py:1364-1493).  The same defaulting rules
+    ("keep compatibility": PWG generator / discriminator, RAdam, StepLR, ``use_*_loss`` flags written
+    back into ``config``) so that any recipe config that names in-scope classes works unchanged; the
+    classes themselves come from this package, i.e. run on the HIP kernels.
+
+    ``only``: optional subset of ("model", "criterion", "optimizer", "scheduler") to build (the rest
+    is returned as None); optimizers need the models, schedulers the optimizers."""
+    import torch.optim.lr_scheduler as lr_scheduler
+
+    from .. import losses, models, optimizers
+    from ..layers import PQMF
+
+    want = set(only) if only is not None else {"model", "criterion", "optimizer", "scheduler"}
+    if "scheduler" in want:
+        want.add("optimizer")
+    if "optimizer" in want:
+        want.add("model")
+    device = torch.device(device)
+
+    def cls(namespace, name, what):
+        if not hasattr(namespace, name):
+            raise NotImplementedError(f"{what} {name!r} is outside the accelerated hot path (SURVEY.md s2)")
+        return getattr(namespace, name)
+
+    model = criterion = optimizer = scheduler = None
+    if "model" in want:
+        g_params = {k.replace("upsample_kernal_sizes", "upsample_kernel_sizes"): v
+                    for k, v in config["generator_params"].items()}
+        model = {
+            "generator": cls(models, config.get("generator_type", "ParallelWaveGANGenerator"), "generator")(
+                **g_params).to(device),
+            "discriminator": cls(models, config.get("discriminator_type", "ParallelWaveGANDiscriminator"),
+                                 "discriminator")(**config["discriminator_params"]).to(device),
+        }
+    if "criterion" in want:
+        criterion = {
+            "gen_adv": losses.GeneratorAdversarialLoss(**config.get("generator_adv_loss_params", {})).to(device),
+            "dis_adv": losses.DiscriminatorAdversarialLoss(**config.get("discriminator_adv_loss_params", {})).to(device),
+        }
+        # the flags are normalised in place, as the reference does, because Trainer reads them back
+        config["use_stft_loss"] = bool(config.get("use_stft_loss", True))
+        if config["use_stft_loss"]:
+            criterion["stft"] = losses.MultiResolutionSTFTLoss(**config["stft_loss_params"]).to(device)
+        config["use_subband_stft_loss"] = bool(config.get("use_subband_stft_loss", False))
+        if config["use_subband_stft_loss"]:
+            assert config["generator_params"]["out_channels"] > 1
+            criterion["sub_stft"] = losses.MultiResolutionSTFTLoss(**config["subband_stft_loss_params"]).to(device)
+        config["use_feat_match_loss"] = bool(config.get("use_feat_match_loss", False))
+        if config["use_feat_match_loss"]:
+            criterion["feat_match"] = losses.FeatureMatchLoss(**config.get("feat_match_loss_params", {})).to(device)
+        config["use_mel_loss"] = bool(config.get("use_mel_loss", False))
+        if config["use_mel_loss"]:
+            mel_params = config.get("mel_loss_params")
+            if mel_params is None:  # fall back to the feature-extraction settings of the recipe
+                mel_params = dict(fs=config["sampling_rate"], fft_size=config["fft_size"], hop_size=config["hop_size"],
+                                  win_length=config["win_length"], window=config["window"],
+                                  num_mels=config["num_mels"], fmin=config["fmin"], fmax=config["fmax"])
+            criterion["mel"] = losses.MelSpectrogramLoss(**mel_params).to(device)
+        if config.get("use_duration_loss", False):
+            raise NotImplementedError("duration loss belongs to the discrete-symbol models (out of scope, SURVEY.md s2)")
+        config["use_duration_loss"] = False
+        if config["generator_params"]["out_channels"] > 1:
+            criterion["pqmf"] = PQMF(subbands=config["generator_params"]["out_channels"],
+                                     **config.get("pqmf_params", {})).to(device)
+    if "optimizer" in want:
+        optimizer = {
+            k: cls(optimizers, config.get(f"{k}_optimizer_type", "RAdam"), "optimizer")(
+                model[k].parameters(), **config[f"{k}_optimizer_params"])
+            for k in ("generator", "discriminator")}
+    if "scheduler" in want:
+        scheduler = {
+            k: cls(lr_scheduler, config.get(f"{k}_scheduler_type", "StepLR"), "scheduler")(
+                optimizer=optimizer[k], **config[f"{k}_scheduler_params"])
+            for k in ("generator", "discriminator")}
+    return model, criterion, optimizer, scheduler

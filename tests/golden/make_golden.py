@@ -128,6 +128,43 @@ def losses(name, seed):
     print(name, {k: (v if np.isscalar(v) else v.shape) for k, v in out.items()})
 
 
+def adv_losses(name, seed):
+    """GeneratorAdversarialLoss / DiscriminatorAdversarialLoss (mse AND hinge) and FeatureMatchLoss of the
+    reference: values and gradients w.r.t. the logits / feature maps, every averaging switch."""
+    import parallel_wavegan.losses as RL
+
+    out = {}
+    real = synth.adv_logits(seed)
+    for lt in ("mse", "hinge"):
+        for avg in (True, False):
+            fake = [[t.clone().requires_grad_() for t in o] for o in synth.adv_logits(seed + 1)]
+            g = RL.GeneratorAdversarialLoss(average_by_discriminators=avg, loss_type=lt)(fake)
+            g.backward()
+            tag = f"{lt}_{int(avg)}"
+            out[f"gen_{tag}"] = g.item()
+            out[f"gen_{tag}_grad"] = np.concatenate([o[-1].grad.numpy().ravel() for o in fake])
+            fake = [[t.clone().requires_grad_() for t in o] for o in synth.adv_logits(seed + 1)]
+            realg = [[t.clone().requires_grad_() for t in o] for o in real]
+            r, f = RL.DiscriminatorAdversarialLoss(average_by_discriminators=avg, loss_type=lt)(fake, realg)
+            (r + 2.0 * f).backward()
+            out[f"dis_real_{tag}"], out[f"dis_fake_{tag}"] = r.item(), f.item()
+            out[f"dis_{tag}_grad_real"] = np.concatenate([o[-1].grad.numpy().ravel() for o in realg])
+            out[f"dis_{tag}_grad_fake"] = np.concatenate([o[-1].grad.numpy().ravel() for o in fake])
+    for al in (True, False):
+        for ad in (True, False):
+            for fin in (True, False):
+                fake = [[t.clone().requires_grad_() for t in o] for o in synth.adv_logits(seed + 1)]
+                fm = RL.FeatureMatchLoss(average_by_layers=al, average_by_discriminators=ad,
+                                         include_final_outputs=fin)(fake, real)
+                fm.backward()
+                tag = f"{int(al)}{int(ad)}{int(fin)}"
+                out[f"fm_{tag}"] = fm.item()
+                out[f"fm_{tag}_grad"] = np.concatenate(
+                    [(t.grad if t.grad is not None else torch.zeros_like(t)).numpy().ravel() for o in fake for t in o])
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), meta=np.array([seed]), **out)
+    print(name, len(out), "entries")
+
+
 def hifigan_train_steps(name, seed, batch=2, n_steps=2):
     """Two full ``Trainer._train_step`` calls of the reference (HiFi-GAN V1 YAML, G+D active)."""
     import tempfile
@@ -226,6 +263,23 @@ def pwg(name, seed):
     print(name, "G std %.4f max %.4f | D std %.4f" % (y.std().item(), y.abs().max().item(), out["d_y"].std()))
 
 
+def pwg_melgan_upsampler(name, seed):
+    """ParallelWaveGANGenerator(upsample_net="MelGANGenerator") (models/parallel_wavegan.py:90-98), small."""
+    import copy
+
+    import parallel_wavegan.models as RM
+
+    g = RM.ParallelWaveGANGenerator(**copy.deepcopy(synth.PWG_MELGAN_UPSAMPLER))
+    g.load_state_dict(synth.synth_state_dict(g.state_dict(), seed=seed, g_scale=synth.PWG_G_SCALE))
+    g.eval()
+    c = synth.synth_input("c", (2, 80, 9), seed=seed)
+    z = synth.synth_input("z", (2, 1, 9 * 256), seed=seed)
+    with torch.no_grad():
+        y = g(z, c)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), meta=np.array([seed]), y=y.numpy())
+    print(name, tuple(y.shape), float(y.abs().max()))
+
+
 def mb_melgan(name, seed):
     """Multi-band MelGAN.v2 generator (+PQMF synthesis), MelGAN multi-scale discriminator, PQMF."""
     import parallel_wavegan.layers as RLy
@@ -269,6 +323,7 @@ def _run_reference_trainer(cfg, model, criterion, optimizer, scheduler, batches,
                  scheduler=scheduler, config=cfg, device=torch.device("cpu"))
     tr.tqdm = tqdm(disable=True)
     out, prev = {}, {}
+    p0 = {key: {n: p.detach().clone() for n, p in model[key].named_parameters()} for key in model}
     for i, b in enumerate(batches):
         tr._train_step(b)
         cur = dict(tr.total_train_loss)
@@ -281,6 +336,11 @@ def _run_reference_trainer(cfg, model, criterion, optimizer, scheduler, batches,
                 norms = {names[p]: float(s["exp_avg"].double().norm()) for p, s in optimizer[key].state.items()}
                 out[f"momnorm_names/{key}"] = np.array(sorted(norms))
                 out[f"momnorm/{key}"] = np.array([norms[k] for k in sorted(norms)])
+                # <first update, first moment> per tensor: pins the optimizer update without being limited by
+                # the sign noise of near-zero gradient entries (they carry no weight in this inner product)
+                dots = {names[p]: float(((p.detach() - p0[key][names[p]]).double() * s["exp_avg"].double()).sum())
+                        for p, s in optimizer[key].state.items()}
+                out[f"upddot/{key}"] = np.array([dots[k] for k in sorted(dots)])
     for key, tag in (("generator", "g"), ("discriminator", "d")):
         sd = model[key].state_dict()
         names = sorted(sd)
@@ -436,11 +496,13 @@ JOBS = {
     "hifigan_v1_libritts_g": lambda: hifigan_generator("hifigan_v1_libritts_g", synth.HIFIGAN_V1_LIBRITTS, 1, 28, 12),
     "hifigan_tiny_g": lambda: hifigan_generator("hifigan_tiny_g", synth.HIFIGAN_TINY, 3, 21, 13),
     "pwg_v1": lambda: pwg("pwg_v1", 51),
+    "pwg_melgan_upsampler": lambda: pwg_melgan_upsampler("pwg_melgan_upsampler", 53),
     "mb_melgan_v2": lambda: mb_melgan("mb_melgan_v2", 61),
     "pwg_v1_train": lambda: pwg_train_steps("pwg_v1_train", 71),
     "mb_melgan_v2_train": lambda: mb_melgan_train_steps("mb_melgan_v2_train", 81),
     "hifigan_v1_d": lambda: hifigan_discriminator("hifigan_v1_d", 21),
     "losses": lambda: losses("losses", 31),
+    "adv_losses": lambda: adv_losses("adv_losses", 33),
     "hifigan_v1_train": lambda: hifigan_train_steps("hifigan_v1_train", 41),
 }
 

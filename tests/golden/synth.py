@@ -136,3 +136,23 @@ PQMF_BUFFERS = ("analysis_filter", "synthesis_filter", "updown_filter")  # fixed
 UHIFIGAN_TINY = dict(in_channels=80, out_channels=1, channels=16, kernel_size=7, downsample_scales=(4, 2),
                      downsample_kernel_sizes=(8, 4), upsample_scales=(2, 4), upsample_kernel_sizes=(4, 8),
                      resblock_kernel_sizes=(3, 7), resblock_dilations=[(1, 3, 5), (1, 3)], dropout=0.3)
+
+
+PWG_MELGAN_UPSAMPLER = dict(
+    aux_context_window=0, layers=6, stacks=2,
+    upsample_net="MelGANGenerator",
+    upsample_params=dict(in_channels=80, out_channels=80, kernel_size=7, channels=256, upsample_scales=[4, 4, 4, 4],
+                         stack_kernel_size=3, stacks=2),
+)
+
+
+def adv_logits(seed):
+    """Synthetic discriminator outputs (3 discriminators x [2 feature maps + logits]); the logits hold
+    exact ties of the hinge terms (x == 1, x == -1) to pin torch.min's 1/2 tie gradient."""
+    outs = []
+    for i, t in enumerate((50, 37, 9)):
+        fm = [synth_input(f"adv_f{i}{j}", (2, 4 * (j + 1), t), seed=seed) for j in range(2)]
+        logit = 1.5 * synth_input(f"adv_l{i}", (2, 1, t), seed=seed)
+        logit[0, 0, 0], logit[1, 0, 1] = 1.0, -1.0
+        outs.append(fm + [logit])
+    return outs

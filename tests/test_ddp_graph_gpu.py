@@ -24,8 +24,8 @@ def _worker(rank, world, port, use_graph, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    tr, _, model, opt = build_trainer(dev, 41, 1.25, 2, N_STEPS, distributed=True)
-    tr.config.update(use_hip_graph=use_graph, graph_warmup_steps=2, rank=rank)
+    tr, _, model, opt = build_trainer(dev, 41, 1.25, 2, N_STEPS, distributed=True, use_hip_graph=use_graph,
+                                      graph_warmup_steps=2, rank=rank)
     tr.tqdm = None
     # every rank trains on its own shard
     c = synth.synth_input("c", (2, 80, 32), seed=100 + rank)
@@ -38,7 +38,11 @@ def _worker(rank, world, port, use_graph, out_dir):
     if use_graph:
         assert len(tr._graphs) == 1
         (entry,) = tr._graphs.values()
-        assert [k for _, k in entry["segments"]] == ["generator", "discriminator", None]
+        # G backward | exchange | G update + D forward + D backward group 0 | exchange 0 | group 1 | ... | D update
+        n_groups = len(tr.reducers["discriminator"].groups)
+        assert n_groups == 4
+        assert [k for _, k in entry["segments"]] == (
+            [("generator", None)] + [("discriminator", gi) for gi in range(n_groups)] + [None])
     sums = {k: float(sum(p.double().sum().item() for p in model[k].parameters())) for k in model}
     absd = {k: float(sum(p.double().abs().sum().item() for p in model[k].parameters())) for k in model}
     torch.save(dict(log=log, sums=sums, absd=absd), os.path.join(out_dir, f"r{rank}_g{int(use_graph)}.pt"))

@@ -42,3 +42,21 @@ def test_generator_matches_oracle_various_lengths(frames, batch, device):
         ref = torch_cpu.hifigan_generator(sd, c, **cfg)
     assert y.shape == ref.shape
     assert max_abs(y, ref) <= WAVE_TOL
+
+
+def test_generator_at_benchmark_length_matches_oracle(device):
+    """bench.py's utterance length (800 frames = 204 800 samples per item): the long-T launches pick the
+    wide tile configurations (128 x 128 / 128 x 256 column tiles) that short test inputs never reach."""
+    cfg = synth.HIFIGAN_V1
+    g = HiFiGANGenerator(**cfg)
+    sd = synth_for(g, 9, 1.25)
+    g.load_state_dict(sd)
+    g.remove_weight_norm()
+    sd = {k: v.detach().clone() for k, v in g.state_dict().items()}
+    g = g.to(device).eval()
+    c = synth.synth_input("c", (2, 80, 800), seed=800)
+    with torch.no_grad():
+        y = g(c.to(device))
+        ref = torch_cpu.hifigan_generator(sd, c, **cfg)
+    assert y.shape == ref.shape == (2, 1, 800 * 256)
+    assert max_abs(y, ref) <= WAVE_TOL

@@ -17,7 +17,7 @@ from tests.util import load_golden
 pytestmark = pytest.mark.gpu
 
 
-def build_trainer(device, seed, g_scale, batch, n_steps, distributed=False):
+def build_trainer(device, seed, g_scale, batch, n_steps, distributed=False, **overrides):
     g = HiFiGANGenerator(**synth.HIFIGAN_V1)
     d = HiFiGANMultiScaleMultiPeriodDiscriminator(**D_PARAMS)
     g.load_state_dict(synth.synth_state_dict(g.state_dict(), seed=seed, g_scale=g_scale))
@@ -40,6 +40,7 @@ def build_trainer(device, seed, g_scale, batch, n_steps, distributed=False):
                   generator_train_start_steps=1, discriminator_train_start_steps=0, train_max_steps=2 + n_steps,
                   save_interval_steps=10 ** 9, eval_interval_steps=10 ** 9, log_interval_steps=10 ** 9,
                   distributed=distributed, rank=0, outdir=tempfile.mkdtemp(), progress=False)
+    config.update(overrides)
     c = synth.synth_input("c", (batch, 80, 32), seed=seed)
     y = 0.5 * synth.synth_input("y", (batch, 1, 8192), seed=seed)
     batches = [((c,), y)] * n_steps
@@ -135,3 +136,37 @@ def test_hip_graph_training_matches_eager(device):
     for i, (a, b) in enumerate(zip(results[False], results[True])):
         for k in a:
             assert abs(a[k] - b[k]) <= 2e-4 * max(abs(a[k]), 1e-3), (i, k, a[k], b[k])
+
+
+def test_hip_graph_two_batch_shapes_without_host_syncs(device):
+    """Two graphs (two batch shapes, e.g. the last partial batch of an epoch) captured by one trainer and
+    replayed alternately, with NO host synchronisation between steps: each captured optimizer launch must
+    keep reading its own chunk table / gradients (a shared, rewritten staging buffer would silently send a
+    replay of the first graph to the second graph's -- or freed -- gradient memory), and the per-step
+    scalars (lr, bias corrections) staged by the host must not be overwritten before their upload ran."""
+    from tests.golden import synth
+
+    order = [0, 0, 0, 1, 1, 1, 0, 1, 0, 1, 1, 0]  # step 3 of each shape captures; later ones replay
+    finals = {}
+    for use_graph in (False, True):
+        tr, _, model, opt = build_trainer(device, 43, 1.25, 2, len(order))
+        tr.config["use_hip_graph"] = use_graph
+        tr.config["graph_warmup_steps"] = 2
+        tr.tqdm = None
+        shapes = [((synth.synth_input("c", (b, 80, 32), seed=50 + b),), 0.5 * synth.synth_input("y", (b, 1, 8192), seed=50 + b))
+                  for b in (2, 1)]
+        for i in order:
+            tr._train_step(shapes[i])
+        if use_graph:
+            assert len(tr._graphs) == 2
+        tr._flush_pending()
+        torch.cuda.synchronize()
+        finals[use_graph] = (dict(tr.total_train_loss),
+                             {k: [p.detach().double().cpu() for p in model[k].parameters()] for k in model})
+    la, lb = finals[False][0], finals[True][0]
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 2e-4 * max(abs(la[k]), 1e-3), (k, la[k], lb[k])
+    for k in ("generator", "discriminator"):
+        for a, b in zip(finals[False][1][k], finals[True][1][k]):
+            # 12 Adam steps at lr 2e-4: a replay that used stale gradients or scalars moves parameters by >> 1e-5
+            assert (a - b).abs().max().item() <= 2e-5 + 1e-4 * a.abs().max().item()

@@ -85,3 +85,17 @@ def test_adversarial_and_feature_match_losses_vs_oracle(device):
     for a_l, b_l in zip(fh_d, fh_c):
         for a, b in zip(a_l, b_l):
             assert max_abs(a.grad, b.grad) <= 1e-6
+
+
+def test_stft_function_honours_its_window_argument(device):
+    """losses.stft(x, fft, hop, win, window) with the reference's signature (losses/stft_loss.py:16-40): the
+    window TENSOR is used as given (Hann, Hamming, an arbitrary taper), checked against torch.stft on CPU."""
+    from parallelwavegan_amd.losses.stft_loss import stft
+
+    x = 0.5 * synth.synth_input("stft_x", (2, 3000), seed=4)
+    for win in (torch.hann_window(240), torch.hamming_window(240), torch.linspace(0.1, 1.0, 240) ** 2):
+        s = torch.stft(x, 512, 60, 240, win, return_complex=True)
+        ref = torch.sqrt(torch.clamp(s.real ** 2 + s.imag ** 2, min=1e-7)).transpose(2, 1)
+        got = stft(x.to(device), 512, 60, 240, win.to(device))
+        assert got.shape == ref.shape
+        assert max_abs(got, ref) <= 2e-5 * float(ref.max())

@@ -1,0 +1,73 @@
+"""GPU: training-mode dropout of the WaveNet residual block (reference layers/residual_block.py:114-116;
+its own unit tests run p=0.05, test/test_parallel_wavegan.py:43).  The HIP mask is counter based, so the
+test rebuilds every layer's mask on the HOST from the documented hash (csrc/elementwise.hip: hash_u32 of
+seed * golden-ratio + index, keep when >= p * 2^32), checks it against the device mask bit for bit, and
+feeds it to the oracle: forward values and all parameter gradients must agree."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_cpu
+from parallelwavegan_amd import functional as Fn
+from parallelwavegan_amd import models
+from tests.golden import synth
+from tests.test_pwg_melgan_gpu import PWG_G
+from tests.util import max_abs
+
+pytestmark = pytest.mark.gpu
+M64 = (1 << 64) - 1
+
+
+def host_mask(n, p, seed):
+    """The keep / (1 - p) multipliers of pwg_dropout for elements 0..n-1 (numpy uint64 arithmetic)."""
+    with np.errstate(over="ignore"):
+        v = np.uint64((seed * 0x9E3779B97F4A7C15) & M64) + np.arange(n, dtype=np.uint64)
+        v ^= v >> np.uint64(33)
+        v *= np.uint64(0xFF51AFD7ED558CCD)
+        v ^= v >> np.uint64(33)
+        v *= np.uint64(0xC4CEB9FE1A85EC53)
+        v ^= v >> np.uint64(33)
+    pf = np.float32(p)  # the C ABI takes p as float
+    keep = (v & np.uint64(0xFFFFFFFF)) >= np.uint64(int(float(pf) * 4294967296.0))
+    return keep.astype(np.float32) * (np.float32(1.0) / (np.float32(1.0) - pf))
+
+
+def test_pwg_generator_with_dropout_matches_oracle_with_host_masks(device):
+    p = 0.05
+    cfg = dict(PWG_G, layers=6, stacks=2, dropout=p)
+    g = models.ParallelWaveGANGenerator(**cfg)
+    sd = synth.synth_state_dict(g.state_dict(), seed=7, g_scale=synth.PWG_G_SCALE)
+    g.load_state_dict(sd)
+    g = g.to(device).train()
+    frames = 12
+    c = synth.synth_input("c", (2, 80, frames + 4), seed=7)
+    z = synth.synth_input("z", (2, 1, frames * 256), seed=7)
+    y = g(z.to(device), c.to(device))
+    y.square().mean().backward()
+    # rebuild each layer's mask from the seeds the layer used
+    masks = []
+    n = 2 * 64 * frames * 256
+    for blk in g.conv_layers:
+        seed, counter = blk._drop.last_seeds
+        total = (seed + int(counter.item())) & M64
+        m = torch.from_numpy(host_mask(n, p, total)).reshape(2, 64, frames * 256)
+        dev_mask = Fn.DropoutFn.apply(torch.ones(2, 64, frames * 256, device=device), p, seed, counter)
+        assert torch.equal(dev_mask.cpu(), m)
+        assert 0.02 < float((m == 0).float().mean()) < 0.09
+        masks.append(m)
+    assert not torch.equal(masks[0], masks[1])  # independent masks per layer
+    sdg = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    ref = torch_cpu.pwg_generator(sdg, z, c, **dict(cfg, dropout_masks=masks))
+    assert max_abs(y, ref) <= 2e-5
+    ref.square().mean().backward()
+    for name, prm in g.named_parameters():
+        gr = sdg[name].grad
+        scale = float(gr.abs().max()) + 1e-12
+        assert max_abs(prm.grad, gr) <= 3e-4 * scale, name
+    # a second call draws new masks; eval mode is the identity
+    y2 = g(z.to(device), c.to(device))
+    assert not torch.equal(y2, y)
+    g.eval()
+    with torch.no_grad():
+        y_eval = g(z.to(device), c.to(device))
+        assert max_abs(y_eval, torch_cpu.pwg_generator(sd, z, c, **cfg)) <= 2e-5

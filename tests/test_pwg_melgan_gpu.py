@@ -161,3 +161,18 @@ def test_melgan_training_gradients_match_oracle(device):
     a = pqmf.analysis(xd)
     a_ref = torch_cpu.pqmf_analysis(x)
     _grads_match((a ** 2).sum(), [xd], (a_ref ** 2).sum(), [x])
+
+
+def test_pwg_with_melgan_upsampler_matches_reference_golden(device):
+    """ParallelWaveGANGenerator(upsample_net="MelGANGenerator") (models/parallel_wavegan.py:90-98)."""
+    import copy
+
+    gold = load_golden("pwg_melgan_upsampler")
+    seed = int(gold["meta"][0])
+    g = models.ParallelWaveGANGenerator(**copy.deepcopy(synth.PWG_MELGAN_UPSAMPLER))
+    g.load_state_dict(synth.synth_state_dict(g.state_dict(), seed=seed, g_scale=synth.PWG_G_SCALE))
+    g = g.to(device).eval()
+    c = synth.synth_input("c", (2, 80, 9), seed=seed)
+    z = synth.synth_input("z", (2, 1, 9 * 256), seed=seed)
+    with torch.no_grad():
+        assert max_abs(g(z.to(device), c.to(device)), gold["y"]) <= WAVE_TOL

@@ -67,7 +67,34 @@ def _worker(rank, world, port, out):
     red.defer = False
     red.exchange_all()
     err_deferred = max((red.flat_grads[p] * scale - g0).abs().max().item() for p, g0 in zip(params, grads))
-    out[rank] = (err, none_left, zero_ok, len(red.buckets), local_only, err_deferred)
+    red.remove()
+    # exchange groups (hipGraph mode: one backward segment per group, group k's all-reduce overlaps group
+    # k+1's backward).  The two ranks deliberately run the step DIFFERENTLY -- rank 0 eagerly with hooks,
+    # rank 1 group by group in deferred mode with restricted backward calls -- and must still issue the
+    # same collective sequence (bucket order) and end with the same averaged gradients.
+    from parallelwavegan_amd.distributed import partition_modules
+
+    groups = partition_modules([model[2], model[0]], 2)
+    assert [len(g) for g in groups] == [2, 2] and groups[0][0] is model[2].bias
+    red2 = GradReducer(params, bucket_bytes=100, groups=groups)
+    assert [b.group for b in red2.buckets] == sorted(b.group for b in red2.buckets)
+    loss = torch.nn.functional.mse_loss(model(x_all[rank]), y_all[rank])
+    if rank == 0:
+        red2.prepare()
+        loss.backward()
+        red2.finish()
+    else:
+        red2.defer = True
+        red2.prepare()
+        for gi, gp in enumerate(red2.groups):
+            torch.autograd.backward(loss, inputs=gp, retain_graph=gi < len(red2.groups) - 1)
+        red2.finish()  # capture-pass semantics: nothing exchanged yet
+        red2.begin_replay()
+        for gi in range(len(red2.groups)):
+            red2.exchange_group(gi)
+        red2.wait_all()
+    err_groups = max((red2.flat_grads[p] * scale - g0).abs().max().item() for p, g0 in zip(params, grads))
+    out[rank] = (err, none_left, zero_ok, len(red.buckets), local_only, err_deferred, err_groups)
     dist.destroy_process_group()
 
 
@@ -83,7 +110,8 @@ def test_grad_reducer_world_size_2():
         p.join(120)
         assert p.exitcode == 0
     for r in range(2):
-        err, none_left, zero_ok, nb, local_only, err_deferred = out[r]
+        err, none_left, zero_ok, nb, local_only, err_deferred, err_groups = out[r]
+        assert err_groups <= 1e-6, err_groups
         assert err <= 1e-6, err
         assert none_left and zero_ok and nb >= 2
         assert local_only > 1e-4        # before exchange_all the buckets hold this rank's gradients only
