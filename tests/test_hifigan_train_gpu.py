@@ -166,7 +166,13 @@ def test_hip_graph_two_batch_shapes_without_host_syncs(device):
     la, lb = finals[False][0], finals[True][0]
     for k in la:
         assert abs(la[k] - lb[k]) <= 2e-4 * max(abs(la[k]), 1e-3), (k, la[k], lb[k])
+    _, _, model0, _ = build_trainer(device, 43, 1.25, 2, 1)  # the (deterministic) initial parameters
     for k in ("generator", "discriminator"):
-        for a, b in zip(finals[False][1][k], finals[True][1][k]):
-            # 12 Adam steps at lr 2e-4: a replay that used stale gradients or scalars moves parameters by >> 1e-5
-            assert (a - b).abs().max().item() <= 2e-5 + 1e-4 * a.abs().max().item()
+        moved = diff = 0.0
+        for a, b, p0 in zip(finals[False][1][k], finals[True][1][k], model0[k].parameters()):
+            moved += (a - p0.detach().double().cpu()).abs().sum().item()
+            diff += (a - b).abs().sum().item()
+        # 12 Adam steps at lr 2e-4 move a parameter by up to 2.4e-3.  Eager and replayed runs differ only by the
+        # sign noise of near-zero gradient entries (measured: ~1 % of the movement); a replay that read stale
+        # gradients, another graph's gradients or another step's bias corrections differs by O(100 %).
+        assert diff <= 0.05 * moved, (k, diff, moved)

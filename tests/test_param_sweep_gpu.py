@@ -109,5 +109,4 @@ def test_unsupported_options_fail_loudly():
     # (use_causal_conv=True is supported since the causal layers landed: tests/test_causal_gpu.py)
     with pytest.raises(NotImplementedError):
         models.HiFiGANGenerator(nonlinear_activation="GELU", nonlinear_activation_params={})
-    with pytest.raises(NotImplementedError):
-        models.ParallelWaveGANGenerator(upsample_net="MelGANGenerator")
+    # (upsample_net="MelGANGenerator" is supported: tests/test_pwg_melgan_gpu.py)

@@ -90,8 +90,12 @@ def test_pwg_v1_two_train_steps(device):
 # Calibration: two CPU runs of the REFERENCE Trainer on this configuration (3 vs 8 threads) differ by
 # 2.0 % in the step-1 fake loss and 9e-4 in the step-1 discriminator loss (Adam with lr 1e-3 turns
 # rounding noise of near-zero gradients into +-lr parameter steps; the fake loss is a small
-# difference-sensitive quantity); every other logged value agrees to < 1e-5.
-MB_LOOSE = {(1, "train/fake_loss"): 0.25, (1, "train/discriminator_loss"): 1e-2}
+# difference-sensitive quantity); every other logged value agrees to < 1e-5.  The bars for these two
+# values are 3x the reference's own run-to-run spread (measured HIP deviation: 3.1e-2 and 1.4e-3; every
+# other step-1 value <= 8e-5).  What pins the discriminator UPDATE itself, free of that sign noise, is
+# the per-tensor <p1 - p0, exp_avg> check in _run_and_compare (bar 5e-3) together with the per-tensor
+# first-moment norms (3e-3): entries whose gradient is rounding noise carry no weight in either.
+MB_LOOSE = {(1, "train/fake_loss"): 6e-2, (1, "train/discriminator_loss"): 3e-3}
 
 
 def test_mb_melgan_v2_two_train_steps(device):
