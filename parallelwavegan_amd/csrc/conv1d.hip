@@ -24,6 +24,7 @@
 //       half-wave -> coalesced 128-B stores; bias/residual/scale/tanh fused.
 #include "common.h"
 
+#include <stdint.h>
 #include <stdlib.h>
 
 namespace pwg {
@@ -69,6 +70,7 @@ struct ConvArgs {
   int ksplit;
   float* partial;
   long slab_elems;
+  int epi_vec;  // 1: y / add1 / add2 / mask are 16-B aligned with y_cstride % 4 == 0 -> LDS-transposed 16-B epilogue
 };
 
 template <int WM, int WN, int WAVES_M, int WAVES_N, int CK>
@@ -255,7 +257,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // (second launch bound: at least 2 waves per SIMD unless the wave owns 8 accumulator tiles -- hipcc's
 // allocation for the 2x2-tile waves otherwise flips between 174 and 256 VGPRs on unrelated edits)
 template <int WM, int WN, int WAVES_M, int WAVES_N, int CK, bool FAST, int ACT>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WM * WN >= 8 ? 1 : 2)) void conv1d_mfma_dma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WM * WN >= 8 ? 1 : (WM * WN == 1 ? 4 : 2))) void conv1d_mfma_dma_kernel(ConvArgs a) {
   constexpr int BM = 32 * WM * WAVES_M;
   constexpr int BN = 32 * WN * WAVES_N;
   constexpr int NWAVES = WAVES_M * WAVES_N;
@@ -447,6 +449,76 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WM * WN >= 8 ? 1 : 2)) voi
   const float* __restrict__ add2_p = a.add2;
   const float* __restrict__ mask_p = a.mask_src;
   float* __restrict__ y_p = a.y;
+  // ---- 16-B epilogue (plain Conv1d, wave tile fully inside the output).  The MFMA D layout gives a lane
+  // ONE time sample of 16 rows, i.e. 16 dword stores (+16 dword loads per fused addend) per 32x32 tile:
+  // the epilogue was issue-bound (ablation: 12.5 % of the generator forward).  Each wave transposes its
+  // tile through a private 32 x 36 float LDS scratch (16 ds_write_b32 + 4 ds_read_b128) so that a lane owns
+  // 4 consecutive time samples of a row: 4 dwordx4 stores / loads per tile, all loads of a tile issued
+  // before its arithmetic.  Element-wise arithmetic and its order are those of the scalar path below.
+  {
+    const int m_w0 = m0 + wave_m * (WM * 32);
+    const int n_w0 = n0 + wave_n * (WN * 32);
+    const bool vec_ok = a.epi_vec && single_phase && W == 1 && a.out_off == 0 && a.out_stride == 1 && m_w0 + WM * 32 <= a.m_g && n_w0 + WN * 32 <= a.n_cols;
+    if (__builtin_amdgcn_readfirstlane(vec_ok ? 1 : 0)) {
+      float* scratch = smem + 2 * buf_floats + wave * (32 * 36);
+      const int trow = lane >> 3;        // + 8 * pass
+      const int tcol = (lane & 7) * 4;
+      const long tile_base = ybase + (long)(g * a.cout_g + m_w0) * a.y_cstride + n_w0;  // wave-uniform
+      // the residual (add1) loads of ALL the wave's tiles are issued first (one exposure of the memory latency
+      // instead of one per tile); add2 (last convolution of an MRF block) and the dgrad mask per tile
+      float4 a1v[WM][WN][4];
+#pragma unroll
+      for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+          for (int ps = 0; ps < 4; ++ps) {
+            const unsigned o = (unsigned)(mi * 32 + ps * 8 + trow) * (unsigned)a.y_cstride + (unsigned)(ni * 32 + tcol);
+            if (add1_p) a1v[mi][ni][ps] = *reinterpret_cast<const float4*>(add1_p + tile_base + o);
+          }
+#pragma unroll
+      for (int mi = 0; mi < WM; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            scratch[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 36 + l31] = acc[mi][ni][r];
+          float4 v[4], a2v[4], mkv[4];
+          float bs[4];
+          unsigned off[4];
+#pragma unroll
+          for (int ps = 0; ps < 4; ++ps) {
+            const int row = mi * 32 + ps * 8 + trow;
+            off[ps] = (unsigned)row * (unsigned)a.y_cstride + (unsigned)(ni * 32 + tcol);
+            bs[ps] = bias_p ? bias_p[g * a.cout_g + m_w0 + row] : 0.f;
+            if (add2_p) a2v[ps] = *reinterpret_cast<const float4*>(add2_p + tile_base + off[ps]);
+            if (mask_p) mkv[ps] = *reinterpret_cast<const float4*>(mask_p + tile_base + off[ps]);
+          }
+#pragma unroll
+          for (int ps = 0; ps < 4; ++ps) v[ps] = *reinterpret_cast<const float4*>(scratch + (ps * 8 + trow) * 36 + tcol);
+#pragma unroll
+          for (int ps = 0; ps < 4; ++ps) {
+            float o[4] = {v[ps].x, v[ps].y, v[ps].z, v[ps].w};
+            const float m4[4] = {mkv[ps].x, mkv[ps].y, mkv[ps].z, mkv[ps].w};
+            const float p4[4] = {a1v[mi][ni][ps].x, a1v[mi][ni][ps].y, a1v[mi][ni][ps].z, a1v[mi][ni][ps].w};
+            const float q4[4] = {a2v[ps].x, a2v[ps].y, a2v[ps].z, a2v[ps].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float t = o[e] + bs[ps];
+              if (mask_p) t *= (m4[e] > 0.f ? 1.f : a.mask_slope);
+              if (add1_p) t += p4[e];
+              if (add2_p) t += q4[e];
+              if (a.out_mul != 1.0f) t *= a.out_mul;
+              if (a.out_div != 1.0f) t = t / a.out_div;
+              o[e] = apply_act(t, a.post_act, a.post_slope);
+            }
+            *reinterpret_cast<float4*>(y_p + tile_base + off[ps]) = make_float4(o[0], o[1], o[2], o[3]);
+          }
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int ni = 0; ni < WN; ++ni) {
     const int n = n0 + (wave_n * WN + ni) * 32 + l31;
@@ -455,36 +527,42 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WM * WN >= 8 ? 1 : 2)) voi
     const int wcol = n - q * W;
 #pragma unroll
     for (int mi = 0; mi < WM; ++mi) {
-      long off[16];
-      bool ok[16];
-      float bsv[16], a1[16], a2[16], mk[16];
+      // (RB outputs at a time: 8 for the single-tile waves that run at 4 waves per SIMD / 128 VGPRs)
+      constexpr int RB = WM * WN == 1 ? 8 : 16;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wave_m * WM + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        int phase = 0, co = m;
-        if (!single_phase) {
-          phase = m / a.cout_g;
-          co = m - phase * a.cout_g;
+      for (int r0 = 0; r0 < 16; r0 += RB) {
+        long off[RB];
+        bool ok[RB];
+        float bsv[RB], a1[RB], a2[RB], mk[RB];
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+          const int r = r0 + j;
+          const int m = m0 + (wave_m * WM + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          int phase = 0, co = m;
+          if (!single_phase) {
+            phase = m / a.cout_g;
+            co = m - phase * a.cout_g;
+          }
+          const int u = q * a.out_stride + phase - a.out_off;
+          const int cglob = g * a.cout_g + co;
+          ok[j] = n_ok && m < a.m_g && u >= 0 && u < a.t_out;
+          off[j] = ybase + (long)cglob * a.y_cstride + (long)u * W + wcol;
+          bsv[j] = (bias_p && ok[j]) ? bias_p[cglob] : 0.f;
+          a1[j] = (add1_p && ok[j]) ? add1_p[off[j]] : 0.f;
+          a2[j] = (add2_p && ok[j]) ? add2_p[off[j]] : 0.f;
+          mk[j] = (mask_p && ok[j]) ? mask_p[off[j]] : 1.f;
         }
-        const int u = q * a.out_stride + phase - a.out_off;
-        const int cglob = g * a.cout_g + co;
-        ok[r] = n_ok && m < a.m_g && u >= 0 && u < a.t_out;
-        off[r] = ybase + (long)cglob * a.y_cstride + (long)u * W + wcol;
-        bsv[r] = (bias_p && ok[r]) ? bias_p[cglob] : 0.f;
-        a1[r] = (add1_p && ok[r]) ? add1_p[off[r]] : 0.f;
-        a2[r] = (add2_p && ok[r]) ? add2_p[off[r]] : 0.f;
-        mk[r] = (mask_p && ok[r]) ? mask_p[off[r]] : 1.f;
-      }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = acc[mi][ni][r] + bsv[r];
-        if (mask_p) v *= (mk[r] > 0.f ? 1.f : a.mask_slope);
-        v += a1[r];
-        v += a2[r];
-        if (a.out_mul != 1.0f) v *= a.out_mul;
-        if (a.out_div != 1.0f) v = v / a.out_div;
-        v = apply_act(v, a.post_act, a.post_slope);
-        if (ok[r]) y_p[off[r]] = v;
+        for (int j = 0; j < RB; ++j) {
+          float v = acc[mi][ni][r0 + j] + bsv[j];
+          if (mask_p) v *= (mk[j] > 0.f ? 1.f : a.mask_slope);
+          v += a1[j];
+          v += a2[j];
+          if (a.out_mul != 1.0f) v *= a.out_mul;
+          if (a.out_div != 1.0f) v = v / a.out_div;
+          v = apply_act(v, a.post_act, a.post_slope);
+          if (ok[j]) y_p[off[j]] = v;
+        }
       }
     }
   }
@@ -647,6 +725,15 @@ static int make_geometry(const pwg_conv1d_desc* d, Geometry* g) {
     g->n_cols = q_rows * d->width;
     g->out_stride = d->stride;
     g->out_off = d->pad_left;
+    if (d->stride == 1 && g->pad >= d->pad_left) {
+      // stride 1 (the data gradient of every stride-1 convolution): substitute q = u + pad_left, i.e. the
+      // transposed convolution IS a plain one with padding (k-1)*dil - pad_left over the flipped taps (which
+      // is how the backward image is packed).  Columns are then the output samples themselves: no
+      // `pad_left` wasted leading columns, tile columns aligned with y (16-B epilogue, FAST row stride).
+      g->pad -= d->pad_left;
+      g->n_cols = d->t_out * d->width;
+      g->out_off = 0;
+    }
   }
   g->m_g = g->phases * g->cout_g;
   g->m_pad = round_up(g->m_g, 128);
@@ -694,7 +781,13 @@ static int launch_conv(const ConvArgs& a0, const Geometry& g, int batch, int gro
   const int act = a.pre_act == PWG_ACT_NONE ? 0
                   : (a.pre_act == PWG_ACT_LEAKY_RELU && a.pre_slope > 0.f && a.pre_slope < 1.f) ? 1 : 2;
   const size_t buf = ((size_t)CK * a.xs_stride + (size_t)g.k_phase * CK * BM) * sizeof(float);
-  const size_t lds = DMA ? 2 * buf : buf;
+  // DMA kernel: two chunk buffers + one 32 x 36 float transposition scratch per wave (16-B epilogue)
+  const size_t lds = DMA ? 2 * buf + (size_t)WAVES_M * WAVES_N * 32 * 36 * sizeof(float) : buf;
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  a.epi_vec = DMA && a.width == 1 && (a.y_cstride % 4) == 0 && al16(a.y) && al16(a.add1) && al16(a.add2) &&
+              al16(a.mask_src) && (((size_t)a.y_bstride) % 4) == 0;
+  static const bool no_vec = getenv("PWG_NO_VEC_EPILOGUE") != nullptr;
+  if (no_vec) a.epi_vec = 0;
   PWG_REQUIRE(lds <= 160 * 1024, PWG_ERR_UNSUPPORTED,
               "conv1d: tile needs %zu B of LDS (k=%d stride=%d dil=%d)", lds, g.k_phase, g.stride, g.dil);
   void (*kern)(ConvArgs);
@@ -752,7 +845,8 @@ static int launch_conv(const ConvArgs& a0, const Geometry& g, int batch, int gro
   return PWG_OK;
 }
 
-// Tile configurations (id -> instantiation).  ids are stable: tools/bench_conv.py sweeps them.
+// Tile configurations (id -> instantiation); tools/bench_conv.py sweeps them.  (The 2x4-accumulator
+// tiles of round 1 needed scratch and never won a sweep: removed.)
 struct TileCfg {
   int bm, bn, ck;
   int wm, wn;  // 32x32 accumulator tiles per wave
@@ -761,25 +855,21 @@ struct TileCfg {
   X(0, 2, 2, 2, 2, 8)     \
   X(1, 2, 2, 2, 2, 16)    \
   X(2, 2, 2, 2, 2, 4)     \
-  X(3, 2, 4, 2, 2, 8)     \
-  X(4, 2, 4, 2, 2, 4)     \
-  X(5, 2, 2, 1, 4, 8)     \
-  X(6, 2, 2, 1, 4, 16)    \
-  X(7, 2, 4, 1, 4, 8)     \
-  X(8, 1, 2, 1, 4, 8)     \
-  X(9, 1, 2, 1, 4, 16)    \
-  X(10, 1, 4, 1, 4, 8)    \
-  X(11, 1, 4, 1, 4, 16)   \
-  X(12, 2, 1, 2, 2, 8)    \
-  X(13, 1, 1, 1, 4, 8)    \
-  X(14, 2, 4, 1, 4, 4)    \
-  X(15, 2, 2, 1, 4, 4)    \
-  X(16, 1, 2, 2, 2, 8)    \
-  X(17, 1, 1, 2, 2, 8)    \
-  X(18, 1, 1, 4, 1, 8)    \
-  X(19, 1, 1, 2, 2, 16)   \
-  X(20, 1, 1, 1, 4, 16)
-static const int kNumCfgs = 21;
+  X(3, 2, 2, 1, 4, 8)     \
+  X(4, 2, 2, 1, 4, 16)    \
+  X(5, 1, 2, 1, 4, 8)     \
+  X(6, 1, 2, 1, 4, 16)    \
+  X(7, 1, 4, 1, 4, 8)     \
+  X(8, 1, 4, 1, 4, 16)    \
+  X(9, 2, 1, 2, 2, 8)     \
+  X(10, 1, 1, 1, 4, 8)    \
+  X(11, 2, 2, 1, 4, 4)    \
+  X(12, 1, 2, 2, 2, 8)    \
+  X(13, 1, 1, 2, 2, 8)    \
+  X(14, 1, 1, 4, 1, 8)    \
+  X(15, 1, 1, 2, 2, 16)   \
+  X(16, 1, 1, 1, 4, 16)
+static const int kNumCfgs = 17;
 
 static TileCfg cfg_info(int id) {
   switch (id) {
@@ -799,7 +889,7 @@ static size_t cfg_lds(int id, const Geometry& g, int W, bool dma) {
   int xs = dma ? round_up(xs_len, 64) : round_up(xs_len, 4);
   if (dma && g.stride == 1 && W == 1 && (g.k_phase - 1) * g.dil <= 64) xs = c.bn + 64;  // FAST row stride (upper bound)
   const size_t buf = ((size_t)c.ck * xs + (size_t)g.k_phase * c.ck * c.bm) * sizeof(float);
-  return dma ? 2 * buf : buf;
+  return dma ? 2 * buf + (size_t)4 * 32 * 36 * sizeof(float) : buf;
 }
 
 static int launch_cfg(int id, bool dma, const ConvArgs& a, const Geometry& g, int batch, int groups,
@@ -836,12 +926,14 @@ struct Cand {
 static int choose_cfg(const Geometry& g, int W, int batch, int groups, bool dma, int* ksplit = nullptr) {
   const int m = g.m_g;
   const int k = g.k_phase;
-  static const Cand big_few[] = {{12, 0.95f}, {0, 0.85f}, {16, 0.85f}, {17, 0.75f}, {18, 0.6f}, {2, 0.8f},
-                                 {19, 0.8f}, {20, 0.82f}};
-  static const Cand big_many[] = {{2, 1.0f}, {12, 0.9f}, {16, 0.85f}, {17, 0.75f}, {18, 0.6f}, {19, 0.8f}, {20, 0.82f}};
-  static const Cand mid_few[] = {{13, 1.0f}, {15, 0.8f}, {17, 0.8f}};
-  static const Cand mid_many[] = {{15, 1.0f}, {13, 0.9f}, {17, 0.8f}};
-  static const Cand small_any[] = {{13, 1.0f}};
+  // ids: 9 = 128x64x8, 0 = 128x128x8, 12 = 64x128x8, 13 = 64x64x8, 14 = 128x32x8, 2 = 128x128x4, 15 = 64x64x16,
+  // 16 = 32x128x16, 10 = 32x128x8, 11 = 64x256x4
+  static const Cand big_few[] = {{9, 0.95f}, {0, 0.85f}, {12, 0.85f}, {13, 0.75f}, {14, 0.6f}, {2, 0.8f},
+                                 {15, 0.8f}, {16, 0.82f}};
+  static const Cand big_many[] = {{2, 1.0f}, {9, 0.9f}, {12, 0.85f}, {13, 0.75f}, {14, 0.6f}, {15, 0.8f}, {16, 0.82f}};
+  static const Cand mid_few[] = {{10, 1.0f}, {11, 0.8f}, {13, 0.8f}};
+  static const Cand mid_many[] = {{11, 1.0f}, {10, 0.9f}, {13, 0.8f}};
+  static const Cand small_any[] = {{10, 1.0f}};
   const Cand* cand;
   int ncand;
   if (m > 64) {
@@ -887,7 +979,7 @@ static int choose_cfg(const Geometry& g, int W, int batch, int groups, bool dma,
     }
   }
   if (best < 0) {
-    best = 13;
+    best = 10;
     best_split = 1;
   }
   if (ksplit) *ksplit = best_split;
@@ -938,6 +1030,7 @@ static int fill_args(const pwg_conv1d_desc* d, const Geometry& g, const float* x
   static const int dbg = getenv("PWG_DBG") ? atoi(getenv("PWG_DBG")) : 0;
   a.dbg = dbg;
   a.ksplit = 1;
+  a.epi_vec = 0;
   a.partial = nullptr;
   a.slab_elems = (long)d->batch * d->c_out * d->t_out * d->width;
   *out = a;

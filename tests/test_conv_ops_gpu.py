@@ -219,7 +219,7 @@ def test_split_reduction_forward_backward(B, Cin, Cout, T, K, stride, pad, group
     y = ops.conv1d_forward(desc, xd, ops.pack_weight(desc, wd), bd, r1d)
     _close(y, y_ref, "split forward")
     # unsplit path on the same data (explicit tile configuration never splits)
-    y_plain = ops.conv1d_forward_cfg(desc, xd, ops.pack_weight(desc, wd), bd, r1d, tile_config=17, use_dma=True)
+    y_plain = ops.conv1d_forward_cfg(desc, xd, ops.pack_weight(desc, wd), bd, r1d, tile_config=13, use_dma=True)
     _close(y, y_plain.cpu(), "split vs unsplit")
     # data gradient of conv(leaky_relu(x)) with accumulation
     pre = F.conv1d(F.leaky_relu(x, 0.1), w, None, padding=pad, groups=groups)
