@@ -390,7 +390,16 @@ def main():
         # "nccl" is RCCL on ROCm.  RCCL refuses two ranks on one device, so when there are fewer GPUs
         # than ranks (single-GPU smoke run of the multi-rank path) the collectives go through gloo.
         backend = os.environ.get("PWG_DIST_BACKEND", "nccl" if n_dev >= world else "gloo")
-        dist.init_process_group(backend)
+        # (gloo's C++ side prints its connection banner to stdout: keep stdout for the one JSON line)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     dev = torch.device("cuda", local_rank % n_dev)
     torch.cuda.set_device(dev)
 
