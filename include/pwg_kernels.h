@@ -320,6 +320,45 @@ int pwg_log_clamp_forward(const float* x, float* y, int64_t n, float eps, float 
 int pwg_log_clamp_backward(const float* x, const float* dy, float* dx, int64_t n, float eps, float log_div,
                            void* stream);
 
+/* Fused single-resolution STFT loss of a (predicted, target) pair -- one launch instead of the
+ * frame/conv/mag/log/reduce chain above, and no spectrum-shaped tensor in HBM:
+ *   sums[0] = sum (|Y| - |X|)^2   sums[1] = sum |Y|^2   sums[2] = sum |log|Y| - log|X||
+ * over the (B, bins, frames) magnitudes |.| = sqrt(max(re^2 + im^2, eps)), from which the caller forms
+ * SpectralConvergenceLoss = sqrt(sums[0]) / sqrt(sums[1]) (losses/stft_loss.py:61) and
+ * LogSTFTMagnitudeLoss = sums[2] / (B * bins * frames) (:82); torch.stft + clamp + sqrt are :16-40.
+ *   fx, fy : the two signals folded by pwg_frame_fold_forward, (B, hop, n_cols), n_cols >= frames + taps - 1
+ *   basis  : windowed DFT image [tap][hop][m_pad], m_pad = 64 * ceil(bins / 32); each 64-row group holds
+ *            32 cosine rows then the 32 matching -sine rows (rows of bins >= `bins` are zero)
+ *   workspace: pwg_stft_loss_workspace_floats() floats.  Deterministic (fixed tiles, fixed sum order).
+ * Backward: given g3 = d loss / d sums (3 DEVICE floats) writes dspec (B, 2*bins, frames) = [d re | d im]
+ * of the PREDICTED signal's spectrum (the target is a constant), i.e. the dy operand of
+ * pwg_conv1d_backward_data on the DFT convolution; pwg_frame_fold_backward finishes the chain.        */
+size_t pwg_stft_loss_workspace_floats(int32_t batch, int32_t bins, int32_t frames);
+int pwg_stft_loss_forward(const float* fx, const float* fy, const float* basis, int32_t batch, int32_t hop,
+                          int32_t n_cols, int32_t taps, int32_t bins, int32_t frames, float eps,
+                          float* workspace, float* sums, void* stream);
+int pwg_stft_loss_backward(const float* fx, const float* fy, const float* basis, int32_t batch, int32_t hop,
+                           int32_t n_cols, int32_t taps, int32_t bins, int32_t frames, float eps,
+                           const float* g3, float* dspec, void* stream);
+
+/* Fused mel-spectrogram loss of a (predicted, target) pair (losses/mel_loss.py:95-110,150-165):
+ *   sum[0] = sum_{b,j,f} | log(max(mel_x, eps)) - log(max(mel_y, eps)) | / log_div,
+ *   mel = filterbank (n_mels x bins) applied to |STFT| = sqrt(max(re^2 + im^2, eps)); F.l1_loss is sum[0] / (B * n_mels * frames).
+ * Same tiling and operands as pwg_stft_loss_*; the filterbank contraction runs on MFMA from the magnitude
+ * registers.  mel_t: filterbank [32 * ceil(bins / 32)][mels_pad] (mel fastest, mels_pad = 32 * ceil(n_mels / 32),
+ * zero padded); mel_b: the same matrix as [mels_pad][32 * ceil(bins / 32)] (bin fastest).  mel_x / mel_y
+ * (B, n_mels, frames) receive the un-clamped mels (kept for the backward pass).  workspace:
+ * pwg_mel_loss_workspace_floats() floats.  Backward writes dspec = [d re | d im] of the predicted signal.   */
+size_t pwg_mel_loss_workspace_floats(int32_t batch, int32_t bins, int32_t frames, int32_t n_mels);
+int pwg_mel_loss_forward(const float* fx, const float* fy, const float* basis, const float* mel_t, int32_t batch,
+                         int32_t hop, int32_t n_cols, int32_t taps, int32_t bins, int32_t frames, int32_t n_mels,
+                         float eps, float log_div, float* workspace, float* mel_x, float* mel_y, float* sum,
+                         void* stream);
+int pwg_mel_loss_backward(const float* fx, const float* basis, const float* mel_b, const float* mel_x,
+                          const float* mel_y, int32_t batch, int32_t hop, int32_t n_cols, int32_t taps,
+                          int32_t bins, int32_t frames, int32_t n_mels, float eps, float log_div,
+                          const float* gout, float* dspec, void* stream);
+
 /* ------------------------------------------------------------------------- */
 /* Loss reductions (deterministic two-stage sums)                              */
 /*   out[0] = scale * sum_i term_i ;  mode 0 |a-b| (F.l1_loss: feat_match_loss.py:44, */

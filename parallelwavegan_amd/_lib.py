@@ -120,6 +120,14 @@ SIGNATURES = {
     "pwg_frame_fold_backward": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pwg_stft_mag_forward": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "pwg_stft_mag_backward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
+    "pwg_stft_loss_workspace_floats": (ctypes.c_size_t, [_i32, _i32, _i32]),
+    "pwg_stft_loss_forward": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
+    "pwg_stft_loss_backward": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
+    "pwg_mel_loss_workspace_floats": (ctypes.c_size_t, [_i32, _i32, _i32, _i32]),
+    "pwg_mel_loss_forward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp,
+                                            _vp, _vp, _vp, _vp]),
+    "pwg_mel_loss_backward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32,
+                                             _vp, _vp, _vp]),
     "pwg_log_clamp_forward": (ctypes.c_int, [_vp, _vp, _i64, _f32, _f32, _vp]),
     "pwg_log_clamp_backward": (ctypes.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _vp]),
     "pwg_reduce_forward": (ctypes.c_int, [_vp, _vp, _f32, _i64, _i32, _f32, _vp, _vp, _vp]),

@@ -1,6 +1,7 @@
 """Mel-spectrogram loss (drop-in for parallel_wavegan.losses.mel_loss)."""
 import math
 
+import numpy as np
 import torch
 
 from .. import functional as Fn
@@ -39,6 +40,14 @@ class MelSpectrogram(torch.nn.Module):
         else:
             raise ValueError(f"log_base: {log_base} is not supported.")
         self.stft_magnitude = STFTMagnitude(fft_size, hop_size, self.win_length, window, eps=eps)
+        # filterbank images of the fused pair-loss kernel (csrc/stft_loss.hip): zero padded to whole 32 x 32 tiles
+        bins = melmat.shape[1]
+        bins_pad, mels_pad = 32 * ((bins + 31) // 32), 32 * ((num_mels + 31) // 32)
+        mel_t = np.zeros((bins_pad, mels_pad), dtype=np.float32)
+        mel_t[:bins, :num_mels] = melmat.T
+        self.register_buffer("mel_t", torch.from_numpy(mel_t), persistent=False)               # [bin][mel]
+        self.register_buffer("mel_b", torch.from_numpy(mel_t.T.copy()), persistent=False)      # [mel][bin]
+        self.num_mels = num_mels
         self._geom = dict(kernel=1, stride=1, dilation=1, padding=0, groups=1, transposed=False, output_padding=0,
                           width=1, pad_mode="zero")
         self._fused = dict(pre_act=None, pre_slope=0.0, post_act=None, post_slope=0.0, out_mul=1.0, out_div=1.0)
@@ -62,5 +71,79 @@ class MelSpectrogramLoss(torch.nn.Module):
                                               window=window, num_mels=num_mels, fmin=fmin, fmax=fmax, center=center,
                                               normalized=normalized, onesided=onesided, eps=eps, log_base=log_base)
 
+    fused = True  # one fused launch for both signals (csrc/stft_loss.hip); False: the op-by-op chain
+
     def forward(self, y_hat, y):
+        if self.fused and not (torch.is_grad_enabled() and y.requires_grad):
+            ms = self.mel_spectrogram
+            if y_hat.dim() == 3:
+                y_hat = y_hat.reshape(-1, y_hat.size(2))
+                y = y.reshape(-1, y.size(2))
+            total = MelPairLossFn.apply(y_hat, y.detach(), ms)
+            n = y_hat.shape[0] * ms.num_mels * ms.stft_magnitude.frames(y_hat.shape[1])
+            return total / n
         return Fn.l1_mean(self.mel_spectrogram(y_hat), self.mel_spectrogram(y))
+
+
+class MelPairLossFn(torch.autograd.Function):
+    """sum | log mel(x) - log mel(y) | with ``pwg_mel_loss_forward`` / ``_backward``: frames -> windowed DFT
+    (MFMA) -> magnitude -> mel filterbank (MFMA) -> clamp -> log -> L1 for both signals in one kernel; the
+    backward pass recomputes the spectrum tiles of x, applies the filterbank's transpose on MFMA and hands
+    d(re)/d(im) to the data-gradient convolution (transposed DFT) and the fold's adjoint."""
+
+    @staticmethod
+    def forward(ctx, x, y, ms):
+        from .. import _lib
+        from ..ops import _ptr, _require_device, _stream
+
+        mod = ms.stft_magnitude
+        x = x if x.is_contiguous() else x.contiguous()
+        y = y if y.is_contiguous() else y.contiguous()
+        _require_device(x, y)
+        b, t = x.shape
+        frames = mod.frames(t)
+        n_cols = frames + mod.taps - 1
+        pad = mod.fft_size // 2 - mod.frame_offset
+        fx = torch.empty(b, mod.hop_size, n_cols, device=x.device, dtype=torch.float32)
+        fy = torch.empty_like(fx)
+        L = _lib.lib()
+        for src, dst in ((x, fx), (y, fy)):
+            _lib.check(L.pwg_frame_fold_forward(_ptr(src), _ptr(dst), b, t, pad, mod.hop_size, n_cols, _stream()),
+                       "frame_fold_forward")
+        ws = torch.empty(L.pwg_mel_loss_workspace_floats(b, mod.bins, frames, ms.num_mels), device=x.device,
+                         dtype=torch.float32)
+        mel_x = torch.empty(b, ms.num_mels, frames, device=x.device, dtype=torch.float32)
+        mel_y = torch.empty_like(mel_x)
+        total = torch.empty(1, device=x.device, dtype=torch.float32)
+        _lib.check(L.pwg_mel_loss_forward(_ptr(fx), _ptr(fy), _ptr(mod.pair_basis), _ptr(ms.mel_t), b, mod.hop_size,
+                                          n_cols, mod.taps, mod.bins, frames, ms.num_mels, float(ms.eps),
+                                          float(ms.log_div), _ptr(ws), _ptr(mel_x), _ptr(mel_y), _ptr(total),
+                                          _stream()), "mel_loss_forward")
+        ctx.save_for_backward(fx, mel_x, mel_y)
+        ctx.ms, ctx.dims = ms, (b, t, frames, n_cols, pad)
+        return total.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        from .. import _lib, ops
+        from ..ops import _ptr, _stream
+
+        fx, mel_x, mel_y = ctx.saved_tensors
+        ms = ctx.ms
+        mod = ms.stft_magnitude
+        b, t, frames, n_cols, pad = ctx.dims
+        gout = gout.contiguous().reshape(1)
+        L = _lib.lib()
+        dspec = torch.empty(b, 2 * mod.bins, frames, device=fx.device, dtype=torch.float32)
+        _lib.check(L.pwg_mel_loss_backward(_ptr(fx), _ptr(mod.pair_basis), _ptr(ms.mel_b), _ptr(mel_x), _ptr(mel_y), b,
+                                           mod.hop_size, n_cols, mod.taps, mod.bins, frames, ms.num_mels,
+                                           float(ms.eps), float(ms.log_div), _ptr(gout), _ptr(dspec), _stream()),
+                   "mel_loss_backward")
+        desc = ops.make_conv_desc(b, mod.hop_size, 2 * mod.bins, n_cols, frames, mod.taps)
+        if getattr(mod, "_bwd_image", None) is None or mod._bwd_image.device != fx.device:
+            mod._bwd_image = ops.pack_weight_bwd(desc, mod.basis)
+        dfold = ops.conv1d_backward_data(desc, dspec, mod._bwd_image)
+        dx = torch.empty(b, t, device=fx.device, dtype=torch.float32)
+        _lib.check(L.pwg_frame_fold_backward(_ptr(dfold), _ptr(dx), b, t, pad, mod.hop_size, n_cols, _stream()),
+                   "frame_fold_backward")
+        return dx, None, None

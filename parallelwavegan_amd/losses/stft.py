@@ -58,6 +58,17 @@ class STFTMagnitude(torch.nn.Module):
         weight = basis.reshape(2 * self.bins, self.taps, hop_size).transpose(0, 2, 1)
         self.register_buffer("basis", torch.from_numpy(np.ascontiguousarray(weight, dtype=np.float32)),
                              persistent=False)
+        # image for the fused pair-loss kernel (csrc/stft_loss.hip): [tap][c][m_pad], 64-row groups of
+        # 32 cosine rows + the 32 matching -sine rows, zero rows past `bins`
+        ngroups = (self.bins + 31) // 32
+        pair = np.zeros((self.taps, hop_size, ngroups * 64), dtype=np.float32)
+        re = basis[: self.bins].reshape(self.bins, self.taps, hop_size)   # [bin][tap][c]
+        im = basis[self.bins:].reshape(self.bins, self.taps, hop_size)
+        for g in range(ngroups):
+            lo, hi = g * 32, min(self.bins, g * 32 + 32)
+            pair[:, :, g * 64: g * 64 + (hi - lo)] = re[lo:hi].transpose(1, 2, 0)
+            pair[:, :, g * 64 + 32: g * 64 + 32 + (hi - lo)] = im[lo:hi].transpose(1, 2, 0)
+        self.register_buffer("pair_basis", torch.from_numpy(pair), persistent=False)
         self._geom = dict(kernel=self.taps, stride=1, dilation=1, padding=0, groups=1, transposed=False,
                           output_padding=0, width=1, pad_mode="zero")
         self._fused = dict(pre_act=None, pre_slope=0.0, post_act=None, post_slope=0.0, out_mul=1.0, out_div=1.0)
@@ -76,3 +87,67 @@ class STFTMagnitude(torch.nn.Module):
 
     def forward(self, x):
         return Fn.StftMagFn.apply(self.spectrum(x), self.eps)
+
+    def pair_sums(self, x, y):
+        """Fused single-launch loss statistics of the pair: tensor [sum (|Y|-|X|)^2, sum |Y|^2,
+        sum |log|Y| - log|X||] over (B, bins, frames); differentiable w.r.t. ``x`` (``y`` is a constant)."""
+        return StftPairSumsFn.apply(x, y.detach(), self)
+
+
+class StftPairSumsFn(torch.autograd.Function):
+    """``pwg_stft_loss_forward`` / ``_backward`` (csrc/stft_loss.hip): no spectrum, magnitude or log tensor
+    in HBM in the forward pass; the backward pass recomputes the tile spectra, writes d(re)/d(im) once and
+    reuses the data-gradient convolution (transposed windowed DFT) and the fold's adjoint."""
+
+    @staticmethod
+    def forward(ctx, x, y, mod):
+        import ctypes
+
+        from .. import _lib, ops
+        from ..ops import _ptr, _require_device, _stream
+
+        x = x if x.is_contiguous() else x.contiguous()
+        y = y if y.is_contiguous() else y.contiguous()
+        _require_device(x, y)
+        b, t = x.shape
+        frames = mod.frames(t)
+        n_cols = frames + mod.taps - 1
+        pad = mod.fft_size // 2 - mod.frame_offset
+        fx = torch.empty(b, mod.hop_size, n_cols, device=x.device, dtype=torch.float32)
+        fy = torch.empty_like(fx)
+        L = _lib.lib()
+        for src, dst in ((x, fx), (y, fy)):
+            _lib.check(L.pwg_frame_fold_forward(_ptr(src), _ptr(dst), b, t, pad, mod.hop_size, n_cols, _stream()),
+                       "frame_fold_forward")
+        ws = torch.empty(L.pwg_stft_loss_workspace_floats(b, mod.bins, frames), device=x.device, dtype=torch.float32)
+        sums = torch.empty(3, device=x.device, dtype=torch.float32)
+        _lib.check(L.pwg_stft_loss_forward(_ptr(fx), _ptr(fy), _ptr(mod.pair_basis), b, mod.hop_size, n_cols, mod.taps,
+                                           mod.bins, frames, float(mod.eps), _ptr(ws), _ptr(sums), _stream()),
+                   "stft_loss_forward")
+        ctx.save_for_backward(fx, fy)
+        ctx.mod, ctx.dims = mod, (b, t, frames, n_cols, pad)
+        return sums
+
+    @staticmethod
+    def backward(ctx, g3):
+        from .. import _lib, ops
+        from ..ops import _ptr, _stream
+
+        fx, fy = ctx.saved_tensors
+        mod = ctx.mod
+        b, t, frames, n_cols, pad = ctx.dims
+        g3 = g3.contiguous()
+        L = _lib.lib()
+        dspec = torch.empty(b, 2 * mod.bins, frames, device=fx.device, dtype=torch.float32)
+        _lib.check(L.pwg_stft_loss_backward(_ptr(fx), _ptr(fy), _ptr(mod.pair_basis), b, mod.hop_size, n_cols, mod.taps,
+                                            mod.bins, frames, float(mod.eps), _ptr(g3), _ptr(dspec), _stream()),
+                   "stft_loss_backward")
+        # d folded = transposed windowed DFT of (d re | d im): the data gradient of the DFT convolution
+        desc = ops.make_conv_desc(b, mod.hop_size, 2 * mod.bins, n_cols, frames, mod.taps)
+        if getattr(mod, "_bwd_image", None) is None or mod._bwd_image.device != fx.device:
+            mod._bwd_image = ops.pack_weight_bwd(desc, mod.basis)
+        dfold = ops.conv1d_backward_data(desc, dspec, mod._bwd_image)
+        dx = torch.empty(b, t, device=fx.device, dtype=torch.float32)
+        _lib.check(L.pwg_frame_fold_backward(_ptr(dfold), _ptr(dx), b, t, pad, mod.hop_size, n_cols, _stream()),
+                   "frame_fold_backward")
+        return dx, None, None

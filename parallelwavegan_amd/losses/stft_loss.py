@@ -48,8 +48,16 @@ class STFTLoss(torch.nn.Module):
         self.register_buffer("window", getattr(torch, window)(win_length))  # state-dict compatibility
         self.stft_magnitude = STFTMagnitude(fft_size, shift_size, win_length, window, eps=1e-7)
 
+    fused = True  # one fused launch per resolution (csrc/stft_loss.hip); False: the op-by-op chain
+
     def forward(self, x, y):
         """x: predicted (B, T), y: ground truth (B, T) -> (sc_loss, mag_loss)."""
+        if self.fused and not (torch.is_grad_enabled() and y.requires_grad):
+            # frame -> windowed DFT (MFMA) -> magnitude -> log -> the three sums, for both signals, in one
+            # kernel; the two losses are 0-dim arithmetic on the sums (stft_loss.py:61, :82)
+            s = self.stft_magnitude.pair_sums(x, y)
+            n = x.shape[0] * self.stft_magnitude.bins * self.stft_magnitude.frames(x.shape[1])
+            return torch.sqrt(s[0]) / torch.sqrt(s[1]), s[2] / n
         x_mag = self.stft_magnitude(x)
         y_mag = self.stft_magnitude(y)
         return self.spectral_convergence_loss(x_mag, y_mag), self.log_stft_magnitude_loss(x_mag, y_mag)

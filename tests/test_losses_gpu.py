@@ -19,12 +19,15 @@ def _rel(a, b):
     return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
 
 
-def test_mel_loss_matches_reference_golden(device):
+@pytest.mark.parametrize("fused", [True, False])
+def test_mel_loss_matches_reference_golden(fused, device):
+    """fused = pwg_mel_loss_* (DFT, magnitude, filterbank, log, L1 of both signals in one kernel)."""
     gold = load_golden("losses")
     seed = int(gold["meta"][0])
     y = (0.5 * synth.synth_input("y", (2, 1, 8192), seed=seed)).to(device)
     yh = (0.5 * synth.synth_input("yh", (2, 1, 8192), seed=seed)).to(device).requires_grad_()
     crit = losses.MelSpectrogramLoss(**MEL_PARAMS).to(device)
+    crit.fused = fused
     loss = crit(yh, y)
     loss.backward()
     assert abs(loss.item() - float(gold["mel_loss"])) <= 2e-5 * float(gold["mel_loss"])
@@ -35,6 +38,7 @@ def test_mel_loss_matches_reference_golden(device):
     # LibriTTS parameters: n_fft 2048, hop 300, window 1200 (window shorter than the FFT)
     crit2 = losses.MelSpectrogramLoss(fs=24000, fft_size=2048, hop_size=300, win_length=1200, window="hann",
                                       num_mels=80, fmin=0, fmax=12000, log_base=None).to(device)
+    crit2.fused = fused
     yh.grad = None
     loss2 = crit2(yh[..., :8100], y[..., :8100])
     loss2.backward()
@@ -42,16 +46,21 @@ def test_mel_loss_matches_reference_golden(device):
     assert _rel(yh.grad.cpu().numpy(), gold["mel2_grad"]) <= 2e-4
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("tag,kw,shape", [
     ("stft", dict(), (2, 6000)),
     ("substft", dict(fft_sizes=[384, 683, 171], hop_sizes=[30, 60, 10], win_lengths=[150, 300, 60]), (2, 4, 1500)),
 ])
-def test_multi_resolution_stft_loss_matches_reference_golden(tag, kw, shape, device):
+def test_multi_resolution_stft_loss_matches_reference_golden(tag, kw, shape, fused, device):
+    """fused = one pwg_stft_loss launch per resolution (no spectrum / magnitude / log tensor in HBM);
+    unfused = the op-by-op chain (frame_fold, DFT conv, stft_mag, log_clamp, reductions)."""
     gold = load_golden("losses")
     seed = int(gold["meta"][0])
     a = (0.5 * synth.synth_input(tag + "x", shape, seed=seed)).to(device).requires_grad_()
     b = (0.5 * synth.synth_input(tag + "y", shape, seed=seed)).to(device)
     crit = losses.MultiResolutionSTFTLoss(**kw).to(device)
+    for f in crit.stft_losses:
+        f.fused = fused
     sc, mag = crit(a, b)
     (sc + mag).backward()
     assert abs(sc.item() - float(gold[tag + "_sc"])) <= 2e-5 * float(gold[tag + "_sc"])
@@ -99,3 +108,46 @@ def test_stft_function_honours_its_window_argument(device):
         got = stft(x.to(device), 512, 60, 240, win.to(device))
         assert got.shape == ref.shape
         assert max_abs(got, ref) <= 2e-5 * float(ref.max())
+
+
+def test_fused_stft_loss_is_deterministic_and_handles_ragged_tiles(device):
+    """Frame / bin counts that are not multiples of the 32 x 32 wave tile, an odd hop, several batch items:
+    fused sums == the unfused chain; two runs are bit-identical (fixed tiles, fixed summation order)."""
+    from parallelwavegan_amd.losses.stft_loss import STFTLoss
+
+    for fft, hop, win, t in ((256, 37, 200, 2500), (512, 128, 512, 4000), (100, 10, 60, 700)):
+        x = (0.5 * synth.synth_input("fx", (3, t), seed=fft)).to(device).requires_grad_()
+        y = (0.5 * synth.synth_input("fy", (3, t), seed=fft + 1)).to(device)
+        crit = STFTLoss(fft, hop, win).to(device)
+        sc, mag = crit(x, y)
+        (sc + 2.0 * mag).backward()
+        g_fused = x.grad.clone()
+        sc2, mag2 = crit(x, y)
+        assert torch.equal(sc, sc2) and torch.equal(mag, mag2)
+        crit.fused = False
+        x.grad = None
+        sc_u, mag_u = crit(x, y)
+        (sc_u + 2.0 * mag_u).backward()
+        assert abs(sc.item() - sc_u.item()) <= 2e-5 * sc_u.item(), (fft, sc.item(), sc_u.item())
+        assert abs(mag.item() - mag_u.item()) <= 2e-5 * mag_u.item(), (fft, mag.item(), mag_u.item())
+        assert _rel(g_fused.cpu().numpy(), x.grad.cpu().numpy()) <= 2e-3
+
+
+def test_fused_mel_loss_log_bases_and_ragged_shapes(device):
+    """log10 / log2 / ln, a mel count that is not a multiple of 32, frame counts off the tile grid: the fused
+    kernel equals the op-by-op chain in value and gradient, and two runs are bit-identical."""
+    for log_base, mels, t, b in ((10.0, 80, 5000, 3), (2.0, 40, 2600, 2), (None, 100, 9000, 1)):
+        y = (0.4 * synth.synth_input("my", (b, 1, t), seed=mels)).to(device)
+        yh = (0.4 * synth.synth_input("myh", (b, 1, t), seed=mels + 1)).to(device).requires_grad_()
+        crit = losses.MelSpectrogramLoss(fs=22050, fft_size=512, hop_size=128, win_length=400, window="hann",
+                                         num_mels=mels, fmin=50, fmax=8000, log_base=log_base).to(device)
+        l1 = crit(yh, y)
+        l1.backward()
+        g1 = yh.grad.clone()
+        assert torch.equal(l1, crit(yh, y))
+        crit.fused = False
+        yh.grad = None
+        l0 = crit(yh, y)
+        l0.backward()
+        assert abs(l1.item() - l0.item()) <= 2e-5 * l0.item(), (log_base, l1.item(), l0.item())
+        assert _rel(g1.cpu().numpy(), yh.grad.cpu().numpy()) <= 5e-4
