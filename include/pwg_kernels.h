@@ -155,6 +155,16 @@ size_t pwg_conv1d_backward_weight_workspace_floats(const pwg_conv1d_desc* d);
 int pwg_conv1d_backward_weight(const pwg_conv1d_desc* d, const float* x, const float* dy, float* dw,
                                float* db, float* workspace, size_t workspace_floats, void* stream);
 
+/* Weight-normalised layers (old-style torch.nn.utils.weight_norm, dim 0: every conv of the generators and
+ * discriminators): the same weight-gradient kernel, but the finishing kernel turns the reduction slabs
+ * directly into dv and dg  (dg = <dw, v> / |v|,  dv = (g / |v|)(dw - v <dw, v> / |v|^2))  -- dw is never
+ * materialised and the separate slab-reduction and weight-norm-backward launches disappear.  v / g: the
+ * layer's weight_v (torch weight layout) and weight_g; db optional as above.  The workspace is mandatory. */
+size_t pwg_conv1d_backward_weight_wn_workspace_floats(const pwg_conv1d_desc* d);
+int pwg_conv1d_backward_weight_wn(const pwg_conv1d_desc* d, const float* x, const float* dy, const float* v,
+                                  const float* g, float* dv, float* dg, float* db, float* workspace,
+                                  size_t workspace_floats, void* stream);
+
 /* Tuning / diagnostics: the same operation with an explicit tile configuration
  * (0 <= tile_config < pwg_conv1d_num_tile_configs()) and staging path (use_dma:
  * 1 = LDS-DMA double-buffered, 0 = register-staged).  tools/bench_conv.py sweeps

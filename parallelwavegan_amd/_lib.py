@@ -87,6 +87,9 @@ SIGNATURES = {
                                                 _vp]),
     "pwg_conv1d_backward_weight_workspace_floats": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
     "pwg_conv1d_backward_weight": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    "pwg_conv1d_backward_weight_wn_workspace_floats": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
+    "pwg_conv1d_backward_weight_wn": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                                     ctypes.c_size_t, _vp]),
     "pwg_conv1d_num_tile_configs": (ctypes.c_int, []),
     "pwg_conv1d_forward_cfg": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "pwg_act_backward": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _f32, _vp]),

@@ -68,6 +68,24 @@ static std::vector<ProfTotal> g_prof_totals;
 
 bool prof_enabled() { return g_prof_on; }
 
+const char* prof_shape_name(const char* family, const char* fmt, ...) {
+  static const bool shapes = getenv("PWG_PROF_SHAPES") != nullptr;
+  if (!shapes || !g_prof_on) return family;
+  char buf[256];
+  int n = snprintf(buf, sizeof(buf), "%s ", family);
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf + n, sizeof(buf) - n, fmt, ap);
+  va_end(ap);
+  static std::mutex mu;
+  static std::vector<std::string*> pool;  // interned: ProfRec keeps the pointer
+  std::lock_guard<std::mutex> lk(mu);
+  for (auto* s : pool)
+    if (*s == buf) return s->c_str();
+  pool.push_back(new std::string(buf));
+  return pool.back()->c_str();
+}
+
 void prof_record(hipStream_t stream, const char* kernel, double flops, double bytes, bool begin) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   if (begin) {

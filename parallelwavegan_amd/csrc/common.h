@@ -30,6 +30,9 @@ void set_error(const char* fmt, ...);
 // Optional per-launch timing with HIP events recorded on the launch stream (pwg_prof_* in the
 // public header).  Zero cost when disabled.
 bool prof_enabled();
+// PWG_PROF_SHAPES=1: launches are accounted per problem shape instead of per kernel family; returns an
+// interned (pointer-stable) name built from the format, else `family` itself
+const char* prof_shape_name(const char* family, const char* fmt, ...);
 void prof_record(hipStream_t stream, const char* kernel, double flops, double bytes, bool begin);
 struct ProfScope {
   hipStream_t s;

@@ -814,7 +814,12 @@ static int launch_conv(const ConvArgs& a0, const Geometry& g, int batch, int gro
                               (double)groups * g.k_phase * g.cin_g * g.m_g);
   maybe_poison_lds(stream);
   {
-    ProfScope prof(stream, DMA ? "conv1d_mfma_dma_kernel" : "conv1d_mfma_kernel", flops, bytes);
+    ProfScope prof(stream,
+                   prof_shape_name(DMA ? "conv1d_mfma_dma_kernel" : "conv1d_mfma_kernel",
+                                   "B%d Cin%d M%d(x%dph) Tin%d cols%d k%d s%d d%d g%d W%d tile%dx%dx%d split%d%s", batch,
+                                   g.cin_g * groups, g.cout_g * groups, g.phases, a.t_in, g.n_cols, g.k_phase, g.stride,
+                                   g.dil, groups, a.width, BM, BN, CK, a.ksplit, a.mask_src ? " dgrad" : ""),
+                   flops, bytes);
     hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
   }
   PWG_CHECK_LAUNCH("conv1d_forward");

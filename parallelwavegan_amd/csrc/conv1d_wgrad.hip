@@ -405,6 +405,85 @@ __global__ void bias_grad_kernel(const float* dy, float* db, int channels, int n
   if (threadIdx.x == 0) atomicAdd(db + c, red[0] + red[1] + red[2] + red[3]);
 }
 
+
+// Fused finish of a weight-normalised layer: dw = sum of the reduction slabs (in slab order), then the
+// old-style weight_norm (dim 0) backward of that row -- dg = <dw, v> / |v|, dv = (g / |v|)(dw - v <dw, v> / |v|^2)
+// -- in ONE kernel: dw is never materialised and the separate reduce_slabs + weight_norm_backward launches
+// (2 x ~170 per HiFi-GAN training step) disappear.  One workgroup per dim-0 slice; 32 element lanes x 8 slab
+// lanes (every slab lane adds its slabs j = sl, sl + 8, ... in order, the 8 partials are added in order:
+// deterministic).  Workgroups past the last row reduce the fused bias row.
+struct WnFinish {
+  const float* v;
+  const float* g;
+  float* dv;
+  float* dg;
+};
+static thread_local const WnFinish* g_wn_finish = nullptr;
+
+template <bool WIDE>
+__global__ __launch_bounds__(256) void reduce_slabs_wn_kernel(const float* __restrict__ slabs, long slab_stride,
+                                                              int nslabs, long slab_elems, const float* __restrict__ v,
+                                                              const float* __restrict__ g, float* __restrict__ dv,
+                                                              float* __restrict__ dg, float* __restrict__ db, int n0,
+                                                              int inner, int nbias) {
+  // WIDE = false (few slabs): row[inner]; one thread per element adds the slabs in order.
+  // WIDE = true (many slabs, short rows): part[8][inner] + 8 slab lanes per element, then the 8 partials in order.
+  extern __shared__ float row[];
+  __shared__ float red[2][4];
+  if ((int)blockIdx.x >= n0) {
+    const int c = ((int)blockIdx.x - n0) * 256 + threadIdx.x;
+    if (c < nbias) {
+      float s = 0.f;
+      for (int j = 0; j < nslabs; ++j) s += slabs[(long)j * slab_stride + slab_elems + c];
+      db[c] = s;
+    }
+    return;
+  }
+  const long base = (long)blockIdx.x * inner;
+  if (WIDE) {
+    const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    float* part = row + inner;  // [8][inner]
+    for (int e = el; e < inner; e += 32) {
+      float s = 0.f;
+      for (int j = sl; j < nslabs; j += 8) s += slabs[(long)j * slab_stride + base + e];
+      part[sl * inner + e] = s;
+    }
+    __syncthreads();
+  }
+  float svv = 0.f, sdv = 0.f;
+  for (int e = threadIdx.x; e < inner; e += 256) {
+    float t;
+    if (WIDE) {
+      const float* part = row + inner;
+      t = part[e];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) t += part[q * inner + e];
+    } else {
+      t = 0.f;
+      for (int j = 0; j < nslabs; ++j) t += slabs[(long)j * slab_stride + base + e];
+    }
+    row[e] = t;
+    const float a = v[base + e];
+    svv += a * a;
+    sdv += a * t;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    svv += __shfl_down(svv, o, 64);
+    sdv += __shfl_down(sdv, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = svv;
+    red[1][threadIdx.x >> 6] = sdv;
+  }
+  __syncthreads();
+  const float tvv = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+  const float tdv = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  const float norm = sqrtf(tvv);
+  if (threadIdx.x == 0) dg[blockIdx.x] = tdv / norm;
+  const float c1 = g[blockIdx.x] / norm, c2 = tdv / tvv;
+  for (int i = threadIdx.x; i < inner; i += 256) dv[base + i] = c1 * (row[i] - v[base + i] * c2);
+}
+
 struct WgPlan {
   bool small;      // 32x32 tile, waves split the taps
   bool win;        // per-tap windows
@@ -527,7 +606,8 @@ static int launch_wgrad_mode(WgArgs a, const WgPlan& p, float* dw_out, float* wo
   a.slab_elems = (long)a.co_g * a.groups * a.ci_g * a.k;
   float* db_out = a.db;  // non-null: the bias gradient rides along (row sums of the G tiles)
   a.slab_stride = a.slab_elems + (db_out ? (long)a.co_g * a.groups : 0);
-  if (p.splits == 1) {
+  const WnFinish* wn = g_wn_finish;
+  if (p.splits == 1 && wn == nullptr) {
     a.dw = dw_out;  // single slice: write the gradients directly
   } else {
     PWG_REQUIRE(workspace && ws_floats >= (size_t)p.splits * a.slab_stride, PWG_ERR_WORKSPACE,
@@ -539,10 +619,44 @@ static int launch_wgrad_mode(WgArgs a, const WgPlan& p, float* dw_out, float* wo
   dim3 grid(p.splits, p.tiles, p.tap_groups);
   maybe_poison_lds(stream);
   {
-    ProfScope prof(stream, "conv1d_wgrad_kernel", flops, bytes);
+    ProfScope prof(stream,
+                   prof_shape_name("conv1d_wgrad_kernel", "B%d Co%d Ci%d k%d s%d d%d g%d W%d cols%d splits%d tiles%d tg%d small%d win%d tt%d",
+                                   a.batch, a.co_g * a.groups, a.ci_g * a.groups, a.k, a.stride, a.dil, a.groups, a.width,
+                                   a.n_cols, p.splits, p.tiles, p.tg, (int)p.small, (int)p.win, p.tt),
+                   flops, bytes);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
   }
   PWG_CHECK_LAUNCH("conv1d_backward_weight");
+  // fused finisher: one workgroup per weight row, so it needs many rows or few slabs to fill the chip; layers
+  // with few rows cut into many slabs (C <= 128 generator stages) keep the wide slab reduction (one workgroup
+  // per 32 elements) followed by the row-wise weight-norm backward, into a spare slab of the workspace
+  const bool wn_fused = wn != nullptr && (p.splits < 16 || a.co_g * a.groups >= 512);
+  if (wn != nullptr && !wn_fused) {
+    float* dw_tmp = workspace + (size_t)p.splits * a.slab_stride;
+    {
+      ProfScope prof(stream, "reduce_slabs_kernel", 0, 4.0 * a.slab_stride * (p.splits + 1));
+      hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)((a.slab_stride + 31) / 32)), dim3(256), 0, stream,
+                         workspace, dw_tmp, db_out, a.slab_elems, a.slab_stride, p.splits);
+      PWG_CHECK_LAUNCH("reduce_slabs");
+    }
+    return pwg_weight_norm_backward(dw_tmp, wn->v, wn->g, wn->dv, wn->dg, a.co_g * a.groups, a.ci_g * a.k, stream);
+  }
+  if (wn != nullptr) {
+    const int n0 = a.co_g * a.groups, inner = a.ci_g * a.k;
+    const int nbias = db_out ? n0 : 0;
+    ProfScope prof(stream, "reduce_slabs_wn_kernel", 0, 4.0 * (a.slab_stride * (double)p.splits + 3.0 * a.slab_elems));
+    const bool wide = p.splits >= 16 && (size_t)9 * inner * sizeof(float) <= 64 * 1024;  // (>= 512 rows of <= 1820 floats)
+    if (wide)
+      hipLaunchKernelGGL(reduce_slabs_wn_kernel<true>, dim3(n0 + ceil_div(nbias, 256)), dim3(256),
+                         (size_t)9 * inner * sizeof(float), stream, (const float*)workspace, a.slab_stride, p.splits,
+                         a.slab_elems, wn->v, wn->g, wn->dv, wn->dg, db_out, n0, inner, nbias);
+    else
+      hipLaunchKernelGGL(reduce_slabs_wn_kernel<false>, dim3(n0 + ceil_div(nbias, 256)), dim3(256),
+                         (size_t)inner * sizeof(float), stream, (const float*)workspace, a.slab_stride, p.splits,
+                         a.slab_elems, wn->v, wn->g, wn->dv, wn->dg, db_out, n0, inner, nbias);
+    PWG_CHECK_LAUNCH("reduce_slabs_wn");
+    return PWG_OK;
+  }
   if (p.splits > 1) {
     ProfScope prof(stream, "reduce_slabs_kernel", 0, 4.0 * a.slab_stride * (p.splits + 1));
     if (p.splits >= 16) {
@@ -697,4 +811,38 @@ extern "C" int pwg_conv1d_backward_weight(const pwg_conv1d_desc* d_in, const flo
     default: WG_CASE(7);
   }
 #undef WG_CASE
+}
+
+
+// Weight-normalised layers: dv, dg (and db) straight from the reduction slabs -- see reduce_slabs_wn_kernel.
+// v (weight_v, torch layout) and g (weight_g, one value per dim-0 slice) are the forward's parameters.  The
+// workspace is always needed here (>= 1 slab): query it with the function below.
+extern "C" size_t pwg_conv1d_backward_weight_wn_workspace_floats(const pwg_conv1d_desc* d_in) {
+  if (!d_in || d_in->groups <= 0 || d_in->c_in % d_in->groups || d_in->c_out % d_in->groups) return 0;
+  const pwg_conv1d_desc flat = flatten_width(*d_in);
+  const pwg_conv1d_desc* d = &flat;
+  int co_g, ci_g, n_cols;
+  wgrad_roles(d, &co_g, &ci_g, &n_cols);
+  const WgPlan p = wgrad_plan(co_g, ci_g, d->groups, d->kernel, d->stride, d->dilation, d->width, n_cols, d->batch);
+  // (+1: room for the summed gradient when the two-kernel finish is used)
+  return (size_t)(p.splits + 1) * ((size_t)co_g * d->groups * ci_g * d->kernel + (size_t)co_g * d->groups);
+}
+
+extern "C" int pwg_conv1d_backward_weight_wn(const pwg_conv1d_desc* d, const float* x, const float* dy, const float* v,
+                                             const float* g, float* dv, float* dg, float* db, float* workspace,
+                                             size_t workspace_floats, void* stream) {
+  PWG_REQUIRE(d && v && g && dv && dg && workspace, PWG_ERR_NULL, "conv1d_backward_weight_wn: NULL pointer");
+  int co_g, ci_g, n_cols;
+  const pwg_conv1d_desc flat = flatten_width(*d);
+  wgrad_roles(&flat, &co_g, &ci_g, &n_cols);
+  PWG_REQUIRE((size_t)ci_g * d->kernel * sizeof(float) <= 64 * 1024, PWG_ERR_UNSUPPORTED,
+              "conv1d_backward_weight_wn: a weight row of %d floats exceeds the LDS row buffer", ci_g * d->kernel);
+  PWG_REQUIRE(workspace_floats >= pwg_conv1d_backward_weight_wn_workspace_floats(d), PWG_ERR_WORKSPACE,
+              "conv1d_backward_weight_wn: workspace too small");
+  const WnFinish wn{v, g, dv, dg};
+  g_wn_finish = &wn;
+  // (dw argument: any non-NULL pointer selects the weight-gradient path; the slabs live in the workspace)
+  const int rc = pwg_conv1d_backward_weight(d, x, dy, dv, db, workspace, workspace_floats, stream);
+  g_wn_finish = nullptr;
+  return rc;
 }

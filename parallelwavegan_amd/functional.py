@@ -177,7 +177,14 @@ class FusedConvFn(torch.autograd.Function):
         dx = dw = db = dg = None
         if need_x:
             dx = ops.conv1d_backward_data(desc, gsum, ctx.holder.bwd(desc), x3).reshape(ctx.x_shape)
-        if need_w or need_g or (need_b and has_bias):
+        wn_row_bytes = 4 * (ctx.w_shape[1] * ctx.w_shape[2])
+        if ctx.has_g and (need_w or need_g) and wn_row_bytes <= 64 * 1024:
+            # weight-normalised layer: slabs -> (dv, dg) in one fused finishing kernel
+            dv, dg, db = ops.conv1d_backward_weight_wn(desc, x3, gsum, v, g.reshape(-1),
+                                                       need_db=need_b and has_bias)
+            dw = dv.reshape(ctx.w_orig_shape)
+            dg = dg.reshape(g.shape)
+        elif need_w or need_g or (need_b and has_bias):
             dw, db = ops.conv1d_backward_weight(desc, x3, gsum, ctx.w_shape, need_dw=need_w or need_g,
                                                 need_db=need_b and has_bias)
             if dw is not None and ctx.has_g:

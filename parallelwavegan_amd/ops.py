@@ -148,6 +148,21 @@ def conv1d_backward_weight(desc, x, dy, weight_shape, need_dw=True, need_db=True
     return dw, db
 
 
+def conv1d_backward_weight_wn(desc, x, dy, v, g, need_db=True):
+    """(dv, dg, db) of a weight-normalised layer: weight-gradient kernel + ONE fused finishing kernel (slab sum
+    + weight-norm backward); ``v`` is weight_v in torch layout, ``g`` weight_g."""
+    _require_device(x, dy, v, g)
+    dv = torch.empty_like(v)
+    dg = torch.empty_like(g)
+    db = torch.empty(desc.c_out, device=x.device, dtype=torch.float32) if need_db else None
+    ws_n = _lib.lib().pwg_conv1d_backward_weight_wn_workspace_floats(ctypes.byref(desc))
+    ws = torch.empty(max(ws_n, 1), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().pwg_conv1d_backward_weight_wn(ctypes.byref(desc), _ptr(x), _ptr(dy), _ptr(v), _ptr(g), _ptr(dv),
+                                                        _ptr(dg), _ptr(db), _ptr(ws), ws_n, _stream()),
+               "conv1d_backward_weight_wn")
+    return dv, dg, db
+
+
 def weight_norm_scale(v, g):
     """scale[i] = g[i] / ||v[i]||  (old-style weight_norm, dim=0)."""
     _require_device(v, g)
@@ -198,10 +213,10 @@ class profile:
         l.pwg_prof_enable(0)
         n = l.pwg_prof_num_kernels()
         for i in range(n):
-            name = ctypes.create_string_buffer(128)
+            name = ctypes.create_string_buffer(256)
             ms, fl, by = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
             cnt = ctypes.c_int64()
-            _lib.check(l.pwg_prof_get(i, name, 128, ctypes.byref(ms), ctypes.byref(cnt), ctypes.byref(fl),
+            _lib.check(l.pwg_prof_get(i, name, 256, ctypes.byref(ms), ctypes.byref(cnt), ctypes.byref(fl),
                                       ctypes.byref(by)), "prof_get")
             self.results[name.value.decode()] = dict(ms=ms.value, launches=cnt.value, flops=fl.value, bytes=by.value)
         l.pwg_prof_reset()
