@@ -959,7 +959,11 @@ static int choose_cfg(const Geometry& g, int W, int batch, int groups, bool dma,
     const double mfma_chunk = 64.0 * c.wm * c.wn * k * (c.ck / 2);  // MFMA cycles per chunk per wave
     const int nchunks = ceil_div(g.cin_g, c.ck);
     int split = 1;
-    while (split < 8 && nchunks >= 8 * split && mfma_chunk * per_cu * (2 * split) <= 6200.0) split *= 2;
+    // ... and only while the launch has fewer than 2 workgroups per CU: a grid that already fills the chip
+    // loses by splitting (measured, tools/sweep_shapes.py: C=128 k=3 T=2048 at 512 workgroups 72 -> 50 TFLOP/s,
+    // C=64 k=3 T=4096 at 1024 workgroups 58 -> 36)
+    while (split < 8 && nchunks >= 8 * split && blocks * split < 512 && mfma_chunk * per_cu * (2 * split) <= 6200.0)
+      split *= 2;
     return split;
   };
   int best = -1, best_split = 1;
