@@ -750,7 +750,8 @@ struct HasFast {
                                 (WM == 1 && WN == 2 && WAVES_M == 2 && WAVES_N == 2 && CK == 8) ||   // 64x128x8
                                 (WM == 1 && WN == 1 && WAVES_M == 2 && WAVES_N == 2 && CK == 8) ||   // 64x64x8
                                 (WM == 1 && WN == 1 && WAVES_M == 2 && WAVES_N == 2 && CK == 16) ||  // 64x64x16
-                                (WM == 1 && WN == 1 && WAVES_M == 1 && WAVES_N == 4 && CK == 16);    // 32x128x16
+                                (WM == 1 && WN == 1 && WAVES_M == 1 && WAVES_N == 4 && CK == 16) ||  // 32x128x16
+                                (WM == 1 && WN == 1 && WAVES_M == 2 && WAVES_N == 2 && CK == 4);     // 64x64x4 (k = 41 groups)
 };
 
 template <int WM, int WN, int WAVES_M, int WAVES_N, int CK>
@@ -873,8 +874,9 @@ struct TileCfg {
   X(13, 1, 1, 2, 2, 8)    \
   X(14, 1, 1, 4, 1, 8)    \
   X(15, 1, 1, 2, 2, 16)   \
-  X(16, 1, 1, 1, 4, 16)
-static const int kNumCfgs = 17;
+  X(16, 1, 1, 1, 4, 16)   \
+  X(17, 1, 1, 2, 2, 4)
+static const int kNumCfgs = 18;
 
 static TileCfg cfg_info(int id) {
   switch (id) {
@@ -936,8 +938,10 @@ static int choose_cfg(const Geometry& g, int W, int batch, int groups, bool dma,
   static const Cand big_few[] = {{9, 0.95f}, {0, 0.85f}, {12, 0.85f}, {13, 0.75f}, {14, 0.6f}, {2, 0.8f},
                                  {15, 0.8f}, {16, 0.82f}};
   static const Cand big_many[] = {{2, 1.0f}, {9, 0.9f}, {12, 0.85f}, {13, 0.75f}, {14, 0.6f}, {15, 0.8f}, {16, 0.82f}};
-  static const Cand mid_few[] = {{10, 1.0f}, {11, 0.8f}, {13, 0.8f}};
-  static const Cand mid_many[] = {{11, 1.0f}, {10, 0.9f}, {13, 0.8f}};
+  // 17 = 64x64x4: the only 64-row tile whose double-buffered weight chunk fits the LDS at k = 41 (grouped
+  // scale-discriminator layers, 64 channels per group, T = 9..128 columns per item)
+  static const Cand mid_few[] = {{10, 1.0f}, {11, 0.8f}, {13, 0.8f}, {17, 0.7f}};
+  static const Cand mid_many[] = {{11, 1.0f}, {10, 0.9f}, {13, 0.8f}, {17, 0.85f}};
   static const Cand small_any[] = {{10, 1.0f}};
   const Cand* cand;
   int ncand;
@@ -946,7 +950,7 @@ static int choose_cfg(const Geometry& g, int W, int batch, int groups, bool dma,
     ncand = k <= 4 ? 8 : 7;
   } else if (m > 32) {
     cand = k <= 8 ? mid_few : mid_many;
-    ncand = 3;
+    ncand = 4;
   } else {
     cand = small_any;
     ncand = 1;
@@ -977,7 +981,10 @@ static int choose_cfg(const Geometry& g, int W, int batch, int groups, bool dma,
       const long ntiles = ceil_div(g.n_cols, c.bn);
       const long blocks = ntiles * ceil_div(m, c.bm) * groups * batch;
       const int split = max_split(c, blocks);
-      const float fill = blocks * split >= 512 ? 1.f : (float)(blocks * split) / 512.f;
+      // (very long filters -- k = 41 grouped layers -- carry >= 5000 MFMA cycles per chunk: one workgroup
+      // per CU already hides the DMA round trip, so 256 workgroups count as a full chip there)
+      const float full = k >= 32 ? 256.f : 512.f;
+      const float fill = blocks * split >= full ? 1.f : (float)(blocks * split) / full;
       const float useful = (float)g.n_cols / (float)(ntiles * c.bn) * (float)m / (float)(ceil_div(m, c.bm) * c.bm);
       const float score = fill * useful * cand[i].speed * (split > 1 ? 0.9f : 1.f);
       if (score > best_score) {

@@ -11,7 +11,7 @@ from parallelwavegan_amd import ops  # noqa: E402
 
 CFG = {0: (128, 128, 8), 1: (128, 128, 16), 2: (128, 128, 4), 3: (64, 256, 8), 4: (64, 256, 16), 5: (32, 256, 8),
        6: (32, 256, 16), 7: (32, 512, 8), 8: (32, 512, 16), 9: (128, 64, 8), 10: (32, 128, 8), 11: (64, 256, 4),
-       12: (64, 128, 8), 13: (64, 64, 8), 14: (128, 32, 8), 15: (64, 64, 16), 16: (32, 128, 16)}
+       12: (64, 128, 8), 13: (64, 64, 8), 14: (128, 32, 8), 15: (64, 64, 16), 16: (32, 128, 16), 17: (64, 64, 4)}
 
 
 def timeit(fn, reps=10):
@@ -32,6 +32,8 @@ SHAPES = [  # (name, B, Cin, Cout, T, k, stride, dil, groups)
     ("mpd 1024 k5 d2 T102", 16, 1024, 1024, 102, 5, 1, 2, 1),
     ("msd 1024 k41 g16 T32", 16, 1024, 1024, 32, 41, 1, 1, 16),
     ("msd 1024 k41 g16 T9", 16, 1024, 1024, 9, 41, 1, 1, 16),
+    ("msd 1024 k41 g16 T17", 16, 1024, 1024, 17, 41, 1, 1, 16),
+    ("msd 256->1024 k41 s4 g16", 16, 256, 1024, 128, 41, 4, 1, 16),
     ("msd 1024 k5 T32", 16, 1024, 1024, 32, 5, 1, 1, 1),
     ("msd 1024 k5 T9", 16, 1024, 1024, 9, 5, 1, 1, 1),
     ("g 256 k11 T256", 16, 256, 256, 256, 11, 1, 1, 1),
@@ -49,14 +51,15 @@ SHAPES = [  # (name, B, Cin, Cout, T, k, stride, dil, groups)
 dev = torch.device("cuda:0")
 for name, b, cin, cout, t, k, s, d, g in SHAPES:
     pad = (k - 1) // 2 * d
-    desc = ops.make_conv_desc(b, cin, cout, t, t, k, stride=s, dilation=d, pad_left=pad, groups=g, post_act="leaky_relu",
-                              post_slope=0.1)
+    t_out = ops.conv_out_length(t, k, s, d, pad, pad)
+    desc = ops.make_conv_desc(b, cin, cout, t, t_out, k, stride=s, dilation=d, pad_left=pad, groups=g,
+                              post_act="leaky_relu", post_slope=0.1)
     w = torch.randn(cout, cin // g, k, device=dev) * 0.05
     wp = ops.pack_weight(desc, w)
     x = torch.randn(b, cin, t, device=dev)
     bias = torch.randn(cout, device=dev)
-    y = torch.empty(b, cout, t, device=dev)
-    flops = 2.0 * (cin // g) * cout * k * t * b
+    y = torch.empty(b, cout, t_out, device=dev)
+    flops = 2.0 * (cin // g) * cout * k * t_out * b
     ms = timeit(lambda: ops.conv1d_forward(desc, x, wp, bias, out=y))
     res = []
     for cid, (bm, bn, ck) in CFG.items():
