@@ -599,6 +599,83 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(FinishArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Few-output-channel convolutions (the generators' last layer: C -> 1, k = 7, at the full audio rate).
+// On the MFMA tile a 1-row output wastes 31/32 of the matrix work (0.6 ms = 2.4 TFLOP/s for HiFi-GAN's
+// 32 -> 1 layer at 3.3 M samples, although it is a 420 MB streaming read).  Here: one workgroup per
+// (item, 1024-sample tile); the input rows go through LDS one channel at a time (pre-activation applied
+// on the way), every thread accumulates 4 outputs (stride 256: conflict-free LDS reads) x <= 4 channels
+// with plain fp32 FMAs in (ci, tap) order.  HBM-bound: one read of x, one write of y.
+// ---------------------------------------------------------------------------
+constexpr int SC_TILE = 1024;
+constexpr int SC_MAXW = 2048;  // cout * cin * k floats of weights in LDS
+__global__ __launch_bounds__(256) void conv1d_small_cout_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                                const float* __restrict__ bias, float* __restrict__ y,
+                                                                int cin, int cin_pad, int m_pad, int cout, int t_in,
+                                                                int t_out, int k, int dil,
+                                                                int pad, int pre_act, float pre_slope, int post_act,
+                                                                float post_slope, float out_mul) {
+  extern __shared__ float sm[];
+  float* ws = sm;                      // [cout][cin][k]
+  float* xs = sm + cout * cin * k;     // [SC_TILE + halo]
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * SC_TILE;
+  const int halo = (k - 1) * dil;
+  const int L = SC_TILE + halo;
+  for (int i = threadIdx.x; i < cout * cin * k; i += 256) {  // from the packed image [tap][ci][m]
+    const int tap = i % k, ci = (i / k) % cin, c = i / (k * cin);
+    ws[i] = wp[((long)tap * cin_pad + ci) * m_pad + c];
+  }
+  float acc[4][4];
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[o][c] = 0.f;
+  const float* xb = x + (long)b * cin * t_in;
+  for (int ci = 0; ci < cin; ++ci) {
+    __syncthreads();  // previous channel consumed (and, first time, the weights staged)
+    for (int i = threadIdx.x; i < L; i += 256) {
+      const int f = t0 - pad + i;
+      float v = (f >= 0 && f < t_in) ? xb[(long)ci * t_in + f] : 0.f;
+      if (pre_act == PWG_ACT_LEAKY_RELU)
+        v = v > 0.f ? v : v * pre_slope;
+      else if (pre_act == PWG_ACT_RELU)
+        v = v > 0.f ? v : 0.f;
+      xs[i] = v;
+    }
+    __syncthreads();
+    for (int tap = 0; tap < k; ++tap) {
+      float xv[4];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) xv[o] = xs[threadIdx.x + 256 * o + tap * dil];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (c < cout) {
+          const float wv = ws[(c * cin + ci) * k + tap];
+#pragma unroll
+          for (int o = 0; o < 4; ++o) acc[o][c] = __builtin_fmaf(wv, xv[o], acc[o][c]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (c < cout) {
+      const float bv = bias ? bias[c] : 0.f;
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const int t = t0 + threadIdx.x + 256 * o;
+        if (t < t_out) {
+          float v = acc[o][c] + bv;
+          if (out_mul != 1.0f) v *= out_mul;
+          y[((long)b * cout + c) * t_out + t] = apply_act(v, post_act, post_slope);
+        }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // weight packing:  torch layout -> [group][tap][ci (pad 16)][m (pad 32)]
 // ---------------------------------------------------------------------------
@@ -1148,6 +1225,22 @@ extern "C" int pwg_conv1d_forward(const pwg_conv1d_desc* d_in, const float* x, c
   Geometry g;
   int rc = make_geometry(d, &g);
   if (rc != PWG_OK) return rc;
+  if (!d->transposed && d->groups == 1 && d->width == 1 && d->stride == 1 && d->pad_mode == PWG_PAD_ZERO &&
+      d->c_out <= 4 && d->c_out * d->c_in * d->kernel <= SC_MAXW && !add1 && !add2 && d->out_div == 1.0f &&
+      d->t_out >= 4096 && (d->kernel - 1) * d->dilation <= 1024) {
+    PWG_REQUIRE(x && w_packed && y, PWG_ERR_NULL, "conv1d_forward: NULL pointer");
+    // few output channels over a long sequence: streaming VALU kernel (see conv1d_small_cout_kernel)
+    const size_t lds = ((size_t)d->c_out * d->c_in * d->kernel + SC_TILE + (d->kernel - 1) * d->dilation) * sizeof(float);
+    const double out_elems = (double)d->batch * d->c_out * d->t_out;
+    ProfScope prof((hipStream_t)stream, "conv1d_small_cout_kernel", 2.0 * out_elems * d->c_in * d->kernel,
+                   4.0 * ((double)d->batch * d->c_in * d->t_in + out_elems));
+    hipLaunchKernelGGL(conv1d_small_cout_kernel, dim3(ceil_div(d->t_out, SC_TILE), d->batch), dim3(256), lds,
+                       (hipStream_t)stream, x, w_packed, bias, y, d->c_in, g.cin_pad, g.m_pad, d->c_out, d->t_in, d->t_out,
+                       d->kernel, d->dilation, d->pad_left, d->pre_act, d->pre_slope, d->post_act, d->post_slope,
+                       d->out_mul);
+    PWG_CHECK_LAUNCH("conv1d_small_cout");
+    return PWG_OK;
+  }
   ConvArgs a;
   rc = fill_args(d, g, x, w_packed, bias, add1, add2, y, &a);
   if (rc != PWG_OK) return rc;

@@ -229,3 +229,30 @@ def test_split_reduction_forward_backward(B, Cin, Cout, T, K, stride, pad, group
     assert _lib.lib().pwg_conv1d_backward_data_workspace_floats(ctypes.byref(desc_b)) > 0
     dx = ops.conv1d_backward_data(desc_b, dyd, ops.pack_weight_bwd(desc_b, wd), xd, acc.to(device))
     _close(dx, x.grad + acc, "split backward_data")
+
+
+@pytest.mark.parametrize("cin,cout,t,k,dil,pre,post", [
+    (32, 1, 5000, 7, 1, "leaky_relu", "tanh"),   # HiFi-GAN / MelGAN output layer
+    (48, 4, 9000, 7, 2, "leaky_relu", None),     # multi-band output, dilated
+    (64, 1, 4100, 1, 1, "relu", None),           # Parallel WaveGAN's last 1x1
+    (16, 3, 4096, 15, 1, None, None),
+])
+def test_small_cout_streaming_kernel(cin, cout, t, k, dil, pre, post, device):
+    """C -> <= 4 channels over a long sequence takes the streaming VALU kernel (conv1d_small_cout_kernel)
+    instead of a 1-row MFMA tile; values vs ATen CPU."""
+    g = torch.Generator().manual_seed(cin + k)
+    x = torch.randn(2, cin, t, generator=g)
+    w = torch.randn(cout, cin, k, generator=g) / (cin * k) ** 0.5
+    b = 0.1 * torch.randn(cout, generator=g)
+    pad = (k - 1) // 2 * dil
+    xa = x if pre is None else (F.leaky_relu(x, 0.1) if pre == "leaky_relu" else F.relu(x))
+    ref = F.conv1d(xa, w, b, dilation=dil, padding=pad)
+    if post == "tanh":
+        ref = torch.tanh(ref)
+    desc = ops.make_conv_desc(2, cin, cout, t, t, k, dilation=dil, pad_left=pad, pre_act=pre, pre_slope=0.1,
+                              post_act=post)
+    wd = w.to(device)
+    with ops.profile() as prof:
+        y = ops.conv1d_forward(desc, x.to(device), ops.pack_weight(desc, wd), b.to(device))
+    assert "conv1d_small_cout_kernel" in prof.results
+    assert (y.cpu() - ref).abs().max().item() <= 2e-5 * max(1.0, float(ref.abs().max()))
