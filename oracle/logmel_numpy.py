@@ -8,9 +8,11 @@ Third-party algorithm: the reference calls ``librosa.stft`` and ``librosa.filter
 definitions are restated: ``stft(y, n_fft, hop_length, win_length, window, center=True,
 pad_mode="reflect")`` = reflect-pad by n_fft//2, frames of n_fft samples every hop_length, multiplied
 by the periodic (``fftbins=True``) window of win_length zero-padded symmetrically to n_fft, rFFT.
-PARITY-UNPINNED against librosa itself; pinned instead against ``torch.stft`` (the formulation of the
+Not pinned against librosa itself (absent); pinned against ``torch.stft`` (the formulation of the
 reference's own ``MelSpectrogram``, losses/mel_loss.py:81-110, which its test_mel_loss.py asserts
-equal to logmelfilterbank) in tests/test_oracle_golden.py.
+equal to logmelfilterbank) in tests/test_oracle_golden.py AND against an independent third-party
+implementation of the librosa definitions, ``transformers.audio_utils.spectrogram`` /
+``mel_filter_bank(norm="slaney", mel_scale="slaney")``, in tests/test_mel_third_party.py (<= 1e-6).
 """
 import numpy as np
 import scipy.signal

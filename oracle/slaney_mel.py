@@ -6,7 +6,10 @@ independently of each other's code path and compared in tests.
 
 Third-party algorithm: librosa (``librosa>=0.8.0``, reference setup.py:29) is
 not vendored under /root/reference and not installed here, so the *values* of
-the basis are PARITY-UNPINNED.  Call sites in the reference:
+the basis cannot be pinned against librosa itself; they are pinned
+(<= 1e-7 relative) against an independent third-party implementation of the same
+definition, ``transformers.audio_utils.mel_filter_bank(norm="slaney",
+mel_scale="slaney")``, in tests/test_mel_third_party.py.  Call sites in the reference:
 ``parallel_wavegan/losses/mel_loss.py:52-59`` and
 ``parallel_wavegan/bin/preprocess.py:72-78``.
 
