@@ -322,9 +322,27 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WM * WN >= 8 ? 1 : (WM * W
   // expressed per lane: an out-of-range lane gets the offset 0xFFFFFFFC, which is past num_records
   // and lands as 0.0 in LDS.
   __amdgpu_buffer_rsrc_t x_rs = uniform_buffer_rsrc(xb, (unsigned)(a.cin_g * a.x_cstride) * 4u);
+  // Interior FAST tiles (the whole BN + 64 staged range inside the row): one 16-B-per-lane DMA per x row
+  // instead of three 4-B ones.  `buffer_load_dwordx4 ... lds` is legal at 4-byte source alignment and its
+  // range check is per dword at the END of the buffer but per access for negative offsets
+  // (tools/probes/glds_x4.hip), so edge tiles keep the dword path below.
+  const bool x4_ok = FAST && f0 >= 0 && f0 + (BN + 64) <= a.t_in;
   auto issue = [&](int ci0, float* buf) {
     float* xs = buf;
     float* ws = buf + CK * XS;
+    if (FAST && __builtin_amdgcn_readfirstlane(x4_ok ? 1 : 0)) {
+      constexpr int LANES = (BN + 64) / 4;  // 16-B pieces per row
+      for (int r = wave; r < CK; r += NWAVES) {
+        const int ci = ci0 + r;
+#pragma unroll
+        for (int l0 = 0; l0 < LANES; l0 += 64) {
+          if (l0 + lane < LANES) {
+            const unsigned off = ci < a.cin_g ? (unsigned)(ci * a.x_cstride + f0 + 4 * (l0 + lane)) * 4u : 0xFFFFFFF0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr_t)(xs + r * XS + 4 * l0), 16, off, 0, 0, 0);
+          }
+        }
+      }
+    } else
     for (int r = wave; r < CK; r += NWAVES) {
       const int ci = ci0 + r;
       const int rowoff = ci * a.x_cstride;

@@ -1,5 +1,8 @@
 """GPU: the Trainer drives the StyleMelGAN and UHiFiGAN families end to end (forward, losses, backward,
-fused Adam) -- finite losses, parameters move, StyleMelGAN stays out of hipGraph capture (random windows)."""
+fused Adam) -- finite losses, parameters move, the auxiliary spectral loss on a fixed batch DESCENDS (a step
+whose gradients, exchange or update were inconsistent with its forward would not), StyleMelGAN stays out of
+hipGraph capture (random windows).  Forward values and gradients of both families are pinned separately
+(tests/test_style_melgan_gpu.py, tests/test_uhifigan_gpu.py)."""
 import tempfile
 
 import numpy as np
@@ -13,11 +16,12 @@ from tests.golden import synth
 pytestmark = pytest.mark.gpu
 
 
-def _run(device, gtype, g, d, batch, n_steps=3, use_graph=False):
+def _run(device, gtype, g, d, batch, n_steps=24, use_graph=False):
     model = {"generator": g.to(device), "discriminator": d.to(device)}
     criterion = {"gen_adv": losses.GeneratorAdversarialLoss(), "dis_adv": losses.DiscriminatorAdversarialLoss(),
                  "stft": losses.MultiResolutionSTFTLoss(fft_sizes=[256, 512], hop_sizes=[32, 64], win_lengths=[128, 256]).to(device)}
-    opt = {k: optimizers.Adam(model[k].parameters(), lr=1e-4, betas=(0.5, 0.9)) for k in model}
+    opt = {"generator": optimizers.Adam(model["generator"].parameters(), lr=5e-4, betas=(0.5, 0.9)),
+           "discriminator": optimizers.Adam(model["discriminator"].parameters(), lr=1e-4, betas=(0.5, 0.9))}
     sched = {k: optimizers.lr_scheduler.StepLR(opt[k], step_size=10 ** 6, gamma=0.5) for k in model}
     config = dict(generator_type=gtype, generator_params={"out_channels": 1}, use_stft_loss=True,
                   use_subband_stft_loss=False, use_mel_loss=False, use_feat_match_loss=False, lambda_aux=1.0,
@@ -30,11 +34,18 @@ def _run(device, gtype, g, d, batch, n_steps=3, use_graph=False):
                  model=model, criterion=criterion, optimizer=opt, scheduler=sched, config=config, device=device)
     tr.tqdm = None
     before = [p.detach().clone() for p in g.parameters()]
+    aux, prev = [], 0.0
     for _ in range(n_steps):
         tr._train_step(batch)
-    tr._flush_pending()
+        tr._flush_pending()
+        cur = tr.total_train_loss["train/spectral_convergence_loss"] + tr.total_train_loss["train/log_stft_magnitude_loss"]
+        aux.append(cur - prev)
+        prev = cur
     assert all(np.isfinite(v) for v in tr.total_train_loss.values()), dict(tr.total_train_loss)
     assert any(not torch.equal(a, b) for a, b in zip(before, g.parameters()))
+    first, last = float(np.mean(aux[:3])), float(np.mean(aux[-3:]))
+    print(f"[family-train] {gtype}: aux loss {first:.4f} -> {last:.4f}")
+    assert last < 0.97 * first, (gtype, aux)
     return tr
 
 
