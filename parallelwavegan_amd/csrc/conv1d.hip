@@ -1044,7 +1044,7 @@ static int choose_cfg(const Geometry& g, int W, int batch, int groups, bool dma,
     cand = k <= 4 ? big_few : big_many;
     ncand = k <= 4 ? 8 : 7;
   } else if (m > 32) {
-    cand = k <= 8 ? mid_few : mid_many;
+    cand = k <= 4 ? mid_few : mid_many;  // (k = 7 at C = 64: 64x256x4 103 vs 32x128x8 95 TFLOP/s, profiles/r02_conv_sweep.txt)
     ncand = 4;
   } else {
     cand = small_any;
