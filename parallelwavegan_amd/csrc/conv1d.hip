@@ -326,15 +326,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WM * WN >= 8 ? 1 : (WM * W
   // instead of three 4-B ones.  `buffer_load_dwordx4 ... lds` is legal at 4-byte source alignment and its
   // range check is per dword at the END of the buffer but per access for negative offsets
   // (tools/probes/glds_x4.hip), so edge tiles keep the dword path below.
-  const bool x4_ok = FAST && f0 >= 0 && f0 + (BN + 64) <= a.t_in;
+  // (generic path: the staged flat range [f0, f0 + L) rounded up to whole 16-B pieces; rows are XS apart,
+  // XS a multiple of 64 floats there)
+  const int lanes4 = FAST ? (BN + 64) / 4 : (L + 3) / 4;  // 16-B pieces per row
+  const bool x4_ok = f0 >= 0 && f0 + 4 * lanes4 <= a.t_in * W;
   auto issue = [&](int ci0, float* buf) {
     float* xs = buf;
     float* ws = buf + CK * XS;
-    if (FAST && __builtin_amdgcn_readfirstlane(x4_ok ? 1 : 0)) {
-      constexpr int LANES = (BN + 64) / 4;  // 16-B pieces per row
+    if (__builtin_amdgcn_readfirstlane(x4_ok ? 1 : 0)) {
+      const int LANES = lanes4;
       for (int r = wave; r < CK; r += NWAVES) {
         const int ci = ci0 + r;
-#pragma unroll
         for (int l0 = 0; l0 < LANES; l0 += 64) {
           if (l0 + lane < LANES) {
             const unsigned off = ci < a.cin_g ? (unsigned)(ci * a.x_cstride + f0 + 4 * (l0 + lane)) * 4u : 0xFFFFFFF0u;
