@@ -176,7 +176,8 @@ def bench_train(args, tag, dev, rank, world, dist, steps, warmup, detail=True):
     # both phases active from the first step (steady state of the recipe after discriminator_train_start_steps)
     conf.update(generator_train_start_steps=0, discriminator_train_start_steps=0, train_max_steps=10 ** 9,
                 save_interval_steps=10 ** 9, eval_interval_steps=10 ** 9, log_interval_steps=10 ** 9,
-                distributed=world > 1, rank=rank, outdir=tempfile.mkdtemp(), progress=False,
+                distributed=world > 1 or os.environ.get("PWG_FORCE_DIST") == "1", rank=rank,
+                outdir=tempfile.mkdtemp(), progress=False,
                 use_hip_graph=not args.no_graph, graph_warmup_steps=2,
                 reuse_real_discriminator_pass=os.environ.get("PWG_REUSE_REAL", "1") == "1")
     batch = synthetic_batch(conf, b, dev, rank)
@@ -402,6 +403,16 @@ def main():
             os.close(saved)
     dev = torch.device("cuda", local_rank % n_dev)
     torch.cuda.set_device(dev)
+    force_dist = world == 1 and os.environ.get("PWG_FORCE_DIST") == "1"
+    if force_dist:
+        # single-GPU exercise of the data-parallel path on RCCL itself: a process group of one rank, the
+        # trainer in distributed mode, every bucket all-reduce really issued (PWG_FORCE_COLLECTIVES)
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ["PWG_FORCE_COLLECTIVES"] = "1"
+        dist.init_process_group(os.environ.get("PWG_DIST_BACKEND", "nccl"), rank=0, world_size=1)
 
     from parallelwavegan_amd import ops
     from parallelwavegan_amd.models import HiFiGANGenerator
@@ -577,7 +588,7 @@ def main():
             if train is not None:
                 train["cpu_baseline"] = cpu_train_baseline(load_conf("hifigan.v1"))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

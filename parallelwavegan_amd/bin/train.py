@@ -253,7 +253,11 @@ class Trainer(object):
                 while not done:
                     graph = torch.cuda.CUDAGraph()
                     exchange = None
-                    with torch.cuda.graph(graph, pool=pool):
+                    # data parallel: RCCL's watchdog thread polls events while we capture; only THIS thread's
+                    # calls are capture-restricted then (kernels launched by the autograd threads into the
+                    # capturing stream are recorded either way)
+                    mode = "thread_local" if self.reducers else "global"
+                    with torch.cuda.graph(graph, pool=pool, capture_error_mode=mode):
                         try:
                             exchange = next(step)
                         except StopIteration:

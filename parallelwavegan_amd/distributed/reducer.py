@@ -22,6 +22,8 @@ still being computed.
 Buckets are large (default 64 MiB): xGMI is a point-to-point mesh (7 links per GPU), so a
 collective is per-link bound and a few big messages beat many small ones.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -95,6 +97,9 @@ class GradReducer:
         self.enabled = True
         self.defer = False  # True: hooks only fill the buckets (hipGraph capture / replay); the caller exchanges
         self.skip_comm = False  # measurement aid: run the step without its collectives (bench: exposed time)
+        # test aid: issue the collectives even in a world of one (exercises RCCL init, its stream semantics and
+        # its interplay with hipGraph capture / replay on a single-GPU box)
+        self.force = bool(os.environ.get("PWG_FORCE_COLLECTIVES")) and dist.is_initialized()
         self._next = 0  # index of the next bucket to launch (collectives go out in bucket order)
         self.bytes = sum(b.flat.numel() * 4 for b in self.buckets)
 
@@ -147,7 +152,7 @@ class GradReducer:
             for ev in b.events:
                 cur.wait_event(ev)
             b.events = []
-        if self.world > 1 and not self.skip_comm:
+        if (self.world > 1 or self.force) and not self.skip_comm:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _launch_ready(self):

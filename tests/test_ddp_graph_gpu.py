@@ -64,3 +64,46 @@ def test_segmented_graph_ddp_matches_eager_ddp():
         for k in ("generator", "discriminator"):
             d = abs(res[(r, 0)]["sums"][k] - res[(r, 1)]["sums"][k])
             assert d <= 1e-6 * res[(r, 0)]["absd"][k], (r, k, d)
+
+
+def _rccl_worker(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+                      PWG_FORCE_COLLECTIVES="1")
+    import torch.distributed as dist
+
+    from tests.golden import synth
+    from tests.test_hifigan_train_gpu import build_trainer
+
+    dist.init_process_group("nccl", rank=0, world_size=1)  # "nccl" is RCCL on ROCm
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    c = synth.synth_input("c", (2, 80, 32), seed=100)
+    y = 0.5 * synth.synth_input("y", (2, 1, 8192), seed=100)
+    logs = {}
+    for distributed in (False, True):
+        tr, _, model, opt = build_trainer(dev, 41, 1.25, 2, N_STEPS, distributed=distributed, use_hip_graph=True,
+                                          graph_warmup_steps=2, rank=0)
+        tr.tqdm = None
+        for _ in range(N_STEPS):
+            tr._train_step(((c,), y))
+        tr._flush_pending()
+        torch.cuda.synchronize()
+        if distributed:
+            (entry,) = tr._graphs.values()
+            assert len(entry["segments"]) == 6  # G | D group 0..3 | D update: RCCL calls between the replays
+            assert all(r.force for r in tr.reducers.values())
+        logs[distributed] = dict(tr.total_train_loss)
+    torch.save(logs, os.path.join(out_dir, "rccl.pt"))
+    dist.destroy_process_group()
+
+
+def test_rccl_collectives_between_graph_segments_world_of_one():
+    """The data-parallel hipGraph step on RCCL itself (process group of ONE rank, every bucket all-reduce
+    really issued: PWG_FORCE_COLLECTIVES): communicator init, the watchdog thread next to a thread-local
+    stream capture, async all-reduces on RCCL's stream between graph replays.  A sum over one rank is the
+    identity, so the losses must follow the non-distributed trainer."""
+    out = tempfile.mkdtemp()
+    mp.spawn(_rccl_worker, args=(29640, out), nprocs=1, join=True)
+    logs = torch.load(os.path.join(out, "rccl.pt"))
+    for k, v in logs[False].items():
+        assert abs(v - logs[True][k]) <= 2e-4 * max(abs(v), 1e-3), (k, v, logs[True][k])
