@@ -179,6 +179,7 @@ def bench_train(args, tag, dev, rank, world, dist, steps, warmup, detail=True):
                 distributed=world > 1 or os.environ.get("PWG_FORCE_DIST") == "1", rank=rank,
                 outdir=tempfile.mkdtemp(), progress=False,
                 use_hip_graph=not args.no_graph, graph_warmup_steps=2,
+                ddp_grad_groups=int(os.environ.get("PWG_DDP_GROUPS", "3")),
                 reuse_real_discriminator_pass=os.environ.get("PWG_REUSE_REAL", "1") == "1")
     batch = synthetic_batch(conf, b, dev, rank)
 

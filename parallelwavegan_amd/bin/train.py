@@ -78,7 +78,7 @@ class Trainer(object):
                 # hipGraph mode replays the backward pass as one graph per exchange group, so that group
                 # k's all-reduce overlaps the replay of group k+1 (independent sub-discriminators)
                 groups = None
-                n_groups = int(config.get("ddp_grad_groups", 4))
+                n_groups = int(config.get("ddp_grad_groups", 3))
                 if config.get("use_hip_graph", False) and n_groups > 1 and hasattr(m, "grad_groups"):
                     groups = m.grad_groups(n_groups)
                 self.reducers[k] = GradReducer(list(m.parameters()), groups=groups,

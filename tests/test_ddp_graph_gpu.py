@@ -40,7 +40,7 @@ def _worker(rank, world, port, use_graph, out_dir):
         (entry,) = tr._graphs.values()
         # G backward | exchange | G update + D forward + D backward group 0 | exchange 0 | group 1 | ... | D update
         n_groups = len(tr.reducers["discriminator"].groups)
-        assert n_groups == 4
+        assert n_groups == 3
         assert [k for _, k in entry["segments"]] == (
             [("generator", None)] + [("discriminator", gi) for gi in range(n_groups)] + [None])
     sums = {k: float(sum(p.double().sum().item() for p in model[k].parameters())) for k in model}
@@ -90,7 +90,7 @@ def _rccl_worker(rank, port, out_dir):
         torch.cuda.synchronize()
         if distributed:
             (entry,) = tr._graphs.values()
-            assert len(entry["segments"]) == 6  # G | D group 0..3 | D update: RCCL calls between the replays
+            assert len(entry["segments"]) == 5  # G | D group 0..2 | D update: RCCL calls between the replays
             assert all(r.force for r in tr.reducers.values())
         logs[distributed] = dict(tr.total_train_loss)
     torch.save(logs, os.path.join(out_dir, "rccl.pt"))
