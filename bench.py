@@ -384,6 +384,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     n_dev = max(torch.cuda.device_count(), 1)
+    dev = torch.device("cuda", local_rank % n_dev)
+    torch.cuda.set_device(dev)  # before the process group exists: RCCL binds to the current device
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -402,8 +404,6 @@ def main():
             sys.stdout.flush()
             os.dup2(saved, 1)
             os.close(saved)
-    dev = torch.device("cuda", local_rank % n_dev)
-    torch.cuda.set_device(dev)
     force_dist = world == 1 and os.environ.get("PWG_FORCE_DIST") == "1"
     if force_dist:
         # single-GPU exercise of the data-parallel path on RCCL itself: a process group of one rank, the
