@@ -509,6 +509,14 @@ def main():
             "kernel_ms_note": "serial event timing of eager launches; the timed region replays a hipGraph whose "
                               "MRF branches overlap, so it can be ~1% shorter than this sum",
             "share_of_step_kernel_time": r["ms"] / sum(v["ms"] for v in prof.results.values()),
+            # every kernel family of the forward pass (algorithmic FLOPs: the one-launch residual units are
+            # credited with the two convolutions they replace, not with their recomputed halo)
+            "kernels": {k_: {"ms_per_step": v["ms"] / prof_steps, "launches_per_step": v["launches"] / prof_steps,
+                             "TFLOPs": v["flops"] / max(v["ms"], 1e-9) * 1e-9,
+                             "frac_of_peak": v["flops"] / max(v["ms"], 1e-9) * 1e-9 / FP32_MATRIX_PEAK_TFLOPS}
+                        for k_, v in sorted(prof.results.items(), key=lambda kv: -kv[1]["ms"])},
+            "all_kernels_frac_of_peak": sum(v["flops"] for v in prof.results.values())
+            / (sum(v["ms"] for v in prof.results.values()) * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
         }
 
     # single-utterance latency (bin/decode.py's regime: batch 1), same graph-replay path

@@ -175,6 +175,40 @@ int pwg_conv1d_forward_cfg(const pwg_conv1d_desc* d, const float* x, const float
                            const float* bias, const float* add1, const float* add2, float* y,
                            int32_t tile_config, int32_t use_dma, void* stream);
 
+/* ------------------------------------------------------------------------- */
+/* One HiFi-GAN MRF residual unit as ONE launch (inference; channels 32 / 64)  */
+/*                                                                            */
+/*   y = ( x + conv_{k,1}(lrelu(conv_{k,d}(lrelu(x)) + b1)) + b2 [+ add2] ) [/ out_div]      (has_conv2 = 1)
+ *   y = ( x + conv_{k,d}(lrelu(x)) + b1 [+ add2] ) [/ out_div]                                (has_conv2 = 0)
+ * replaces one iteration of the loop at layers/residual_block.py:253-257 (`xt = convs1[idx](x);
+ * xt = convs2[idx](xt); x = xt + x`), add2 / out_div additionally fold the MRF mean of
+ * models/hifigan.py:186-190.  All input channels of a column tile stay resident in LDS, the
+ * intermediate activation never reaches HBM (csrc/resunit.hip).  Both convolutions are
+ * "same"-padded with zeros (padding = (k-1)/2*dilation), k odd, t % 4 == 0, 0 < slope < 1;
+ * pwg_resunit_supported() tells whether a unit fits (otherwise use two pwg_conv1d_forward calls:
+ * identical result up to fp32 summation order).  Weights: torch layout (C, C, k) re-laid by
+ * pwg_resunit_pack_weight (`scale` = optional weight-norm row scale as in pwg_conv1d_pack_weight).
+ * x / y / add2: (batch, channels, t), 16-B aligned, y must not alias x.                            */
+typedef struct pwg_resunit_desc {
+  int32_t batch;
+  int32_t channels;
+  int32_t t;
+  int32_t kernel;
+  int32_t dilation;   /* of the first convolution; the second one has dilation 1 */
+  int32_t has_conv2;
+  float slope1;       /* LeakyReLU in front of the first convolution  */
+  float slope2;       /* LeakyReLU in front of the second convolution */
+  float out_div;      /* 1.0f = off */
+} pwg_resunit_desc;
+int pwg_resunit_supported(const pwg_resunit_desc* d);
+/* 1 when the one-launch unit is also the faster choice on MI355X (measured, see csrc/resunit.hip) */
+int pwg_resunit_profitable(const pwg_resunit_desc* d);
+size_t pwg_resunit_packed_weight_floats(int32_t channels, int32_t kernel);
+int pwg_resunit_pack_weight(int32_t channels, int32_t kernel, const float* w, const float* scale,
+                            float* w_packed, void* stream);
+int pwg_resunit_forward(const pwg_resunit_desc* d, const float* x, const float* w1_packed, const float* b1,
+                        const float* w2_packed, const float* b2, const float* add2, float* y, void* stream);
+
 /* Old-style torch.nn.utils.weight_norm (dim=0) scale: scale[i] = g[i]/||v[i,...]||_2
  * replaces torch._weight_norm at every conv call site.
  * v: (n0, inner) flattened, g: (n0).                                          */

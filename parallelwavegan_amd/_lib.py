@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libpwgkernels.so")
 
 PWG_ACT_NONE, PWG_ACT_LEAKY_RELU, PWG_ACT_TANH, PWG_ACT_RELU = 0, 1, 2, 3
 PWG_PAD_ZERO, PWG_PAD_REFLECT, PWG_PAD_REPLICATE = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class ConvDesc(ctypes.Structure):
@@ -36,6 +36,22 @@ class ConvDesc(ctypes.Structure):
         ("post_act", ctypes.c_int32),
         ("post_slope", ctypes.c_float),
         ("out_mul", ctypes.c_float),
+        ("out_div", ctypes.c_float),
+    ]
+
+
+class ResUnitDesc(ctypes.Structure):
+    """Mirror of ``pwg_resunit_desc`` (include/pwg_kernels.h)."""
+
+    _fields_ = [
+        ("batch", ctypes.c_int32),
+        ("channels", ctypes.c_int32),
+        ("t", ctypes.c_int32),
+        ("kernel", ctypes.c_int32),
+        ("dilation", ctypes.c_int32),
+        ("has_conv2", ctypes.c_int32),
+        ("slope1", ctypes.c_float),
+        ("slope2", ctypes.c_float),
         ("out_div", ctypes.c_float),
     ]
 
@@ -92,6 +108,11 @@ SIGNATURES = {
                                                      ctypes.c_size_t, _vp]),
     "pwg_conv1d_num_tile_configs": (ctypes.c_int, []),
     "pwg_conv1d_forward_cfg": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "pwg_resunit_supported": (ctypes.c_int, [ctypes.POINTER(ResUnitDesc)]),
+    "pwg_resunit_profitable": (ctypes.c_int, [ctypes.POINTER(ResUnitDesc)]),
+    "pwg_resunit_packed_weight_floats": (ctypes.c_size_t, [_i32, _i32]),
+    "pwg_resunit_pack_weight": (ctypes.c_int, [_i32, _i32, _vp, _vp, _vp, _vp]),
+    "pwg_resunit_forward": (ctypes.c_int, [ctypes.POINTER(ResUnitDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pwg_act_backward": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _f32, _vp]),
     "pwg_add3_div": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _vp]),
     "pwg_wave_to_pcm16": (ctypes.c_int, [_vp, _vp, _i64, _vp]),

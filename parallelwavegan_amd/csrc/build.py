@@ -15,7 +15,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # the MFMA kernels never produce or consume NaNs on purpose; without IEEE-mode sNaN quieting the
 # in-loop LeakyReLU is v_mul + v_max instead of three instructions (see csrc/conv1d.hip, ACT == 1)
 EXTRA = {"conv1d.hip": ["-fno-honor-nans", "-mno-amdgpu-ieee"],
-         "conv1d_wgrad.hip": ["-fno-honor-nans", "-mno-amdgpu-ieee"]}
+         "conv1d_wgrad.hip": ["-fno-honor-nans", "-mno-amdgpu-ieee"],
+         "resunit.hip": ["-fno-honor-nans", "-mno-amdgpu-ieee"]}
 
 
 def sources():

@@ -86,10 +86,17 @@ class PreparedWeights:
     keeps one instance per parameter epoch, so every forward / backward of that epoch -- e.g. D(y) and
     D(G(c)) of a discriminator phase -- shares a single scale + pack + pack launch sequence."""
 
-    __slots__ = ("key", "w", "scale", "fwd", "_bwd")
+    __slots__ = ("key", "w", "scale", "fwd", "_bwd", "_res")
 
     def __init__(self, key, w, scale, fwd):
-        self.key, self.w, self.scale, self.fwd, self._bwd = key, w, scale, fwd, None
+        self.key, self.w, self.scale, self.fwd, self._bwd, self._res = key, w, scale, fwd, None, None
+
+    def res(self):
+        """MFMA A-operand image for the one-launch residual unit (csrc/resunit.hip), built on first use."""
+        if self._res is None:
+            with torch.no_grad():
+                self._res = ops.resunit_pack_weight(self.w, self.scale)
+        return self._res
 
     def bwd(self, desc):
         if self._bwd is None:

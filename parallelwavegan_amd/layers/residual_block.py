@@ -4,6 +4,7 @@ import math
 import torch
 
 from .. import functional as Fn
+from .. import ops
 from .activation import FusedActivation
 from .conv import Conv1d as _Conv1d
 
@@ -103,6 +104,36 @@ class HiFiGANResidualBlock(torch.nn.Module):
                 self.convs2.append(torch.nn.Sequential(
                     FusedActivation(nonlinear_activation, **nonlinear_activation_params), conv(1)))
 
+    fuse_units = True  # inference: one launch per unit where csrc/resunit.hip covers the geometry (C = 32 / 64)
+
+    def _unit_one_launch(self, idx, x, accum, out_div):
+        """``(x + convs2[idx](convs1[idx](x)) [+ accum]) [/ out_div]`` as ONE kernel launch, or None when the
+        unit has to run as separate convolutions (training: the intermediate is needed by the backward pass;
+        causal / wide layers: no resident-tile kernel)."""
+        act1, conv1 = self.convs1[idx][0], self.convs1[idx][1]
+        if (not self.fuse_units or self.use_causal_conv or act1.kind != "leaky_relu" or x.dim() != 3
+                or not x.is_cuda or conv1._needs_grad(x, accum)):
+            return None
+        slope2, conv2 = act1.slope, None
+        if self.use_additional_convs:
+            act2, conv2 = self.convs2[idx][0], self.convs2[idx][1]
+            if act2.kind != "leaky_relu" or conv2._needs_grad(x) or conv2.has_spectral_norm:
+                return None
+            slope2 = act2.slope
+        if conv1.has_spectral_norm or conv1.pad_mode != "zero":
+            return None
+        desc = ops.make_resunit_desc(x.shape[0], x.shape[1], x.shape[2], self.kernel_size, conv1.dilation,
+                                     conv2 is not None, act1.slope, slope2, out_div)
+        if not ops.resunit_profitable(desc):
+            return None
+        with torch.no_grad():
+            x = x.contiguous()
+            return ops.resunit_forward(
+                desc, x, conv1.prepared().res(), None if conv1.bias is None else conv1.bias.detach(),
+                None if conv2 is None else conv2.prepared().res(),
+                None if (conv2 is None or conv2.bias is None) else conv2.bias.detach(),
+                None if accum is None else accum.contiguous())
+
     def forward(self, x, accum=None, out_div=1.0):
         """Returns ``(block(x) + accum) / out_div``; accum/out_div let the caller fold the
         MRF sum ``cs += block(c); c = cs / num_blocks`` (models/hifigan.py:186-190 in the
@@ -111,6 +142,10 @@ class HiFiGANResidualBlock(torch.nn.Module):
         for idx in range(n):
             last = idx == n - 1
             act1, conv1 = self.convs1[idx][0], self.convs1[idx][1]
+            y = self._unit_one_launch(idx, x, accum if last else None, out_div if last else 1.0)
+            if y is not None:
+                x = y
+                continue
             if self.use_additional_convs:
                 xt = conv1(x, pre_act=act1.kind, pre_slope=act1.slope)
                 act2, conv2 = self.convs2[idx][0], self.convs2[idx][1]

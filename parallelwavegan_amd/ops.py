@@ -7,7 +7,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ConvDesc
+from ._lib import ConvDesc, ResUnitDesc
 
 ACT = {None: _lib.PWG_ACT_NONE, "none": _lib.PWG_ACT_NONE, "leaky_relu": _lib.PWG_ACT_LEAKY_RELU,
        "tanh": _lib.PWG_ACT_TANH, "relu": _lib.PWG_ACT_RELU}
@@ -106,6 +106,43 @@ def conv1d_forward(desc, x, w_packed, bias=None, add1=None, add2=None, out=None)
     ws, ws_n = _workspace(_lib.lib().pwg_conv1d_forward_workspace_floats(ctypes.byref(desc)), x.device)
     _lib.check(_lib.lib().pwg_conv1d_forward(ctypes.byref(desc), _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(add1),
                                              _ptr(add2), _ptr(out), _ptr(ws), ws_n, _stream()), "conv1d_forward")
+    return out
+
+
+def make_resunit_desc(batch, channels, t, kernel, dilation, has_conv2=True, slope1=0.1, slope2=0.1, out_div=1.0):
+    return ResUnitDesc(int(batch), int(channels), int(t), int(kernel), int(dilation), int(bool(has_conv2)),
+                       float(slope1), float(slope2), float(out_div))
+
+
+def resunit_supported(desc):
+    """Does the one-launch residual unit (csrc/resunit.hip) cover this geometry?"""
+    return bool(_lib.lib().pwg_resunit_supported(ctypes.byref(desc)))
+
+
+def resunit_profitable(desc):
+    """Supported AND measured faster than the separate convolutions (heuristic lives with the kernel)."""
+    return bool(_lib.lib().pwg_resunit_profitable(ctypes.byref(desc)))
+
+
+def resunit_pack_weight(w, scale=None):
+    """torch-layout (C, C, k) weight (+ optional weight-norm row scale) -> MFMA A-operand image."""
+    _require_device(w, scale)
+    c, k = w.shape[0], w.shape[2]
+    assert w.shape[1] == c
+    out = torch.empty(_lib.lib().pwg_resunit_packed_weight_floats(c, k), device=w.device, dtype=torch.float32)
+    _lib.check(_lib.lib().pwg_resunit_pack_weight(c, k, _ptr(w), _ptr(scale), _ptr(out), _stream()),
+               "resunit_pack_weight")
+    return out
+
+
+def resunit_forward(desc, x, w1_packed, b1, w2_packed=None, b2=None, add2=None, out=None):
+    """One MRF residual unit: ``(x + conv2(lrelu(conv1(lrelu(x)) + b1)) + b2 [+ add2]) [/ out_div]``."""
+    _require_device(x, w1_packed, b1, w2_packed, b2, add2, out)
+    assert x.numel() == desc.batch * desc.channels * desc.t
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(_lib.lib().pwg_resunit_forward(ctypes.byref(desc), _ptr(x), _ptr(w1_packed), _ptr(b1), _ptr(w2_packed),
+                                              _ptr(b2), _ptr(add2), _ptr(out), _stream()), "resunit_forward")
     return out
 
 
