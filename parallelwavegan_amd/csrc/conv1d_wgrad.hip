@@ -14,6 +14,8 @@
 // deterministic, no atomics.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace pwg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -36,6 +38,8 @@ struct WgArgs {
   long slab_stride; // floats between consecutive slabs (dW + fused bias row)
   float slope_g, slope_x;  // branch-free pre-activation slopes (1 = none)
   unsigned g_bytes, x_bytes;
+  int tap_major;  // slab layout: 1 = [tap][o][i] (coalesced partial-sum stores, the finishers permute), 0 = torch (o, i, tap)
+  int dbg;  // timing experiments only (PWG_WG_DBG env): 1 = no DMA after the first chunk, 2 = no waits / barriers, 4 = no stores
 };
 
 // TT = reduction columns per chunk (32 / 64 / 128): long sequences under a narrow tile want long
@@ -262,11 +266,12 @@ __global__ __launch_bounds__(256, (TG > 7 ? 1 : 2)) void conv1d_wgrad_kernel(WgA
     };
     auto mma = [&](float av, float(&bv)[TG]) {
       bsum += av;  // fused bias gradient: row sums of G (only used where G is the raw output gradient)
-      if (ACT) av = __builtin_fmaf(a.slope_g, __builtin_fminf(av, 0.f), __builtin_fmaxf(av, 0.f));
+      // pre-activation with 0 <= slope <= 1 (1 = identity, 0 = ReLU): max(v, slope * v), 2 VALU ops
+      if (ACT) av = __builtin_fmaxf(av, av * a.slope_g);
 #pragma unroll
       for (int t = 0; t < TG; ++t) {
         float v = bv[t];
-        if (ACT) v = __builtin_fmaf(a.slope_x, __builtin_fminf(v, 0.f), __builtin_fmaxf(v, 0.f));
+        if (ACT) v = __builtin_fmaxf(v, v * a.slope_x);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, v, acc[t], 0, 0, 0);
       }
     };
@@ -299,11 +304,13 @@ __global__ __launch_bounds__(256, (TG > 7 ? 1 : 2)) void conv1d_wgrad_kernel(WgA
   };
   if (c_begin < c_end) issue(nb_b, nb_n0, smem);
   for (int c = c_begin; c < c_end; ++c) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (!(a.dbg & 2)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
     const int par = (c - c_begin) & 1;
     float* buf = smem + par * buf_floats;
-    if (c + 1 < c_end) {
+    if (c + 1 < c_end && !(a.dbg & 1)) {
       advance(nb_b, nb_n0);
       issue(nb_b, nb_n0, smem + (par ^ 1) * buf_floats);
     }
@@ -332,14 +339,21 @@ __global__ __launch_bounds__(256, (TG > 7 ? 1 : 2)) void conv1d_wgrad_kernel(WgA
       a.db[(long)blockIdx.x * a.slab_stride + grp * a.co_g + o] = rs;
   }
   const int i = i0 + wave_i * 32 + l31;
-  if (i < a.ci_g) {
+  if (i < a.ci_g && !(a.dbg & 4)) {
 #pragma unroll
     for (int t = 0; t < TG; ++t) {
       if (t < ntaps) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int o = o0 + wave_o * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          if (o < a.co_g) slab[(((long)(grp * a.co_g + o)) * a.ci_g + i) * a.k + k0 + t0 + t] = acc[t][r];
+          if (o < a.co_g) {
+            // tap-major slabs: the 32 lanes of a half-wave (consecutive i) write one 128-B segment; in torch
+            // layout they are k floats apart, every store instruction touching 64 different sectors (the
+            // slab stores were 30-40 % of the kernel time on the C3 shapes, profiles/r02_wgrad_ablation.txt)
+            const long e = a.tap_major ? ((long)(k0 + t0 + t) * co_tot + grp * a.co_g + o) * a.ci_g + i
+                                       : (((long)(grp * a.co_g + o)) * a.ci_g + i) * a.k + k0 + t0 + t;
+            slab[e] = acc[t][r];
+          }
         }
       }
     }
@@ -350,19 +364,27 @@ __global__ __launch_bounds__(256, (TG > 7 ? 1 : 2)) void conv1d_wgrad_kernel(WgA
 // into hundreds of reduction slices): 32 elements x 8 slab lanes per workgroup, every lane sums its
 // slabs (stride 8) in a fixed order, then the 8 partials are added in a fixed order (deterministic).
 // Elements [0, dw_elems) of a slab go to dw, the rest (fused bias row) to db.
+// Slabs are tap-major ([tap][o][i], `plane` = rows * ci_g elements per tap): element e of a slab goes to
+// dw[(e % plane) * k + e / plane] (torch layout (o, i, tap)) -- read coalesced nslabs times, scattered once.
+__device__ __forceinline__ long slab_to_torch(long e, long plane, int k) {
+  const long tap = e / plane;
+  return (e - tap * plane) * k + tap;
+}
+
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ dw, float* __restrict__ db,
-                                    long dw_elems, long elems, int nslabs) {
+                                    long dw_elems, long elems, int nslabs, long plane, int k) {
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < elems; e += (long)gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int j = 0; j < nslabs; ++j) s += slabs[(long)j * elems + e];
-    if (e < dw_elems) dw[e] = s;
+    if (e < dw_elems) dw[slab_to_torch(e, plane, k)] = s;
     else db[e - dw_elems] = s;
   }
 }
 
 __global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* __restrict__ slabs,
                                                                 float* __restrict__ dw, float* __restrict__ db,
-                                                                long dw_elems, long elems, int nslabs) {
+                                                                long dw_elems, long elems, int nslabs, long plane,
+                                                                int k) {
   __shared__ float part[8][32];
   const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const long e = (long)blockIdx.x * 32 + el;
@@ -383,7 +405,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* __r
     float s = part[0][el];
 #pragma unroll
     for (int q = 1; q < 8; ++q) s += part[q][el];
-    if (e < dw_elems) dw[e] = s;
+    if (e < dw_elems) dw[slab_to_torch(e, plane, k)] = s;
     else db[e - dw_elems] = s;
   }
 }
@@ -425,7 +447,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_wn_kernel(const float* __res
                                                               int nslabs, long slab_elems, const float* __restrict__ v,
                                                               const float* __restrict__ g, float* __restrict__ dv,
                                                               float* __restrict__ dg, float* __restrict__ db, int n0,
-                                                              int inner, int nbias) {
+                                                              int inner, int nbias, int ci_g, int k) {
   // WIDE = false (few slabs): row[inner]; one thread per element adds the slabs in order.
   // WIDE = true (many slabs, short rows): part[8][inner] + 8 slab lanes per element, then the 8 partials in order.
   extern __shared__ float row[];
@@ -439,19 +461,24 @@ __global__ __launch_bounds__(256) void reduce_slabs_wn_kernel(const float* __res
     }
     return;
   }
+  // row o of dW: k segments of ci_g consecutive floats in a tap-major slab (segment `tap` starts at
+  // (tap * n0 + o) * ci_g); gathered in slab order (coalesced) into row[] in torch order (i * k + tap)
   const long base = (long)blockIdx.x * inner;
+  const long seg0 = (long)blockIdx.x * ci_g, seg_step = (long)n0 * ci_g;
   if (WIDE) {
     const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    float* part = row + inner;  // [8][inner]
+    float* part = row + inner;  // [8][inner], slab order
     for (int e = el; e < inner; e += 32) {
+      const int tap = e / ci_g, i = e - tap * ci_g;
+      const long src = seg0 + tap * seg_step + i;
       float s = 0.f;
-      for (int j = sl; j < nslabs; j += 8) s += slabs[(long)j * slab_stride + base + e];
+      for (int j = sl; j < nslabs; j += 8) s += slabs[(long)j * slab_stride + src];
       part[sl * inner + e] = s;
     }
     __syncthreads();
   }
-  float svv = 0.f, sdv = 0.f;
   for (int e = threadIdx.x; e < inner; e += 256) {
+    const int tap = e / ci_g, i = e - tap * ci_g;
     float t;
     if (WIDE) {
       const float* part = row + inner;
@@ -459,13 +486,18 @@ __global__ __launch_bounds__(256) void reduce_slabs_wn_kernel(const float* __res
 #pragma unroll
       for (int q = 1; q < 8; ++q) t += part[q * inner + e];
     } else {
+      const long src = seg0 + tap * seg_step + i;
       t = 0.f;
-      for (int j = 0; j < nslabs; ++j) t += slabs[(long)j * slab_stride + base + e];
+      for (int j = 0; j < nslabs; ++j) t += slabs[(long)j * slab_stride + src];
     }
-    row[e] = t;
+    row[i * k + tap] = t;
+  }
+  __syncthreads();
+  float svv = 0.f, sdv = 0.f;
+  for (int e = threadIdx.x; e < inner; e += 256) {
     const float a = v[base + e];
     svv += a * a;
-    sdv += a * t;
+    sdv += a * row[e];
   }
   for (int o = 32; o > 0; o >>= 1) {
     svv += __shfl_down(svv, o, 64);
@@ -607,9 +639,11 @@ static int launch_wgrad_mode(WgArgs a, const WgPlan& p, float* dw_out, float* wo
   float* db_out = a.db;  // non-null: the bias gradient rides along (row sums of the G tiles)
   a.slab_stride = a.slab_elems + (db_out ? (long)a.co_g * a.groups : 0);
   const WnFinish* wn = g_wn_finish;
+  a.tap_major = 0;
   if (p.splits == 1 && wn == nullptr) {
-    a.dw = dw_out;  // single slice: write the gradients directly
+    a.dw = dw_out;  // single slice: write the gradients directly (torch layout)
   } else {
+    a.tap_major = 1;
     PWG_REQUIRE(workspace && ws_floats >= (size_t)p.splits * a.slab_stride, PWG_ERR_WORKSPACE,
                 "conv1d_backward_weight: workspace of %zu floats needed, %zu given",
                 (size_t)p.splits * a.slab_stride, ws_floats);
@@ -630,13 +664,14 @@ static int launch_wgrad_mode(WgArgs a, const WgPlan& p, float* dw_out, float* wo
   // fused finisher: one workgroup per weight row, so it needs many rows or few slabs to fill the chip; layers
   // with few rows cut into many slabs (C <= 128 generator stages) keep the wide slab reduction (one workgroup
   // per 32 elements) followed by the row-wise weight-norm backward, into a spare slab of the workspace
+  const long plane = (long)a.co_g * a.groups * a.ci_g;  // elements per tap of a tap-major slab
   const bool wn_fused = wn != nullptr && (p.splits < 16 || a.co_g * a.groups >= 512);
   if (wn != nullptr && !wn_fused) {
     float* dw_tmp = workspace + (size_t)p.splits * a.slab_stride;
     {
       ProfScope prof(stream, "reduce_slabs_kernel", 0, 4.0 * a.slab_stride * (p.splits + 1));
       hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)((a.slab_stride + 31) / 32)), dim3(256), 0, stream,
-                         workspace, dw_tmp, db_out, a.slab_elems, a.slab_stride, p.splits);
+                         workspace, dw_tmp, db_out, a.slab_elems, a.slab_stride, p.splits, plane, a.k);
       PWG_CHECK_LAUNCH("reduce_slabs");
     }
     return pwg_weight_norm_backward(dw_tmp, wn->v, wn->g, wn->dv, wn->dg, a.co_g * a.groups, a.ci_g * a.k, stream);
@@ -649,11 +684,11 @@ static int launch_wgrad_mode(WgArgs a, const WgPlan& p, float* dw_out, float* wo
     if (wide)
       hipLaunchKernelGGL(reduce_slabs_wn_kernel<true>, dim3(n0 + ceil_div(nbias, 256)), dim3(256),
                          (size_t)9 * inner * sizeof(float), stream, (const float*)workspace, a.slab_stride, p.splits,
-                         a.slab_elems, wn->v, wn->g, wn->dv, wn->dg, db_out, n0, inner, nbias);
+                         a.slab_elems, wn->v, wn->g, wn->dv, wn->dg, db_out, n0, inner, nbias, a.ci_g, a.k);
     else
       hipLaunchKernelGGL(reduce_slabs_wn_kernel<false>, dim3(n0 + ceil_div(nbias, 256)), dim3(256),
                          (size_t)inner * sizeof(float), stream, (const float*)workspace, a.slab_stride, p.splits,
-                         a.slab_elems, wn->v, wn->g, wn->dv, wn->dg, db_out, n0, inner, nbias);
+                         a.slab_elems, wn->v, wn->g, wn->dv, wn->dg, db_out, n0, inner, nbias, a.ci_g, a.k);
     PWG_CHECK_LAUNCH("reduce_slabs_wn");
     return PWG_OK;
   }
@@ -661,12 +696,12 @@ static int launch_wgrad_mode(WgArgs a, const WgPlan& p, float* dw_out, float* wo
     ProfScope prof(stream, "reduce_slabs_kernel", 0, 4.0 * a.slab_stride * (p.splits + 1));
     if (p.splits >= 16) {
       hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)((a.slab_stride + 31) / 32)), dim3(256), 0, stream,
-                         workspace, dw_out, db_out, a.slab_elems, a.slab_stride, p.splits);
+                         workspace, dw_out, db_out, a.slab_elems, a.slab_stride, p.splits, plane, a.k);
     } else {
       long blocks = (a.slab_stride + 255) / 256;
       if (blocks > 2048) blocks = 2048;
       hipLaunchKernelGGL(reduce_slabs_kernel, dim3((int)blocks), dim3(256), 0, stream, workspace, dw_out, db_out,
-                         a.slab_elems, a.slab_stride, p.splits);
+                         a.slab_elems, a.slab_stride, p.splits, plane, a.k);
     }
     PWG_CHECK_LAUNCH("reduce_slabs");
   }
@@ -676,7 +711,7 @@ static int launch_wgrad_mode(WgArgs a, const WgPlan& p, float* dw_out, float* wo
 template <int TG, bool SMALL, int TT>
 static int launch_wgrad(WgArgs a, const WgPlan& p, float* dw_out, float* workspace, size_t ws_floats,
                         hipStream_t stream, double flops, double bytes) {
-  const bool act = a.slope_g != 1.f || a.slope_x != 1.f;
+  const bool act = (a.slope_g != 1.f || a.slope_x != 1.f) && !(a.dbg & 8);
 #define WG_GO(WINV, MODEV) \
   return launch_wgrad_mode<TG, SMALL, TT, WINV, MODEV>(a, p, dw_out, workspace, ws_floats, stream, flops, bytes)
   if (a.width != 1) WG_GO(false, 2);  // per-tap windows need width == 1 and stride == 1 (wgrad_plan)
@@ -747,6 +782,9 @@ extern "C" int pwg_conv1d_backward_weight(const pwg_conv1d_desc* d_in, const flo
   if (!dw) return PWG_OK;
   WgArgs a;
   const float slope = d->pre_act == PWG_ACT_LEAKY_RELU ? d->pre_slope : (d->pre_act == PWG_ACT_RELU ? 0.f : 1.f);
+  PWG_REQUIRE(slope >= 0.f && slope <= 1.f, PWG_ERR_UNSUPPORTED,
+              "conv1d_backward_weight: LeakyReLU slope %g outside [0, 1] (the operand activation is max(v, slope*v))",
+              (double)slope);
   if (!d->transposed) {
     a.g = dy;
     a.x = x;
@@ -772,6 +810,8 @@ extern "C" int pwg_conv1d_backward_weight(const pwg_conv1d_desc* d_in, const flo
     a.g_bytes = (unsigned)(x_elems * 4);
     a.x_bytes = (unsigned)(y_elems * 4);
   }
+  static const int dbg = getenv("PWG_WG_DBG") ? atoi(getenv("PWG_WG_DBG")) : 0;
+  a.dbg = dbg;
   a.dw = nullptr;
   a.db = fuse_bias ? db : nullptr;
   a.groups = d->groups;
