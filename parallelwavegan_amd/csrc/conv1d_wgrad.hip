@@ -542,7 +542,13 @@ static size_t wgrad_lds(bool small, bool win, int taps_block, int tt, int stride
 static WgPlan wgrad_plan(int co_g, int ci_g, int groups, int k, int stride, int dil, int width, int n_cols,
                          int batch) {
   WgPlan p;
-  p.small = co_g <= 32 || ci_g <= 32;
+  // tuning overrides (tools/bench_wgrad.py sweeps): PWG_WG_SMALL=1 forces the 32x32 tile, PWG_WG_TG the taps per
+  // wave of the 64x64 tile, PWG_WG_TT caps the chunk length, PWG_WG_RES the resident workgroups per CU
+  static const int env_small = getenv("PWG_WG_SMALL") ? atoi(getenv("PWG_WG_SMALL")) : 0;
+  static const int env_tg = getenv("PWG_WG_TG") ? atoi(getenv("PWG_WG_TG")) : 0;
+  static const int env_tt = getenv("PWG_WG_TT") ? atoi(getenv("PWG_WG_TT")) : 0;
+  static const int env_res = getenv("PWG_WG_RES") ? atoi(getenv("PWG_WG_RES")) : 0;
+  p.small = co_g <= 32 || ci_g <= 32 || env_small;
   if (p.small) {
     const int per_wave = ceil_div(k, 4);
     // at most 4 accumulators per wave: with 6 or 11 (k = 41: all taps in one workgroup) the kernel drops
@@ -569,6 +575,7 @@ static WgPlan wgrad_plan(int co_g, int ci_g, int groups, int k, int stride, int 
         p.tg = tg;
       }
     }
+    if (env_tg > 0) p.tg = env_tg < 7 ? env_tg : 7;
     p.taps_block = p.tg;
   }
   const int bt = p.small ? 32 : 64;
@@ -583,6 +590,7 @@ static WgPlan wgrad_plan(int co_g, int ci_g, int groups, int k, int stride, int 
     for (int tt = p.small ? 128 : 32; tt >= 32; tt >>= 1) {
       int xs;
       if (tt > 32 && tt > n_cols) continue;
+      if (env_tt > 0 && tt > env_tt && tt > 32) continue;
       if (wgrad_lds(p.small, p.win, p.taps_block, tt, stride, dil, width, k, &xs) <= 80 * 1024) {
         p.tt = tt;
         break;
@@ -610,7 +618,7 @@ static WgPlan wgrad_plan(int co_g, int ci_g, int groups, int k, int stride, int 
   p.tiles = ceil_div(co_g, bt) * ceil_div(ci_g, bt) * groups;
   // one wave of resident workgroups (register-limited: 2 per CU with 6-7 accumulators, else 3), all
   // with the same amount of work; at least 256 columns of reduction per workgroup
-  const int resident = 256 * ((!p.small && p.tg >= 6) ? 2 : 3);
+  const int resident = 256 * (env_res > 0 ? env_res : ((!p.small && p.tg >= 6) ? 2 : 3));
   int splits = resident / (p.tiles * p.tap_groups);
   const int min_chunks = 256 / p.tt > 1 ? 256 / p.tt : 1;
   if (splits > p.chunks_total / min_chunks) splits = p.chunks_total / min_chunks;

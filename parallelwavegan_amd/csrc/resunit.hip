@@ -25,6 +25,7 @@
 #include "common.h"
 
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace pwg {
 
@@ -48,6 +49,8 @@ struct ResUnitArgs {
   int p2;      // (k-1)/2 in pair mode, 0 otherwise
   int xw4;     // 16-B pieces staged per x row
   float slope1, slope2, out_div;
+  int dbg;      // timing experiments (PWG_RU_DBG): 1 = no LeakyReLU on the B operands, 2 = weights loaded once (no per-tap A loads),
+                // 4 = no x-tile DMA, 8 = no global stores
 };
 
 template <int C>
@@ -64,7 +67,7 @@ struct ResUnitCfg {
 // bl: LDS lane base (row lhi, first column of the wave); RS: LDS row stride; tap_step: columns per tap.
 template <int C, int RS, bool ACT>
 __device__ __forceinline__ void resunit_contract(const float* __restrict__ wl, const float* bl, int tap_step, int k,
-                                                 float slope, f32x16 (&acc)[2]) {
+                                                 float slope, f32x16 (&acc)[2], bool reload_a = true) {
   using Cfg = ResUnitCfg<C>;
   constexpr int CP = Cfg::CP;
   constexpr int G = 8;        // channel pairs per operand group (LDS reads of group g+1 fly under group g's MFMAs)
@@ -117,10 +120,10 @@ __device__ __forceinline__ void resunit_contract(const float* __restrict__ wl, c
   load_b(B0, 0, 0);
   int tap = 0;
   for (; tap + 2 <= k; tap += 2) {
-    load_a(A1, tap + 1);
+    if (reload_a || tap == 0) load_a(A1, tap + 1);
     __builtin_amdgcn_sched_barrier(0);
     tap_body(A0, tap);
-    load_a(A0, tap + 2 < k ? tap + 2 : k - 1);
+    if (reload_a) load_a(A0, tap + 2 < k ? tap + 2 : k - 1);
     __builtin_amdgcn_sched_barrier(0);
     tap_body(A1, tap + 1);
   }
@@ -152,7 +155,8 @@ __global__ __launch_bounds__(256, 2) void resunit_kernel(ResUnitArgs a) {
   const float* xb = a.x + (long)b * C * T;
   __amdgpu_buffer_rsrc_t x_rs = uniform_buffer_rsrc(xb, (unsigned)(C * T) * 4u);
   const int XW = a.xw4 * 4;
-  if (__builtin_amdgcn_readfirstlane((f0 >= 0 && f0 + XW <= T) ? 1 : 0)) {
+  if (a.dbg & 4) {
+  } else if (__builtin_amdgcn_readfirstlane((f0 >= 0 && f0 + XW <= T) ? 1 : 0)) {
     for (int r = wave; r < C; r += 4)
       for (int l0 = 0; l0 < a.xw4; l0 += 64)
         if (l0 + lane < a.xw4) {
@@ -198,7 +202,10 @@ __global__ __launch_bounds__(256, 2) void resunit_kernel(ResUnitArgs a) {
   // ---- phase 1: conv_{k,d} over lrelu(x); h column m (output slot m in single mode) reads x-tile
   // column m + tap*d + sh
   const float* w1l = a.w1 + (long)wave_m * (CP * 64) + lane;
-  resunit_contract<C, XS, true>(w1l, xs + lhi * XS + wave_n * 64 + l31 + a.sh, a.d1, a.k, a.slope1, acc);
+  if (a.dbg & 1)
+    resunit_contract<C, XS, false>(w1l, xs + lhi * XS + wave_n * 64 + l31 + a.sh, a.d1, a.k, a.slope1, acc, !(a.dbg & 2));
+  else
+    resunit_contract<C, XS, true>(w1l, xs + lhi * XS + wave_n * 64 + l31 + a.sh, a.d1, a.k, a.slope1, acc, !(a.dbg & 2));
 
   if (pair) {
     // h = lrelu(acc + b1) (conv2's pre-activation applied at production), 0 outside [0, T)
@@ -219,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void resunit_kernel(ResUnitArgs a) {
     __syncthreads();
     // ---- phase 2: conv_{k,1} over h; output slot n reads h column n + tap
     const float* w2l = a.w2 + (long)wave_m * (CP * 64) + lane;
-    resunit_contract<C, HS, false>(w2l, hs + lhi * HS + wave_n * 64 + l31, 1, a.k, 1.f, acc);
+    resunit_contract<C, HS, false>(w2l, hs + lhi * HS + wave_n * 64 + l31, 1, a.k, 1.f, acc, !(a.dbg & 2));
   } else {
     __syncthreads();  // the other waves may still be reading x columns this wave is about to overwrite
   }
@@ -245,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void resunit_kernel(ResUnitArgs a) {
     const long row = ((long)b * C + c) * T;
     for (int q = lane; q < nv; q += 64) {
       const int t = t0 + 4 * q;
-      if (t >= T) continue;
+      if (t >= T || (a.dbg & 8)) continue;
       float4 v = *reinterpret_cast<const float4*>(xs + c * XS + a.hla + 4 * q);
       if (a.add2) {
         const float4 u = *reinterpret_cast<const float4*>(a.add2 + row + t);
@@ -362,6 +369,8 @@ int pwg_resunit_forward(const pwg_resunit_desc* d, const float* x, const float* 
   a.T = d->t; a.k = d->kernel; a.d1 = d->dilation;
   a.bn_out = g.bn_out; a.hla = g.hla; a.sh = g.sh; a.p2 = g.p2; a.xw4 = g.xw4;
   a.slope1 = d->slope1; a.slope2 = d->slope2; a.out_div = d->out_div;
+  static const int dbg = getenv("PWG_RU_DBG") ? atoi(getenv("PWG_RU_DBG")) : 0;
+  a.dbg = dbg;
   void (*kern)(ResUnitArgs) = d->channels == 32 ? resunit_kernel<32> : resunit_kernel<64>;
   if (g.lds > 64 * 1024 && !lds_limit_is_set(reinterpret_cast<const void*>(kern), g.lds)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
