@@ -34,7 +34,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 struct ResUnitArgs {
   const float* x;
-  const float* w1;  // packed [tap][C/32][C/2][64]
+  const float* w1;  // packed [tap][C/32][C/8][64 lanes][4]
   const float* b1;
   const float* w2;  // nullptr: single convolution
   const float* b2;
@@ -74,10 +74,18 @@ __device__ __forceinline__ void resunit_contract(const float* __restrict__ wl, c
   constexpr int NG = CP / G;  // 2 or 4 (even: the B ping-pong phase is the same at every tap start)
   constexpr int TAP_W = Cfg::MB * CP * 64;  // floats per tap of the packed image
   float A0[CP], A1[CP], B0[G][2], B1[G][2];
+  // one global_load_dwordx4 per 4 channel pairs (image [tap][row block][cp/4][lane][4]): with a dword per channel
+  // pair the loop ran at 118 TFLOP/s beside 2 workgroups per CU, with 16-B loads at 144 (tools/probes/mfma_loop.hip)
   auto load_a = [&](float(&A)[CP], int tap) {
-    const float* p = wl + (long)tap * TAP_W;
+    const float4* p4 = reinterpret_cast<const float4*>(wl + (long)tap * TAP_W);
 #pragma unroll
-    for (int cp = 0; cp < CP; ++cp) A[cp] = p[cp * 64];
+    for (int q = 0; q < CP / 4; ++q) {
+      const float4 v = p4[q * 64];
+      A[4 * q] = v.x;
+      A[4 * q + 1] = v.y;
+      A[4 * q + 2] = v.z;
+      A[4 * q + 3] = v.w;
+    }
   };
   auto load_b = [&](float(&B)[G][2], int tap, int g) {
     const float* p = bl + tap * tap_step;
@@ -201,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void resunit_kernel(ResUnitArgs a) {
 
   // ---- phase 1: conv_{k,d} over lrelu(x); h column m (output slot m in single mode) reads x-tile
   // column m + tap*d + sh
-  const float* w1l = a.w1 + (long)wave_m * (CP * 64) + lane;
+  const float* w1l = a.w1 + (long)wave_m * (CP * 64) + lane * 4;
   if (a.dbg & 1)
     resunit_contract<C, XS, false>(w1l, xs + lhi * XS + wave_n * 64 + l31 + a.sh, a.d1, a.k, a.slope1, acc, !(a.dbg & 2));
   else
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void resunit_kernel(ResUnitArgs a) {
     }
     __syncthreads();
     // ---- phase 2: conv_{k,1} over h; output slot n reads h column n + tap
-    const float* w2l = a.w2 + (long)wave_m * (CP * 64) + lane;
+    const float* w2l = a.w2 + (long)wave_m * (CP * 64) + lane * 4;
     resunit_contract<C, HS, false>(w2l, hs + lhi * HS + wave_n * 64 + l31, 1, a.k, 1.f, acc, !(a.dbg & 2));
   } else {
     __syncthreads();  // the other waves may still be reading x columns this wave is about to overwrite
@@ -266,17 +274,19 @@ __global__ __launch_bounds__(256, 2) void resunit_kernel(ResUnitArgs a) {
   }
 }
 
-// packed image: [tap][row block][channel pair][lane] with lane -> (row = lane & 31, channel = 2*cp + (lane >> 5)),
-// i.e. every 64-float record is one A operand of v_mfma_f32_32x32x2_f32
+// packed image: [tap][row block][channel pair / 4][lane][4]; element j of a lane's 16 B is the A operand of channel
+// pair cp = 4 * (cp / 4) + j: lane -> (row = lane & 31, channel = 2 * cp + (lane >> 5)) of v_mfma_f32_32x32x2_f32
 __global__ void resunit_pack_kernel(const float* w, const float* scale, float* out, int C, int k) {
   const int total = k * C * C;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int lane = i & 63;
-    int r = i >> 6;
-    const int cp = r % (C / 2);
-    r /= (C / 2);
+    const int j = i & 3;
+    const int lane = (i >> 2) & 63;
+    int r = i >> 8;
+    const int q = r % (C / 8);
+    r /= (C / 8);
     const int mb = r % (C / 32);
     const int tap = r / (C / 32);
+    const int cp = 4 * q + j;
     const int m = mb * 32 + (lane & 31);
     const int ci = 2 * cp + (lane >> 5);
     float v = w[((long)m * C + ci) * k + tap];

@@ -147,8 +147,15 @@ class HiFiGANResidualBlock(torch.nn.Module):
                 x = y
                 continue
             if self.use_additional_convs:
-                xt = conv1(x, pre_act=act1.kind, pre_slope=act1.slope)
                 act2, conv2 = self.convs2[idx][0], self.convs2[idx][1]
+                if not (conv1._needs_grad(x) or conv2._needs_grad(x, accum)):
+                    # inference: the intermediate has one consumer, so its activation is applied ONCE by the
+                    # producer's epilogue instead of on every operand read of the consumer (k reads per
+                    # element, 2 VALU ops each inside the MFMA loop); same fp32 values either way
+                    xt = conv1(x, pre_act=act1.kind, pre_slope=act1.slope, post_act=act2.kind, post_slope=act2.slope)
+                    x = conv2(xt, add1=x, add2=accum if last else None, out_div=out_div if last else 1.0)
+                    continue
+                xt = conv1(x, pre_act=act1.kind, pre_slope=act1.slope)
                 x = conv2(xt, pre_act=act2.kind, pre_slope=act2.slope, add1=x,
                           add2=accum if last else None, out_div=out_div if last else 1.0)
             else:
