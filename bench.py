@@ -480,7 +480,7 @@ def main():
         name, r = max(prof.results.items(), key=lambda kv: kv[1]["ms"])
         achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
         traffic, traffic_src = None, None
-        for pmc_name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+        for pmc_name in ("r02_pmc_hbm_traffic.json",):
             pmc_file = os.path.join(ROOT, "profiles", pmc_name)
             if os.path.exists(pmc_file) and args.batch == 16 and args.frames == 800:
                 # HBM bytes per launch of this kernel on THIS workload, from separate rocprofv3 --pmc passes
@@ -488,7 +488,8 @@ def main():
                 # counters cannot be read from inside the process, so the committed summary is cited
                 with open(pmc_file) as f:
                     pmc = json.load(f)
-                if pmc.get("kernel") == name:
+                if pmc.get("kernel") == name and abs(pmc.get("launches_per_forward", r["launches"] / prof_steps)
+                                                      - r["launches"] / prof_steps) < 0.5:  # same launch mix
                     traffic, traffic_src = pmc["hbm_bytes_per_launch"], "profiles/" + pmc_name
                     break
         roofline = {
@@ -513,6 +514,7 @@ def main():
             # credited with the two convolutions they replace, not with their recomputed halo)
             "kernels": {k_: {"ms_per_step": v["ms"] / prof_steps, "launches_per_step": v["launches"] / prof_steps,
                              "TFLOPs": v["flops"] / max(v["ms"], 1e-9) * 1e-9,
+                             "algorithmic_bytes_per_launch": v["bytes"] / max(v["launches"], 1),
                              "frac_of_peak": v["flops"] / max(v["ms"], 1e-9) * 1e-9 / FP32_MATRIX_PEAK_TFLOPS}
                         for k_, v in sorted(prof.results.items(), key=lambda kv: -kv[1]["ms"])},
             "all_kernels_frac_of_peak": sum(v["flops"] for v in prof.results.values())

@@ -29,6 +29,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"].split("(")[0]
             k = "conv1d_mfma_dma_kernel" if "conv1d_mfma_dma_kernel" in k else k
+            k = "resunit_kernel" if "resunit_kernel" in k else k
             agg[k][0] += 1; agg[k][1] += float(row["Counter_Value"])
     out[c] = {k: {"dispatches": n, "sum": v, "avg_per_dispatch": v / n} for k, (n, v) in agg.items() if "pwg" in k or "conv1d" in k}
 json.dump(out, open("$O/pmc_hbm.json", "w"), indent=1)
@@ -49,7 +50,7 @@ for f in glob.glob("$O/train_pmc_*/**/*counter_collection.csv", recursive=True):
     agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0].replace("void ", "")
-        for fam in ("conv1d_mfma_dma_kernel", "conv1d_wgrad_kernel", "conv1d_mfma_kernel"):
+        for fam in ("conv1d_mfma_dma_kernel", "conv1d_wgrad_kernel", "conv1d_mfma_kernel", "resunit_kernel"):
             if fam in k:
                 k = fam
         if "pwg" not in row["Kernel_Name"]:
