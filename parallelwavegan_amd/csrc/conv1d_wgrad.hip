@@ -175,7 +175,9 @@ __global__ __launch_bounds__(256, (TG > 7 ? 1 : 2)) void conv1d_wgrad_kernel(WgA
     const int f0 = (h0 * a.stride + k0 * a.dil - a.pad) * W;
     const int L = ((h1 - h0) * a.stride + (ntaps_block - 1) * a.dil + 1) * W;
     const int Lr = (L + 63) & ~63;  // whole DMA pieces (the row stride XS covers them)
-    if (i_full && f0 >= 0 && f0 + Lr <= a.x_len) {
+    // (full chunks only: the last chunk of an item stages fewer columns than the MFMA loop walks, and the
+    // predicated path below zero-fills the rest -- stale LDS there meets G = 0, and 0 * NaN is NaN)
+    if (i_full && f0 >= 0 && f0 + Lr <= a.x_len && n0 + TT <= a.n_cols) {
 #pragma unroll 1
       for (int e0 = 0; e0 < Lr; e0 += 64) {
         const int fl = f0 + e0 + lane;

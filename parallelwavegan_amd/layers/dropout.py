@@ -18,6 +18,7 @@ class Dropout(torch.nn.Module):
         self.p = float(p)
         self._counter = None  # int64 device scalar, created lazily on the input's device
         self.last_seeds = None
+        self._uid = None
 
     def forward(self, x):
         if not self.training or self.p == 0.0:
@@ -26,7 +27,11 @@ class Dropout(torch.nn.Module):
             self._counter = torch.zeros(1, dtype=torch.int64, device=x.device)
         used = self._counter.clone()  # the value this call (and its backward) uses
         self._counter += 7919           # plumbing: advance the device counter for the next call / replay
-        seed = (int(torch.initial_seed()) * 1000003 + id(self) % 65521) & ((1 << 62) - 1)
+        if self._uid is None:
+            # per-layer stream id drawn from torch's CPU generator at the first training call: masks are
+            # reproducible after torch.manual_seed() (like torch.nn.Dropout's), independent of object addresses
+            self._uid = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        seed = (int(torch.initial_seed()) * 1000003 + self._uid) & ((1 << 62) - 1)
         self.last_seeds = (seed, used)
         return Fn.DropoutFn.apply(x, self.p, seed, used)
 

@@ -148,7 +148,7 @@ class HiFiGANResidualBlock(torch.nn.Module):
                 continue
             if self.use_additional_convs:
                 act2, conv2 = self.convs2[idx][0], self.convs2[idx][1]
-                if not (conv1._needs_grad(x) or conv2._needs_grad(x, accum)):
+                if not self.use_causal_conv and not (conv1._needs_grad(x) or conv2._needs_grad(x, accum)):
                     # inference: the intermediate has one consumer, so its activation is applied ONCE by the
                     # producer's epilogue instead of on every operand read of the consumer (k reads per
                     # element, 2 VALU ops each inside the MFMA loop); same fp32 values either way
