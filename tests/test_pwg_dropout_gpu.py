@@ -52,7 +52,8 @@ def test_pwg_generator_with_dropout_matches_oracle_with_host_masks(device):
     c = synth.synth_input("c", (2, 80, frames + 4), seed=7)
     z = synth.synth_input("z", (2, 1, frames * 256), seed=7)
     # masks are a function of torch's seed (layers/dropout.py): pinned, so that the comparison below is the same
-    # computation on every run
+    # computation on every run (with the bars below 39 of 40 mask sets pass; the odd one out is a bias gradient at
+    # 3.x e-4: row sums of dy with cancellation, tools/loop_dropout_test.py)
     torch.manual_seed(SEED)
     y = g(z.to(device), c.to(device))
     y.square().mean().backward()
@@ -81,7 +82,10 @@ def test_pwg_generator_with_dropout_matches_oracle_with_host_masks(device):
         # relative to the tensor's largest entry, floored for tensors whose gradient is rounding noise
         # (e.g. the weight-norm direction of a single-input-channel conv: exactly 0 in exact arithmetic)
         scale = max(float(gr.abs().max()), 1e-3 * gmax)
-        assert max_abs(prm.grad, gr) <= (2e-3 if name in CANCELLING else 3e-4) * scale, name
+        # weight-norm gains: dg = <dw, v> / |v| is the small radial part of dw (two orders below |dw| here), so
+        # the summation-order noise of dw (1e-6 relative after 6144 sequential fp32 adds) shows up as 1e-4..1e-3 of dg
+        loose = name in CANCELLING or name.endswith("weight_g")
+        assert max_abs(prm.grad, gr) <= (2e-3 if loose else 3e-4) * scale, name
     # a second call draws new masks; eval mode is the identity
     y2 = g(z.to(device), c.to(device))
     assert not torch.equal(y2, y)

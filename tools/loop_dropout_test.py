@@ -8,11 +8,11 @@ import tests.test_pwg_dropout_gpu as T  # noqa: E402
 
 dev = torch.device("cuda:0")
 fails = 0
-for s in [-1] + list(range(11)):
-    T.SEED = 1000 + 7919 * max(s, 0)
+for s in range(40):
+    T.SEED = 1000 + 7919 * s
     try:
         T.test_pwg_generator_with_dropout_matches_oracle_with_host_masks(dev)
     except AssertionError as e:
         fails += 1
         print("seed", T.SEED, "FAIL:", str(e)[:60].replace("\n", " "))
-print("fails", fails, "of 12")
+print("fails", fails, "of 40")
