@@ -31,7 +31,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             k = "conv1d_mfma_dma_kernel" if "conv1d_mfma_dma_kernel" in k else k
             k = "resunit_kernel" if "resunit_kernel" in k else k
             agg[k][0] += 1; agg[k][1] += float(row["Counter_Value"])
-    out[c] = {k: {"dispatches": n, "sum": v, "avg_per_dispatch": v / n} for k, (n, v) in agg.items() if "pwg" in k or "conv1d" in k}
+    out[c] = {k: {"dispatches": n, "sum": v, "avg_per_dispatch": v / n} for k, (n, v) in agg.items() if "pwg" in k or "conv1d" in k or "resunit" in k}
 json.dump(out, open("$O/pmc_hbm.json", "w"), indent=1)
 for c, d in out.items():
     for k, v in d.items(): print(c, k, v)
