@@ -97,3 +97,26 @@ def test_workspace_queries_answer_without_a_gpu():
     assert n > 0 and n % (16 * 1024 * 32) == 0
     assert l.pwg_conv1d_backward_data_workspace_floats(ctypes.byref(few)) > 0
     assert l.pwg_conv1d_backward_weight_workspace_floats(ctypes.byref(big)) > 0
+
+
+def test_resunit_geometry_queries_answer_without_a_gpu():
+    """pwg_resunit_supported / _profitable / _packed_weight_floats are pure functions of the descriptor."""
+    from parallelwavegan_amd import ops
+
+    ok = [(32, 3, 1), (32, 3, 5), (32, 7, 3), (32, 11, 5), (64, 3, 1), (64, 7, 5), (64, 11, 5)]
+    for c, k, d in ok:
+        for pair in (True, False):
+            assert ops.resunit_supported(ops.make_resunit_desc(2, c, 8192, k, d, pair)), (c, k, d, pair)
+    # wider than the resident tile / not a multiple of 4 samples / even kernel / slope outside (0, 1)
+    assert not ops.resunit_supported(ops.make_resunit_desc(2, 128, 8192, 3, 1))
+    assert not ops.resunit_supported(ops.make_resunit_desc(2, 64, 8192, 11, 7))
+    assert not ops.resunit_supported(ops.make_resunit_desc(2, 32, 8190, 3, 1))
+    assert not ops.resunit_supported(ops.make_resunit_desc(2, 32, 8192, 4, 1))
+    assert not ops.resunit_supported(ops.make_resunit_desc(2, 32, 8192, 3, 1, True, 0.0, 0.1))
+    assert not ops.resunit_supported(ops.make_resunit_desc(2, 32, 8192, 3, 1, True, 0.1, 1.5))
+    # the measured choice: every C = 32 unit, C = 64 up to k = 7; single-convolution units always
+    assert ops.resunit_profitable(ops.make_resunit_desc(2, 32, 8192, 11, 5))
+    assert ops.resunit_profitable(ops.make_resunit_desc(2, 64, 8192, 7, 3))
+    assert not ops.resunit_profitable(ops.make_resunit_desc(2, 64, 8192, 11, 5))
+    assert ops.resunit_profitable(ops.make_resunit_desc(2, 64, 8192, 11, 5, False))
+    assert _lib.lib().pwg_resunit_packed_weight_floats(64, 11) == 11 * 64 * 64
