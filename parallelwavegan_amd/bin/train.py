@@ -70,6 +70,11 @@ class Trainer(object):
             for m in self.model.values():  # independent sub-networks become parallel graph branches
                 if hasattr(m, "branch_streams"):
                     m.branch_streams = True
+            # parameters of the sub-networks receive their gradients on the branch streams by design (the joins
+            # are explicit events, streams.py); torch >= 2.9 warns about that once per process
+            quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+            if quiet is not None:
+                quiet(False)
         self.reducers = None
         if config.get("distributed", False):
             self.reducers = {}
