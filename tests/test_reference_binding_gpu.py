@@ -36,3 +36,6 @@ def test_reference_side_binding_runs_an_mrf_block(device):
     dev_params = [tuple(t_.to(device).contiguous() for t_ in p) for p in params]
     y = ffi.hifigan_residual_block_forward(x.to(device), dev_params, k, dils)
     assert (y.cpu() - ref).abs().max().item() <= 3e-5 * float(ref.abs().max())
+    # the same block with one pwg_resunit_forward launch per dilation
+    y1 = ffi.hifigan_residual_block_forward_one_launch_per_unit(x.to(device), dev_params, k, dils)
+    assert (y1.cpu() - ref).abs().max().item() <= 3e-5 * float(ref.abs().max())

@@ -39,6 +39,22 @@ _lib.pwg_conv1d_forward.restype = ctypes.c_int
 _lib.pwg_conv1d_forward.argtypes = [_dp] + [_vp] * 7 + [ctypes.c_size_t, _vp]  # ..., workspace, ws_floats, stream
 
 
+class ResUnitDesc(ctypes.Structure):  # mirrors pwg_resunit_desc field by field
+    _fields_ = [(n, ctypes.c_int32) for n in ("batch", "channels", "t", "kernel", "dilation", "has_conv2")] + \
+               [("slope1", ctypes.c_float), ("slope2", ctypes.c_float), ("out_div", ctypes.c_float)]
+
+
+_rp = ctypes.POINTER(ResUnitDesc)
+_lib.pwg_resunit_supported.restype = ctypes.c_int
+_lib.pwg_resunit_supported.argtypes = [_rp]
+_lib.pwg_resunit_packed_weight_floats.restype = ctypes.c_size_t
+_lib.pwg_resunit_packed_weight_floats.argtypes = [ctypes.c_int32, ctypes.c_int32]
+_lib.pwg_resunit_pack_weight.restype = ctypes.c_int
+_lib.pwg_resunit_pack_weight.argtypes = [ctypes.c_int32, ctypes.c_int32, _vp, _vp, _vp, _vp]  # C, k, w, scale, out, stream
+_lib.pwg_resunit_forward.restype = ctypes.c_int
+_lib.pwg_resunit_forward.argtypes = [_rp] + [_vp] * 8  # desc, x, w1p, b1, w2p, b2, add2, y, stream
+
+
 def _check(rc):
     if rc != 0:
         raise RuntimeError(_lib.pwg_last_error().decode())
@@ -86,4 +102,32 @@ def hifigan_residual_block_forward(x, params, kernel_size, dilations, slope=0.1)
         xt = conv1d_lrelu_residual(x, pack_weight(v1, g1, kernel_size, dil), b1, torch.zeros_like(x), kernel_size, dil,
                                    slope)
         x = conv1d_lrelu_residual(xt, pack_weight(v2, g2, kernel_size, 1), b2, x, kernel_size, 1, slope)
+    return x
+
+
+def resunit_pack_weight(weight_v, weight_g):
+    """MFMA A-operand image of a weight-normalised (C, C, k) weight for the one-launch residual unit."""
+    c, _, k = weight_v.shape
+    scale = torch.empty(c, device=weight_v.device)
+    _check(_lib.pwg_weight_norm_scale(weight_v.data_ptr(), weight_g.data_ptr(), scale.data_ptr(), c, c * k, _stream()))
+    packed = torch.empty(_lib.pwg_resunit_packed_weight_floats(c, k), device=weight_v.device)
+    _check(_lib.pwg_resunit_pack_weight(c, k, weight_v.data_ptr(), scale.data_ptr(), packed.data_ptr(), _stream()))
+    return packed
+
+
+def hifigan_residual_block_forward_one_launch_per_unit(x, params, kernel_size, dilations, slope=0.1):
+    """Inference variant: each ``xt = convs1[idx](x); xt = convs2[idx](xt); x = xt + x`` iteration
+    (residual_block.py:253-257) is ONE ``pwg_resunit_forward`` launch where the library supports the geometry
+    (32 / 64 channels), else the two launches above."""
+    b, c, t = x.shape
+    for (v1, g1, b1, v2, g2, b2), dil in zip(params, dilations):
+        d = ResUnitDesc(b, c, t, kernel_size, dil, 1, slope, slope, 1.0)
+        if not _lib.pwg_resunit_supported(ctypes.byref(d)):
+            x = hifigan_residual_block_forward(x, [(v1, g1, b1, v2, g2, b2)], kernel_size, [dil], slope)
+            continue
+        w1, w2 = resunit_pack_weight(v1, g1), resunit_pack_weight(v2, g2)  # (a real module caches these per weight)
+        y = torch.empty_like(x)
+        _check(_lib.pwg_resunit_forward(ctypes.byref(d), x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+                                        b2.data_ptr(), None, y.data_ptr(), _stream()))
+        x = y
     return x
