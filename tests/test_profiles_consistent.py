@@ -1,0 +1,28 @@
+"""The committed PMC traffic summary that bench.py cites (`roofline.traffic`) is reproducible from the committed raw
+counter sums and the bench line of the same profiling run (tools/pmc_traffic_summary.py) -- CPU only."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_traffic_summary_is_derived_from_the_committed_raw_counters(tmp_path):
+    out = tmp_path / "traffic.json"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic_summary.py"),
+                           os.path.join(ROOT, "profiles", "r02_i_pmc_hbm_raw.json"),
+                           os.path.join(ROOT, "profiles", "r02_i_infer_bench.json"), str(out), "r02_i"],
+                          stdout=subprocess.DEVNULL)
+    new = json.load(open(out))
+    old = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")))
+    assert new["kernel"] == old["kernel"] == "conv1d_mfma_dma_kernel"
+    for fam in ("conv1d_mfma_dma_kernel", "resunit_kernel"):
+        for key in ("hbm_bytes_per_launch", "algorithmic_bytes_per_launch", "launches_per_forward"):
+            assert abs(new["kernels"][fam][key] - old["kernels"][fam][key]) <= 1e-9 * old["kernels"][fam][key]
+    # what bench.py reads
+    assert old["hbm_bytes_per_launch"] == old["kernels"]["conv1d_mfma_dma_kernel"]["hbm_bytes_per_launch"]
+    # the bench line of the round cites exactly this number for the same launch mix
+    bench = json.load(open(os.path.join(ROOT, "profiles", "r02_i_bench.json")))
+    assert bench["roofline"]["traffic"] == old["hbm_bytes_per_launch"]
+    assert bench["roofline"]["launches_per_step"] == old["launches_per_forward"]
