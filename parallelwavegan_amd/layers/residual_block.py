@@ -112,7 +112,7 @@ class HiFiGANResidualBlock(torch.nn.Module):
         causal / wide layers: no resident-tile kernel)."""
         act1, conv1 = self.convs1[idx][0], self.convs1[idx][1]
         if (not self.fuse_units or self.use_causal_conv or act1.kind != "leaky_relu" or x.dim() != 3
-                or not x.is_cuda or conv1._needs_grad(x, accum)):
+                or not x.is_cuda or conv1._needs_grad(x, None if callable(accum) else accum)):
             return None
         slope2, conv2 = act1.slope, None
         if self.use_additional_convs:
@@ -126,6 +126,8 @@ class HiFiGANResidualBlock(torch.nn.Module):
                                      conv2 is not None, act1.slope, slope2, out_div)
         if not ops.resunit_profitable(desc):
             return None
+        if callable(accum):
+            accum = accum()  # (resolved as late as possible: it may wait for another stream)
         with torch.no_grad():
             x = x.contiguous()
             return ops.resunit_forward(
@@ -134,15 +136,27 @@ class HiFiGANResidualBlock(torch.nn.Module):
                 None if (conv2 is None or conv2.bias is None) else conv2.bias.detach(),
                 None if accum is None else accum.contiguous())
 
-    def forward(self, x, accum=None, out_div=1.0):
-        """Returns ``(block(x) + accum) / out_div``; accum/out_div let the caller fold the
+    def forward(self, x, accum=None, out_div=1.0, accum_join=None):
+        """``accum_join``: optional callable evaluated right before the block's last kernel, returning ``accum``
+        (streams.run_branches_chained: the previous MRF branch is only waited for there).
+        Returns ``(block(x) + accum) / out_div``; accum/out_div let the caller fold the
         MRF sum ``cs += block(c); c = cs / num_blocks`` (models/hifigan.py:186-190 in the
         reference) into this block's last kernel."""
         n = len(self.convs1)
+
+        def acc():
+            """the addend of the last kernel, resolved right before that kernel is launched"""
+            nonlocal accum, accum_join
+            if accum_join is not None:
+                accum, accum_join = accum_join(), None
+            return accum
+
         for idx in range(n):
             last = idx == n - 1
             act1, conv1 = self.convs1[idx][0], self.convs1[idx][1]
-            y = self._unit_one_launch(idx, x, accum if last else None, out_div if last else 1.0)
+            # (a pending join is passed on as a callable and resolved right before the launch)
+            y = self._unit_one_launch(idx, x, (acc if accum_join is not None else accum) if last else None,
+                                      out_div if last else 1.0)
             if y is not None:
                 x = y
                 continue
@@ -153,12 +167,12 @@ class HiFiGANResidualBlock(torch.nn.Module):
                     # producer's epilogue instead of on every operand read of the consumer (k reads per
                     # element, 2 VALU ops each inside the MFMA loop); same fp32 values either way
                     xt = conv1(x, pre_act=act1.kind, pre_slope=act1.slope, post_act=act2.kind, post_slope=act2.slope)
-                    x = conv2(xt, add1=x, add2=accum if last else None, out_div=out_div if last else 1.0)
+                    x = conv2(xt, add1=x, add2=acc() if last else None, out_div=out_div if last else 1.0)
                     continue
                 xt = conv1(x, pre_act=act1.kind, pre_slope=act1.slope)
                 x = conv2(xt, pre_act=act2.kind, pre_slope=act2.slope, add1=x,
-                          add2=accum if last else None, out_div=out_div if last else 1.0)
+                          add2=acc() if last else None, out_div=out_div if last else 1.0)
             else:
                 x = conv1(x, pre_act=act1.kind, pre_slope=act1.slope, add1=x,
-                          add2=accum if last else None, out_div=out_div if last else 1.0)
+                          add2=acc() if last else None, out_div=out_div if last else 1.0)
         return x

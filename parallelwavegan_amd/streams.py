@@ -43,3 +43,34 @@ def run_branches(branches, device, enabled=True):
         cur.wait_stream(s)
         _record(o, cur)  # produced on a side stream, consumed on the caller's stream
     return outs
+
+
+def run_branches_chained(branches, device):
+    """Like :func:`run_branches`, for branches whose results are summed in order (``cs += block(c)``): branch j is
+    called as ``fn(join)`` where ``join()`` -- to be called right before the branch's LAST kernel -- makes the
+    branch's stream wait for branch j-1 and returns that branch's result (None for j = 0), so the running sum
+    rides in the last kernel's epilogue instead of a separate combine launch.  Everything before the last kernel
+    of every branch still runs concurrently.  Returns the last branch's result on the caller's stream."""
+    cur = torch.cuda.current_stream(device)
+    side = _streams(device, len(branches))
+    fork = torch.cuda.Event()
+    fork.record(cur)
+    prev = None  # (completion event, result) of the previous branch
+    for fn, s in zip(branches, side):
+        s.wait_event(fork)
+        with torch.cuda.stream(s):
+            def join(prev=prev, s=s):
+                if prev is None:
+                    return None
+                s.wait_event(prev[0])
+                _record(prev[1], s)  # produced on the previous branch's stream, consumed on this one
+                return prev[1]
+
+            out = fn(join)
+            done = torch.cuda.Event()
+            done.record(s)
+            prev = (done, out)
+    for s in side:
+        cur.wait_stream(s)
+    _record(prev[1], cur)
+    return prev[1]

@@ -60,3 +60,24 @@ def test_generator_at_benchmark_length_matches_oracle(device):
         ref = torch_cpu.hifigan_generator(sd, c, **cfg)
     assert y.shape == ref.shape == (2, 1, 800 * 256)
     assert max_abs(y, ref) <= WAVE_TOL
+
+
+def test_chained_branch_ends_equal_the_serial_running_sum(device):
+    """Inference with MRF branches on parallel streams whose last kernels are chained (streams.run_branches_chained)
+    is bit-identical to the serial running sum `cs += block(c); c = cs / num_blocks` (reference
+    models/hifigan.py:186-190) and to the fork / combine-kernel variant."""
+    from parallelwavegan_amd.models import HiFiGANGenerator
+
+    torch.manual_seed(3)
+    g = HiFiGANGenerator(channels=128, upsample_scales=(4, 4), upsample_kernel_sizes=(8, 8)).to(device).eval()
+    c = torch.randn(2, 80, 64, device=device)
+    with torch.no_grad():
+        serial = g(c)
+        g.branch_streams = True
+        g.chain_min_elems = 0
+        chained = g(c)
+        g.chain_min_elems = 1 << 62
+        forked = g(c)
+    torch.cuda.synchronize()
+    assert torch.equal(chained, serial)
+    assert torch.equal(forked, serial)
