@@ -20,7 +20,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-constexpr int C = 128, BM = 128, BN = 128, CK = 4, XS = BN + 64;
+constexpr int C = 128, BM = 128;
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* base, unsigned bytes) {
   const unsigned long long p = (unsigned long long)base;
@@ -31,13 +31,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* base, unsigne
 }
 
 // x: (B, C, T); y: (B, C, T) (only the interior tiles are launched: no padding logic); k taps, dilation 1
-template <bool WREG>
-__global__ __launch_bounds__(256, 2) void conv_probe(const float* x, const float* wl /* [k][C][C] m fastest */,
+// CK: input channels per chunk (per barrier); WAVES_N: column groups of 64 (2 -> 128x128 tile, 4 waves; 4 -> 128x256, 8 waves)
+template <bool WREG, int CK, int WAVES_N>
+__global__ __launch_bounds__(128 * WAVES_N, 2) void conv_probe(const float* x, const float* wl /* [k][C][C] m fastest */,
                                                      const float* wr /* [C/CK][k][2][64][4] */, float* y, int T, int k) {
+  constexpr int BN = 64 * WAVES_N, XS = BN + 64, NW = 2 * WAVES_N, KS = CK / 2;
+  static_assert(!WREG || CK == 4, "register-weight records hold 4 channels");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int buf_floats = CK * XS + (WREG ? 0 : k * CK * BM);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave_m = wave >> 1, wave_n = wave & 1, l31 = lane & 31, lhi = lane >> 5;
+  const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N, l31 = lane & 31, lhi = lane >> 5;
   const int b = blockIdx.y;
   const int n0 = (blockIdx.x + 1) * BN;  // interior tiles: [n0 - pad, n0 + BN + pad) inside the row
   const int pad = (k - 1) / 2;
@@ -51,16 +54,17 @@ __global__ __launch_bounds__(256, 2) void conv_probe(const float* x, const float
 
   auto issue = [&](int c, float* buf) {
     float* xs = buf;
-    // one 16-B LDS-DMA instruction per x row: (BN + 64) floats = 48 lanes
-    for (int r = wave; r < CK; r += 4)
-      if (lane < XS / 4) {
-        const unsigned off = (unsigned)((c * CK + r) * T + n0 - pad + 4 * lane) * 4u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr_t)(xs + r * XS), 16, off, 0, 0, 0);
-      }
+    // 16-B LDS-DMA per x row: (BN + 64) floats = 48 lanes (BN = 128) / 64 + 16 lanes (BN = 256)
+    for (int r = wave; r < CK; r += NW)
+      for (int l0 = 0; l0 < XS / 4; l0 += 64)
+        if (l0 + lane < XS / 4) {
+          const unsigned off = (unsigned)((c * CK + r) * T + n0 - pad + 4 * (l0 + lane)) * 4u;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr_t)(xs + r * XS + 4 * l0), 16, off, 0, 0, 0);
+        }
     if (!WREG) {
       float* ws = buf + CK * XS;  // [tap][ci][BM]
       const int npieces = k * CK * BM / 256;
-      for (int p = wave; p < npieces; p += 4) {
+      for (int p = wave; p < npieces; p += NW) {
         const int rr = 2 * p + (lane >> 5);  // one piece = 256 floats = two (tap, ci) rows of 128; this lane's row
         const int tap = rr / CK, ci = rr - tap * CK;
         const float* src = wl + ((long)tap * C + c * CK + ci) * C + (lane & 31) * 4;
@@ -82,24 +86,24 @@ __global__ __launch_bounds__(256, 2) void conv_probe(const float* x, const float
     const float* xl = buf + lhi * XS + wave_n * 64 + l31;
     const float* wlds = buf + CK * XS + wave_m * 64 + l31 + lhi * BM;
     for (int tap = 0; tap < k; ++tap) {
-      float av[2][2], bv[2][2];
+      float av[KS][2], bv[KS][2];
       if (WREG) {
         // next record: next tap of this chunk, or tap 0 of the next chunk (the last one re-reads: harmless)
         const int nxt = (c * k + tap + 1 < nchunks * k) ? c * k + tap + 1 : c * k + tap;
         a_nxt = wr4[(long)nxt * 128];
-        av[0][0] = a_cur.x; av[0][1] = a_cur.y; av[1][0] = a_cur.z; av[1][1] = a_cur.w;
+        av[0][0] = a_cur.x; av[0][1] = a_cur.y; av[KS - 1][0] = a_cur.z; av[KS - 1][1] = a_cur.w;
       } else {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi) av[kk][mi] = wlds[(tap * CK + 2 * kk) * BM + mi * 32];
       }
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
+      for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) bv[kk][ni] = xl[2 * kk * XS + tap + ni * 32];
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
+      for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -142,36 +146,72 @@ int main() {
     for (int tap = 0; tap < k; ++tap)
       for (int ci = 0; ci < C; ++ci)
         for (int m = 0; m < C; ++m) hwl[((size_t)tap * C + ci) * C + m] = hw[((size_t)m * C + ci) * k + tap];
-    for (int c = 0; c < C / CK; ++c)
+    for (int c = 0; c < C / 4; ++c)  // register-weight records: 4 channels per chunk
       for (int tap = 0; tap < k; ++tap)
         for (int wm = 0; wm < 2; ++wm)
           for (int lane = 0; lane < 64; ++lane)
             for (int j = 0; j < 4; ++j) {
               const int kk = j >> 1, mi = j & 1;
-              const int m = wm * 64 + mi * 32 + (lane & 31), ci = c * CK + 2 * kk + (lane >> 5);
+              const int m = wm * 64 + mi * 32 + (lane & 31), ci = c * 4 + 2 * kk + (lane >> 5);
               hwr[((((size_t)c * k + tap) * 2 + wm) * 64 + lane) * 4 + j] = hw[((size_t)m * C + ci) * k + tap];
             }
     (void)hipMalloc(&wl, hw.size() * 4);
     (void)hipMalloc(&wr, hw.size() * 4);
     (void)hipMemcpy(wl, hwl.data(), hw.size() * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(wr, hwr.data(), hw.size() * 4, hipMemcpyHostToDevice);
-    const dim3 grid(T / BN - 2, B);
-    const double flops = 2.0 * grid.x * BN * (double)B * C * C * k;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
-    float ms[2];
-    for (int v = 0; v < 2; ++v) {
-      const size_t lds = 2 * (CK * XS + (v ? 0 : k * CK * BM)) * sizeof(float);
-      auto kern = v ? conv_probe<true> : conv_probe<false>;
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      for (int rep = 0; rep < 3; ++rep) {
-        (void)hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, 0, x, wl, wr, v ? yr : yl, T, k);
-        (void)hipEventRecord(e1, 0);
-        (void)hipDeviceSynchronize();
-        (void)hipEventElapsedTime(&ms[v], e0, e1);
+    struct Variant {
+      const char* name;
+      void (*kern)(const float*, const float*, const float*, float*, int, int);
+      int ck, bn;
+      bool wreg;
+    };
+    const Variant variants[] = {
+        {"LDS weights 128x128x4", conv_probe<false, 4, 2>, 4, 128, false},
+        {"reg weights 128x128x4", conv_probe<true, 4, 2>, 4, 128, true},
+        {"LDS weights 128x128x8", conv_probe<false, 8, 2>, 8, 128, false},
+        {"LDS weights 128x128x16", conv_probe<false, 16, 2>, 16, 128, false},
+        {"LDS weights 128x256x4 (8 waves)", conv_probe<false, 4, 4>, 4, 256, false},
+        {"LDS weights 128x256x8 (8 waves)", conv_probe<false, 8, 4>, 8, 256, false},
+    };
+    float ms[2] = {0, 0};
+    for (const Variant& v : variants) {
+      const size_t lds = 2 * ((size_t)v.ck * (v.bn + 64) + (v.wreg ? 0 : (size_t)k * v.ck * BM)) * sizeof(float);
+      if (lds > 160 * 1024) continue;
+      const dim3 grid(T / v.bn - 2, B);
+      const double flops = 2.0 * grid.x * v.bn * (double)B * C * C * k;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(v.kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      float t = 0, t8 = 0;
+      // second timing with the LDS allocation inflated so that exactly 8 waves share a CU (2 per SIMD), the
+      // occupancy of the real kernel's 174-VGPR waves: 2 workgroups of 4 waves or 1 workgroup of 8
+      const size_t lds8 = v.bn == 128 ? 80 * 1024 : 159 * 1024;
+      for (int pass = 0; pass < 2; ++pass) {
+        const size_t l = pass ? (lds8 > lds ? lds8 : lds) : lds;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(v.kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);
+        for (int rep = 0; rep < 3; ++rep) {
+          (void)hipEventRecord(e0, 0);
+          hipLaunchKernelGGL(v.kern, grid, dim3(2 * v.bn), l, 0, x, wl, wr, v.wreg ? yr : yl, T, k);
+          (void)hipEventRecord(e1, 0);
+          (void)hipDeviceSynchronize();
+          (void)hipEventElapsedTime(pass ? &t8 : &t, e0, e1);
+        }
       }
+      printf("k=%2d  %-34s %7.1f us %6.1f TFLOP/s (LDS %zu KB) | at 8 waves per CU %7.1f us %6.1f TFLOP/s\n", k, v.name, t * 1e3,
+             flops / (t * 1e-3) / 1e12, lds / 1024, t8 * 1e3, flops / (t8 * 1e-3) / 1e12);
+      if (&v == &variants[0]) ms[0] = t;
+      if (&v == &variants[1]) ms[1] = t;
+    }
+    // compare the first two variants (same tile, same summation order)
+    (void)hipMemset(yl, 0, hx.size() * 4);
+    (void)hipMemset(yr, 0, hx.size() * 4);
+    {
+      const dim3 grid(T / 128 - 2, B);
+      const size_t l0 = 2 * ((size_t)4 * 192 + (size_t)k * 4 * BM) * sizeof(float), l1 = 2 * (size_t)4 * 192 * sizeof(float);
+      hipLaunchKernelGGL((conv_probe<false, 4, 2>), grid, dim3(256), l0, 0, x, wl, wr, yl, T, k);
+      hipLaunchKernelGGL((conv_probe<true, 4, 2>), grid, dim3(256), l1, 0, x, wl, wr, yr, T, k);
+      (void)hipDeviceSynchronize();
     }
     std::vector<float> a(hx.size()), bvec(hx.size());
     (void)hipMemcpy(a.data(), yl, a.size() * 4, hipMemcpyDeviceToHost);
@@ -181,8 +221,7 @@ int main() {
       md = fmax(md, fabs((double)a[i] - bvec[i]));
       mx = fmax(mx, fabs((double)a[i]));
     }
-    printf("k=%2d  LDS weights %7.1f us %6.1f TFLOP/s | register weights %7.1f us %6.1f TFLOP/s | max|L-R| %.2e (max|y| %.2e)\n", k,
-           ms[0] * 1e3, flops / (ms[0] * 1e-3) / 1e12, ms[1] * 1e3, flops / (ms[1] * 1e-3) / 1e12, md, mx);
+    printf("k=%2d  max|LDS - reg| over the outputs %.2e (max|y| %.2e)\n", k, md, mx);
     (void)hipFree(wl);
     (void)hipFree(wr);
   }
