@@ -178,7 +178,7 @@ def bench_train(args, tag, dev, rank, world, dist, steps, warmup, detail=True):
                 save_interval_steps=10 ** 9, eval_interval_steps=10 ** 9, log_interval_steps=10 ** 9,
                 distributed=world > 1 or os.environ.get("PWG_FORCE_DIST") == "1", rank=rank,
                 outdir=tempfile.mkdtemp(), progress=False,
-                use_hip_graph=not args.no_graph, graph_warmup_steps=2,
+                use_hip_graph=not args.no_graph, graph_warmup_steps=2, record_loss_history=True,
                 ddp_grad_groups=int(os.environ.get("PWG_DDP_GROUPS", "3")),
                 reuse_real_discriminator_pass=os.environ.get("PWG_REUSE_REAL", "1") == "1")
     batch = synthetic_batch(conf, b, dev, rank)
@@ -209,6 +209,10 @@ def bench_train(args, tag, dev, rank, world, dist, steps, warmup, detail=True):
                      sampler={"train": None, "dev": None}, model=model, criterion=criterion, optimizer=opt,
                      scheduler=sched, config=conf, device=dev)
         tr.tqdm = None
+        if os.environ.get("PWG_DBG_STFT"):  # debugging aid (tools/debug_bench_train.py)
+            from tools.debug_bench_train import install_stft_debug
+
+            install_stft_debug(tr)
         try:
             for _ in range(warmup):
                 tr._train_step(batch)
@@ -238,7 +242,17 @@ def bench_train(args, tag, dev, rank, world, dist, steps, warmup, detail=True):
             "ms_per_step_without_collectives": t_nocomm / steps * 1e3,
         }
     tr._flush_pending()
-    finite = all(v == v and abs(v) != float("inf") for v in tr.total_train_loss.values())
+    # every loss of every step (warm-up included) was kept on the device (Trainer.loss_history): say WHICH loss
+    # went non-finite at WHICH step instead of a bare flag
+    hist = tr.loss_history()
+    first_bad = None
+    for st, losses in hist:
+        bad = [k for k, v in losses.items() if not (v == v and abs(v) != float("inf"))]
+        if bad:
+            first_bad = {"step": st, "losses": bad, "values": {k: repr(losses[k]) for k in bad}}
+            break
+    finite = first_bad is None and all(v == v and abs(v) != float("inf") for v in tr.total_train_loss.values())
+    last_losses = {k.split("/")[-1]: round(v, 6) for k, v in hist[-1][1].items()} if hist else None
     # one more (eager) step with per-kernel event timing; every rank runs it -- a data-parallel step
     # contains collectives -- but only rank 0 reports
     prof = None
@@ -256,7 +270,9 @@ def bench_train(args, tag, dev, rank, world, dist, steps, warmup, detail=True):
         out = {
             "config": f"{tag}: {name} (egs/ljspeech/voc1/conf), B={b} x {conf['batch_max_steps']} samples per GPU, "
                       f"generator + discriminator phase, {conf.get('generator_optimizer_type', 'RAdam')}",
-            "value": steps / elapsed,
+            # a step that produced a non-finite loss is not a measurement: no value
+            "value": steps / elapsed if finite else None,
+            "value_of_the_invalid_run": None if finite else steps / elapsed,
             "unit": "steps/s",
             "ms_per_step": ms,
             "steps": steps,
@@ -268,6 +284,9 @@ def bench_train(args, tag, dev, rank, world, dist, steps, warmup, detail=True):
             "parallelism": f"dp{world}" if world > 1 else "single",
             "hip_graph": bool(tr._graphs),
             "losses_finite": finite,
+            "first_nonfinite": first_bad,
+            "steps_checked": len(hist),
+            "last_step_losses": last_losses,
         }
         if dist_info is not None:
             dist_info["exposed_comm_ms"] = ms - dist_info["ms_per_step_without_collectives"]
@@ -562,6 +581,12 @@ def main():
 
     if rank == 0:
         value = samples_per_step * world * args.steps / elapsed
+        train_brief, train_ok = None, None
+        if train is not None:
+            runs = {"c3": train, **{k[:2]: v for k, v in configs.items() if k.endswith("_train")}}
+            train_brief = {k: (round(v["value"], 3) if v.get("value") else None) for k, v in sorted(runs.items())}
+            # False as soon as ANY measured training configuration produced a non-finite loss (or failed to run)
+            train_ok = all(v.get("losses_finite", False) for v in runs.values())
         out = {
             "metric": "HiFi-GAN V1 22.05 kHz generator inference RTF^-1 (audio samples/s)",
             "value": value,
@@ -585,6 +610,9 @@ def main():
                 "parallelism": f"replicas x{world}",
             },
             "rtf": 22050.0 / value,
+            # the training results in brief, early in the line (the full objects follow under "train" / "configs")
+            "train_steps_per_s": train_brief,
+            "train_ok": train_ok,
             "hip_graph": not args.no_graph,
             "parity": parity,
             "latency": latency,

@@ -55,6 +55,12 @@ int pwg_prof_num_kernels(void);
 int pwg_prof_get(int32_t idx, char* name, size_t name_cap, double* total_ms, int64_t* launches,
                  double* flops, double* bytes);
 
+/* Debugging aid (tests): while on, every CU's LDS is filled with NaN bit patterns before each MFMA    */
+/* kernel launched through this ABI, so that a result depending on LDS nobody wrote (0 * stale tile      */
+/* element in a contraction) turns non-finite deterministically.  Same as the environment variable       */
+/* PWG_POISON_LDS=1, switchable at run time; returns the previous setting.                                */
+int pwg_debug_poison_lds(int on);
+
 /* ------------------------------------------------------------------------- */
 /* Activations / padding selectors                                            */
 /* ------------------------------------------------------------------------- */
@@ -367,14 +373,16 @@ int pwg_log_clamp_backward(const float* x, const float* dy, float* dx, int64_t n
 /* Fused single-resolution STFT loss of a (predicted, target) pair -- one launch instead of the
  * frame/conv/mag/log/reduce chain above, and no spectrum-shaped tensor in HBM:
  *   sums[0] = sum (|Y| - |X|)^2   sums[1] = sum |Y|^2   sums[2] = sum |log|Y| - log|X||
- * over the (B, bins, frames) magnitudes |.| = sqrt(max(re^2 + im^2, eps)), from which the caller forms
- * SpectralConvergenceLoss = sqrt(sums[0]) / sqrt(sums[1]) (losses/stft_loss.py:61) and
- * LogSTFTMagnitudeLoss = sums[2] / (B * bins * frames) (:82); torch.stft + clamp + sqrt are :16-40.
+ * over the (B, bins, frames) magnitudes |.| = sqrt(max(re^2 + im^2, eps)), and the two losses themselves:
+ *   sums[3] = SpectralConvergenceLoss = sqrt(sums[0]) / sqrt(sums[1])      (losses/stft_loss.py:61)
+ *   sums[4] = LogSTFTMagnitudeLoss    = sums[2] / (B * bins * frames)      (:82)
+ * (`sums`: 5 device floats); torch.stft + clamp + sqrt are :16-40.
  *   fx, fy : the two signals folded by pwg_frame_fold_forward, (B, hop, n_cols), n_cols >= frames + taps - 1
  *   basis  : windowed DFT image [tap][hop][m_pad], m_pad = 64 * ceil(bins / 32); each 64-row group holds
  *            32 cosine rows then the 32 matching -sine rows (rows of bins >= `bins` are zero)
  *   workspace: pwg_stft_loss_workspace_floats() floats.  Deterministic (fixed tiles, fixed sum order).
- * Backward: given g3 = d loss / d sums (3 DEVICE floats) writes dspec (B, 2*bins, frames) = [d re | d im]
+ * Backward: given the forward's `sums` and g2 = d loss / d (sums[3], sums[4]) (2 DEVICE floats) writes dspec
+ * (B, 2*bins, frames) = [d re | d im]  (the gradient of sums[3] is 0 where sums[0] == 0, torch.norm's subgradient)
  * of the PREDICTED signal's spectrum (the target is a constant), i.e. the dy operand of
  * pwg_conv1d_backward_data on the DFT convolution; pwg_frame_fold_backward finishes the chain.        */
 size_t pwg_stft_loss_workspace_floats(int32_t batch, int32_t bins, int32_t frames);
@@ -383,7 +391,7 @@ int pwg_stft_loss_forward(const float* fx, const float* fy, const float* basis, 
                           float* workspace, float* sums, void* stream);
 int pwg_stft_loss_backward(const float* fx, const float* fy, const float* basis, int32_t batch, int32_t hop,
                            int32_t n_cols, int32_t taps, int32_t bins, int32_t frames, float eps,
-                           const float* g3, float* dspec, void* stream);
+                           const float* sums, const float* g2, float* dspec, void* stream);
 
 /* Fused mel-spectrogram loss of a (predicted, target) pair (losses/mel_loss.py:95-110,150-165):
  *   sum[0] = sum_{b,j,f} | log(max(mel_x, eps)) - log(max(mel_y, eps)) | / log_div,

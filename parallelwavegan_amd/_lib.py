@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libpwgkernels.so")
 
 PWG_ACT_NONE, PWG_ACT_LEAKY_RELU, PWG_ACT_TANH, PWG_ACT_RELU = 0, 1, 2, 3
 PWG_PAD_ZERO, PWG_PAD_REFLECT, PWG_PAD_REPLICATE = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class ConvDesc(ctypes.Structure):
@@ -85,6 +85,7 @@ SIGNATURES = {
     "pwg_last_error": (ctypes.c_char_p, []),
     "pwg_abi_version": (ctypes.c_int, []),
     "pwg_target_arch": (ctypes.c_int, []),
+    "pwg_debug_poison_lds": (ctypes.c_int, [ctypes.c_int]),
     "pwg_prof_enable": (ctypes.c_int, [ctypes.c_int]),
     "pwg_prof_reset": (ctypes.c_int, []),
     "pwg_prof_num_kernels": (ctypes.c_int, []),
@@ -146,7 +147,8 @@ SIGNATURES = {
     "pwg_stft_mag_backward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "pwg_stft_loss_workspace_floats": (ctypes.c_size_t, [_i32, _i32, _i32]),
     "pwg_stft_loss_forward": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
-    "pwg_stft_loss_backward": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
+    "pwg_stft_loss_backward": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp,
+                                              _vp]),
     "pwg_mel_loss_workspace_floats": (ctypes.c_size_t, [_i32, _i32, _i32, _i32]),
     "pwg_mel_loss_forward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp,
                                             _vp, _vp, _vp, _vp]),

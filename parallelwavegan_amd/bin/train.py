@@ -14,8 +14,10 @@ composition of ``_train_step`` (:189-340).  What differs is how a step is execut
 * data parallelism: ``distributed.GradReducer`` (bucketed RCCL all-reduce overlapped with the
   backward pass) instead of apex DDP.
 """
+import argparse
 import logging
 import os
+import sys
 from collections import defaultdict
 
 import torch
@@ -64,6 +66,9 @@ class Trainer(object):
         if "VQVAE" in gtype or "Duration" in gtype:
             raise NotImplementedError(f"{gtype} is outside the accelerated hot path (SURVEY.md s2)")
         self._pending = []  # (name, device scalar) of the current logging interval
+        # config["record_loss_history"]: keep every step's loss scalars on the device (tiny async copies, no host
+        # sync) so that a run can say afterwards WHICH loss went non-finite at WHICH step (bench.py)
+        self._loss_hist = [] if config.get("record_loss_history", False) else None
         self._capturing = False
         self._graphs, self._graph_seen = {}, {}
         if config.get("use_hip_graph", False) and config.get("branch_streams", True):
@@ -156,6 +161,17 @@ class Trainer(object):
             self.total_train_loss[n] += v
         self._pending = []
 
+    def loss_history(self):
+        """[(step, {loss name: value})] of every step since construction (``record_loss_history``); one host sync."""
+        if not self._loss_hist:
+            return []
+        flat = torch.cat([v.reshape(-1) for _, _, v in self._loss_hist]).cpu().tolist()
+        out, i = [], 0
+        for step, names, _ in self._loss_hist:
+            out.append((step, dict(zip(names, flat[i:i + len(names)]))))
+            i += len(names)
+        return out
+
     # ------------------------------------------------------------------ one optimisation step
     def _generator_forward(self, x):
         y_ = self.model["generator"](*x)
@@ -239,6 +255,13 @@ class Trainer(object):
             if self._graph_seen[key] <= self.config.get("graph_warmup_steps", 2):
                 return False  # run this step eagerly
             torch.cuda.synchronize()
+            # pinned staging for the captured optimizer / clip launches (cannot be allocated while capturing)
+            from ..optimizers.fused import reserve_clip_tables_for_capture
+
+            for opt in self.optimizer.values():
+                if hasattr(opt, "reserve_for_capture"):
+                    opt.reserve_for_capture()
+            reserve_clip_tables_for_capture()
             static_x = [None if t is None else t.clone() for t in x]
             static_y = y.clone()
             self._flush_pending()
@@ -315,6 +338,8 @@ class Trainer(object):
         if entry["accum"] is not None:
             entry["accum"].add_(entry["vals"])
             entry["count"] += 1
+            if self._loss_hist is not None:
+                self._loss_hist.append((self.steps, entry["names"], entry["vals"].clone()))
         if gen_on:
             self.scheduler["generator"].step()
         if disc_on:
@@ -326,7 +351,11 @@ class Trainer(object):
             pass
         else:
             x, y = self._parse_batch(batch)
+            first = len(self._pending)
             self._device_step(x, y)
+            if self._loss_hist is not None and len(self._pending) > first:
+                new = self._pending[first:]
+                self._loss_hist.append((self.steps, [n for n, _ in new], torch.stack([v.reshape(()) for _, v in new])))
         self.steps += 1
         if getattr(self, "tqdm", None) is not None:
             self.tqdm.update(1)
@@ -673,3 +702,160 @@ class DeviceCollater(object):
         if self.use_noise_input:
             inputs = (torch.randn(y.size(), device=self.device),) + inputs
         return inputs, y
+
+
+class _DeviceBatches(object):
+    """Iterable of batches for one epoch from an HBM-resident corpus (:class:`DeviceCollater`): the index stream of a
+    (Distributed)Sampler or a fresh permutation, cut into ``batch_size`` groups."""
+
+    def __init__(self, collater, batch_size, sampler=None, shuffle=True):
+        self.collater, self.batch_size, self.sampler, self.shuffle = collater, batch_size, sampler, shuffle
+
+    def __len__(self):
+        n = len(self.sampler) if self.sampler is not None else len(self.collater)
+        return (n + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        if self.sampler is not None:
+            idx = list(iter(self.sampler))
+        else:
+            idx = torch.randperm(len(self.collater)).tolist() if self.shuffle else list(range(len(self.collater)))
+        for i in range(0, len(idx), self.batch_size):
+            batch = self.collater(idx[i:i + self.batch_size])
+            if batch[1].shape[0] > 0:
+                yield batch
+
+
+def main(argv=None):
+    """``parallel-wavegan-train``: the command line of the reference's ``main()`` (bin/train.py:928-1546) for the
+    mel -> waveform recipes on one or several MI355X.
+
+    ``--train-dumpdir`` / ``--dev-dumpdir`` hold ``format: npy`` (``*-wave.npy`` + ``*-feats.npy``) or ``hdf5`` dumps;
+    ``--config`` is a recipe YAML (objects are built by ``utils.build_from_config`` with the reference's defaulting
+    rules).  One process per GPU: under ``parallelwavegan_amd.distributed.launch`` / ``torch.distributed.run`` the
+    rank comes from ``--rank/--local_rank`` or ``LOCAL_RANK``, the process group is RCCL (``nccl`` backend; ``gloo`` when
+    the ranks share a device or there is none), the training set is sharded by a ``DistributedSampler`` and gradients
+    are averaged by ``GradReducer``.  Extra config keys of this engine: ``use_hip_graph`` (default true on a GPU),
+    ``device_collater`` (default true: corpus resident in HBM, one gather launch per batch), ``ddp_grad_groups``."""
+    import yaml
+
+    from ..datasets import AudioMelDataset
+    from ..utils import build_from_config
+
+    p = argparse.ArgumentParser(description="Train a GAN vocoder on MI355X (see parallelwavegan_amd/bin/train.py).")
+    for split in ("train", "dev"):
+        p.add_argument(f"--{split}-wav-scp", default=None, type=str, help="kaldi-style wav.scp (not supported here)")
+        p.add_argument(f"--{split}-feats-scp", default=None, type=str, help="kaldi-style feats.scp (not supported here)")
+        p.add_argument(f"--{split}-segments", default=None, type=str, help="kaldi-style segments (not supported here)")
+        p.add_argument(f"--{split}-dumpdir", default=None, type=str, help=f"directory including the {split} data")
+    p.add_argument("--outdir", type=str, required=True, help="directory to save checkpoints")
+    p.add_argument("--config", type=str, required=True, help="yaml format configuration file")
+    p.add_argument("--pretrain", default="", type=str, nargs="?", help="checkpoint to load parameters from")
+    p.add_argument("--resume", default="", type=str, nargs="?", help="checkpoint to resume training from")
+    p.add_argument("--verbose", type=int, default=1, help="logging level; higher is more logging")
+    p.add_argument("--rank", "--local_rank", default=None, type=int, help="local rank (default: $LOCAL_RANK or 0)")
+    args = p.parse_args(argv)
+
+    local_rank = args.rank if args.rank is not None else int(os.environ.get("LOCAL_RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", str(local_rank)))
+    args.rank, args.world_size, args.distributed = rank, world_size, world_size > 1
+    if not torch.cuda.is_available():
+        raise RuntimeError("parallel-wavegan-train of this package needs an MI355X: there is no CPU compute path")
+    n_dev = torch.cuda.device_count()
+    device = torch.device("cuda", local_rank % n_dev)
+    torch.cuda.set_device(device)  # before the process group exists: RCCL binds to the current device
+    if args.distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("PWG_DIST_BACKEND", "nccl" if n_dev >= world_size else "gloo")
+        torch.distributed.init_process_group(backend=backend, init_method="env://")
+    if rank != 0:
+        sys.stdout = open(os.devnull, "w")
+    level = logging.DEBUG if args.verbose > 1 else logging.INFO if args.verbose > 0 else logging.WARN
+    logging.basicConfig(level=level, stream=sys.stdout,
+                        format="%(asctime)s (%(module)s:%(lineno)d) %(levelname)s: %(message)s")
+    os.makedirs(args.outdir, exist_ok=True)
+    for split in ("train", "dev"):
+        if getattr(args, f"{split}_feats_scp") is not None or getattr(args, f"{split}_wav_scp") is not None:
+            raise NotImplementedError("kaldi scp input is Kaldi glue (out of scope, SURVEY.md s2): use --*-dumpdir")
+        if getattr(args, f"{split}_dumpdir") is None:
+            raise ValueError(f"Please specify --{split}-dumpdir.")
+
+    with open(args.config) as f:
+        config = yaml.load(f, Loader=yaml.Loader)
+    config.update(vars(args))
+    from .. import __version__
+
+    config["version"] = __version__
+    config.setdefault("use_hip_graph", True)
+    if rank == 0:
+        with open(os.path.join(args.outdir, "config.yml"), "w") as f:
+            yaml.dump(config, f, Dumper=yaml.Dumper)
+    for key, value in config.items():
+        logging.info(f"{key} = {value}")
+
+    gtype = config.get("generator_type", "ParallelWaveGANGenerator")
+    if "VQVAE" in gtype or "Duration" in gtype or config.get("use_local_condition") or config.get("use_global_condition"):
+        raise NotImplementedError(f"{gtype} / conditioning inputs are outside the accelerated hot path (SURVEY.md s2)")
+    if gtype == "UHiFiGANGenerator":
+        raise NotImplementedError("f0 / excitation dumps: build the data loader around Collater(use_f0_and_excitation=True)")
+    use_noise_input = "ParallelWaveGAN" in gtype
+    acw = config["generator_params"].get("aux_context_window", 0)
+    hop = config.get("hop_size")
+    if config.get("remove_short_samples", True):
+        mel_length_threshold = config["batch_max_steps"] // hop + 2 * acw
+    else:
+        mel_length_threshold = None
+    fmt = config.get("format", "hdf5")
+    dataset = {split: AudioMelDataset(getattr(args, f"{split}_dumpdir"), format=fmt,
+                                      mel_length_threshold=mel_length_threshold,
+                                      allow_cache=config.get("allow_cache", False)) for split in ("train", "dev")}
+    logging.info(f"The number of training files = {len(dataset['train'])}.")
+    logging.info(f"The number of development files = {len(dataset['dev'])}.")
+
+    sampler = {"train": None, "dev": None}
+    if args.distributed:
+        from torch.utils.data.distributed import DistributedSampler
+
+        sampler = {"train": DistributedSampler(dataset["train"], num_replicas=world_size, rank=rank, shuffle=True),
+                   "dev": DistributedSampler(dataset["dev"], num_replicas=world_size, rank=rank, shuffle=False)}
+    ckw = dict(batch_max_steps=config["batch_max_steps"], hop_size=hop, aux_context_window=acw,
+               use_noise_input=use_noise_input)
+    if config.get("device_collater", True):
+        data_loader = {split: _DeviceBatches(DeviceCollater([dataset[split][i] for i in range(len(dataset[split]))],
+                                                            device, **ckw),
+                                             config["batch_size"], sampler[split], shuffle=not args.distributed)
+                       for split in ("train", "dev")}
+    else:
+        from torch.utils.data import DataLoader
+
+        collater = Collater(pin_memory=False, **ckw)
+        data_loader = {split: DataLoader(dataset=dataset[split], shuffle=not args.distributed, collate_fn=collater,
+                                         batch_size=config["batch_size"], num_workers=config.get("num_workers", 0),
+                                         sampler=sampler[split], pin_memory=config.get("pin_memory", False))
+                       for split in ("train", "dev")}
+
+    model, criterion, optimizer, scheduler = build_from_config(config, device)
+    for part in (model, optimizer, scheduler):
+        for v in part.values():
+            logging.info(v)
+    trainer = Trainer(steps=0, epochs=0, data_loader=data_loader, sampler=sampler, model=model, criterion=criterion,
+                      optimizer=optimizer, scheduler=scheduler, config=config, device=device)
+    if args.pretrain:
+        trainer.load_checkpoint(args.pretrain, load_only_params=True)
+        logging.info(f"Successfully load parameters from {args.pretrain}.")
+    if args.resume:
+        trainer.load_checkpoint(args.resume)
+        logging.info(f"Successfully resumed from {args.resume}.")
+    try:
+        trainer.run()
+    finally:
+        if rank == 0:
+            trainer.save_checkpoint(os.path.join(config["outdir"], f"checkpoint-{trainer.steps}steps.pkl"))
+            logging.info(f"Successfully saved checkpoint @ {trainer.steps}steps.")
+        if args.distributed:
+            torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

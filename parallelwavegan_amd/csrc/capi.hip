@@ -29,6 +29,16 @@ bool lds_limit_is_set(const void* kern, size_t bytes) {
   return false;
 }
 
+__global__ void zero_fill_kernel(float* p, long n) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) p[i] = 0.f;
+}
+void zero_fill(float* p, long n, hipStream_t stream) {
+  if (n <= 0) return;
+  long blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(zero_fill_kernel, dim3((int)blocks), dim3(256), 0, stream, p, n);
+}
+
 // ---- debugging aid: PWG_POISON_LDS=1 fills the LDS of every CU with NaN bit patterns before each
 // MFMA kernel launch, so that a result depending on stale LDS content (0 * unwritten tile element in a
 // contraction) fails deterministically instead of once in a while on a cold GPU ---------------------
@@ -38,9 +48,10 @@ __global__ void poison_lds_kernel(float* sink) {
   __syncthreads();
   if (sink && threadIdx.x == 0 && lds[17] == 1.0f) sink[0] = 1.f;
 }
+static int g_poison_lds = -1;  // -1: take PWG_POISON_LDS from the environment at the first launch
 void maybe_poison_lds(hipStream_t stream) {
-  static const bool on = getenv("PWG_POISON_LDS") != nullptr;
-  if (!on) return;
+  if (g_poison_lds < 0) g_poison_lds = getenv("PWG_POISON_LDS") != nullptr ? 1 : 0;
+  if (!g_poison_lds) return;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(poison_lds_kernel),
@@ -127,6 +138,12 @@ static void prof_fold() {
 }
 }  // namespace pwg
 
+extern "C" int pwg_debug_poison_lds(int on) {
+  const int was = pwg::g_poison_lds > 0 ? 1 : 0;
+  pwg::g_poison_lds = on ? 1 : 0;
+  return was;
+}
+
 extern "C" int pwg_prof_enable(int on) {
   std::lock_guard<std::mutex> lk(pwg::g_prof_mu);
   pwg::g_prof_on = on != 0;
@@ -158,5 +175,5 @@ extern "C" int pwg_prof_get(int32_t idx, char* name, size_t name_cap, double* to
 }
 
 extern "C" const char* pwg_last_error(void) { return pwg::g_err; }
-extern "C" int pwg_abi_version(void) { return 4; }
+extern "C" int pwg_abi_version(void) { return 5; }
 extern "C" int pwg_target_arch(void) { return 950; }

@@ -64,6 +64,12 @@ bool lds_limit_is_set(const void* kern, size_t bytes);
 // PWG_POISON_LDS=1 (debugging): NaN-fill every CU's LDS before an MFMA kernel launch (capi.hip)
 void maybe_poison_lds(hipStream_t stream);
 
+// Zero n floats with an ordinary kernel launch.  Used instead of hipMemsetAsync on every path that a training
+// step captures into a hipGraph: a captured memset becomes a memset NODE, and the one failure mode the round-2
+// bench ever showed (C2: garbage STFT-loss sums on a graph replay) sat exactly on the only buffer whose
+// correctness depended on such a node (the unwritten tail of the partial-sum array).  Kernel nodes only.
+void zero_fill(float* p, long n, hipStream_t stream);
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 

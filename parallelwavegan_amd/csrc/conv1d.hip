@@ -848,7 +848,8 @@ struct HasFast {
                                 (WM == 1 && WN == 1 && WAVES_M == 2 && WAVES_N == 2 && CK == 8) ||   // 64x64x8
                                 (WM == 1 && WN == 1 && WAVES_M == 2 && WAVES_N == 2 && CK == 16) ||  // 64x64x16
                                 (WM == 1 && WN == 1 && WAVES_M == 1 && WAVES_N == 4 && CK == 16) ||  // 32x128x16
-                                (WM == 1 && WN == 1 && WAVES_M == 2 && WAVES_N == 2 && CK == 4);     // 64x64x4 (k = 41 groups)
+                                (WM == 1 && WN == 1 && WAVES_M == 2 && WAVES_N == 2 && CK == 4) ||   // 64x64x4 (k = 41 groups)
+                                (WM == 2 && WN == 2 && WAVES_M == 2 && WAVES_N == 4 && (CK == 4 || CK == 8));  // 128x256, 8 waves
 };
 
 template <int WM, int WN, int WAVES_M, int WAVES_N, int CK>
@@ -953,6 +954,7 @@ static int launch_conv(const ConvArgs& a0, const Geometry& g, int batch, int gro
 struct TileCfg {
   int bm, bn, ck;
   int wm, wn;  // 32x32 accumulator tiles per wave
+  int waves;   // waves per workgroup (4, or 8 for the 128x256 tiles: one workgroup per CU)
 };
 #define PWG_CONV_CFGS(X)  \
   X(0, 2, 2, 2, 2, 8)     \
@@ -972,18 +974,20 @@ struct TileCfg {
   X(14, 1, 1, 4, 1, 8)    \
   X(15, 1, 1, 2, 2, 16)   \
   X(16, 1, 1, 1, 4, 16)   \
-  X(17, 1, 1, 2, 2, 4)
-static const int kNumCfgs = 18;
+  X(17, 1, 1, 2, 2, 4)    \
+  X(18, 2, 2, 2, 4, 4)    \
+  X(19, 2, 2, 2, 4, 8)
+static const int kNumCfgs = 20;
 
 static TileCfg cfg_info(int id) {
   switch (id) {
 #define X(ID, WM, WN, WVM, WVN, CK) \
   case ID:                          \
-    return TileCfg{32 * WM * WVM, 32 * WN * WVN, CK, WM, WN};
+    return TileCfg{32 * WM * WVM, 32 * WN * WVN, CK, WM, WN, WVM * WVN};
     PWG_CONV_CFGS(X)
 #undef X
   }
-  return TileCfg{0, 0, 0, 0, 0};
+  return TileCfg{0, 0, 0, 0, 0, 0};
 }
 
 static size_t cfg_lds(int id, const Geometry& g, int W, bool dma) {
@@ -993,7 +997,7 @@ static size_t cfg_lds(int id, const Geometry& g, int W, bool dma) {
   int xs = dma ? round_up(xs_len, 64) : round_up(xs_len, 4);
   if (dma && g.stride == 1 && W == 1 && (g.k_phase - 1) * g.dil <= 64) xs = c.bn + 64;  // FAST row stride (upper bound)
   const size_t buf = ((size_t)c.ck * xs + (size_t)g.k_phase * c.ck * c.bm) * sizeof(float);
-  return dma ? 2 * buf + (size_t)4 * 32 * 36 * sizeof(float) : buf;
+  return dma ? 2 * buf + (size_t)c.waves * 32 * 36 * sizeof(float) : buf;
 }
 
 static int launch_cfg(int id, bool dma, const ConvArgs& a, const Geometry& g, int batch, int groups,
@@ -1021,6 +1025,7 @@ struct Cand {
   int id;
   float speed;
 };
+
 // ksplit (optional out): number of reduction slices.  A workgroup walks its ci-chunks serially and a
 // chunk costs at least one DMA + barrier round trip (~2.7 us measured) however little MFMA work it
 // carries; when the chosen tile leaves the SIMDs that idle (few workgroups, short chunks: the
@@ -1032,9 +1037,16 @@ static int choose_cfg(const Geometry& g, int W, int batch, int groups, bool dma,
   const int k = g.k_phase;
   // ids: 9 = 128x64x8, 0 = 128x128x8, 12 = 64x128x8, 13 = 64x64x8, 14 = 128x32x8, 2 = 128x128x4, 15 = 64x64x16,
   // 16 = 32x128x16, 10 = 32x128x8, 11 = 64x256x4
+  // 18 / 19 = 128x256x4 / x8 with 8 waves (one workgroup per CU, one barrier domain, half the weight DMA per MFMA):
+  // tools/probes/conv_wreg.hip (loop only, no epilogue) ranked them first at every k, but on the real kernel they
+  // LOSE 5-10 % to 128x128x4 at C = 256 and 3-5 % to 64x256x4 at C = 128 (profiles/r03_conv_sweep.txt): with one
+  // workgroup per CU nothing overlaps a workgroup's epilogue / first-chunk latency.  Kept as sweepable
+  // configurations (pwg_conv1d_forward_cfg), never chosen.
+  // 11 = 64x256x4 for exactly 128 rows: two row blocks re-read x, still 3-7 % faster than 128x128x4 there.
   static const Cand big_few[] = {{9, 0.95f}, {0, 0.85f}, {12, 0.85f}, {13, 0.75f}, {14, 0.6f}, {2, 0.8f},
-                                 {15, 0.8f}, {16, 0.82f}};
-  static const Cand big_many[] = {{2, 1.0f}, {9, 0.9f}, {12, 0.85f}, {13, 0.75f}, {14, 0.6f}, {15, 0.8f}, {16, 0.82f}};
+                                 {15, 0.8f}, {16, 0.82f}, {11, 0.97f}};
+  static const Cand big_many[] = {{2, 1.0f}, {9, 0.9f}, {12, 0.85f}, {13, 0.75f}, {14, 0.6f}, {15, 0.8f}, {16, 0.82f},
+                                  {11, 1.06f}};
   // 17 = 64x64x4: the only 64-row tile whose double-buffered weight chunk fits the LDS at k = 41 (grouped
   // scale-discriminator layers, 64 channels per group, T = 9..128 columns per item)
   static const Cand mid_few[] = {{10, 1.0f}, {11, 0.8f}, {13, 0.8f}, {17, 0.7f}};
@@ -1044,7 +1056,7 @@ static int choose_cfg(const Geometry& g, int W, int batch, int groups, bool dma,
   int ncand;
   if (m > 64) {
     cand = k <= 4 ? big_few : big_many;
-    ncand = k <= 4 ? 8 : 7;
+    ncand = (k <= 4 ? 9 : 8) - (m > 128 ? 1 : 0);  // (the last entry, 64x256x4, only for m <= 128)
   } else if (m > 32) {
     cand = k <= 4 ? mid_few : mid_many;  // (k = 7 at C = 64: 64x256x4 103 vs 32x128x8 95 TFLOP/s, profiles/r02_conv_sweep.txt)
     ncand = 4;
@@ -1070,17 +1082,19 @@ static int choose_cfg(const Geometry& g, int W, int batch, int groups, bool dma,
   int best = -1, best_split = 1;
   float best_score = -1.f;
   for (int pass = 0; pass < 2 && best < 0; ++pass) {
-    const size_t cap = pass == 0 ? 80 * 1024 : 160 * 1024;  // first try to keep >= 2 workgroups per CU
     for (int i = 0; i < ncand; ++i) {
-      if (cfg_lds(cand[i].id, g, W, dma) > cap) continue;
       const TileCfg c = cfg_info(cand[i].id);
+      // first try to keep >= 2 workgroups per CU (the 8-wave tiles are one workgroup per CU by design)
+      const size_t cap = (pass == 0 && c.waves < 8) ? 80 * 1024 : 160 * 1024;
+      if (cfg_lds(cand[i].id, g, W, dma) > cap) continue;
+      if (c.waves == 8 && (!dma || g.stride != 1 || W != 1 || (k - 1) * g.dil > 64)) continue;  // FAST geometry only
       if (c.ck == 16 && (!dma || g.cin_g < 256)) continue;  // 16-channel chunks: long reductions only
       const long ntiles = ceil_div(g.n_cols, c.bn);
       const long blocks = ntiles * ceil_div(m, c.bm) * groups * batch;
       const int split = max_split(c, blocks);
       // (very long filters -- k = 41 grouped layers -- carry >= 5000 MFMA cycles per chunk: one workgroup
       // per CU already hides the DMA round trip, so 256 workgroups count as a full chip there)
-      const float full = k >= 32 ? 256.f : 512.f;
+      const float full = (k >= 32 || c.waves == 8) ? 256.f : 512.f;
       const float fill = blocks * split >= full ? 1.f : (float)(blocks * split) / full;
       const float useful = (float)g.n_cols / (float)(ntiles * c.bn) * (float)m / (float)(ceil_div(m, c.bm) * c.bm);
       const float score = fill * useful * cand[i].speed * (split > 1 ? 0.9f : 1.f);
@@ -1247,8 +1261,12 @@ extern "C" int pwg_conv1d_forward(const pwg_conv1d_desc* d_in, const float* x, c
   if (rc != PWG_OK) return rc;
   if (!d->transposed && d->groups == 1 && d->width == 1 && d->stride == 1 && d->pad_mode == PWG_PAD_ZERO &&
       d->c_out <= 4 && d->c_out * d->c_in * d->kernel <= SC_MAXW && !add1 && !add2 && d->out_div == 1.0f &&
-      d->t_out >= 4096 && (d->kernel - 1) * d->dilation <= 1024) {
-    PWG_REQUIRE(x && w_packed && y, PWG_ERR_NULL, "conv1d_forward: NULL pointer");
+      d->t_out >= 4096 && (d->kernel - 1) * d->dilation <= 1024 &&
+      (d->pre_act == PWG_ACT_NONE || d->pre_act == PWG_ACT_LEAKY_RELU || d->pre_act == PWG_ACT_RELU)) {
+    // (the same argument checks as the MFMA path: fill_args validates pointers and the pre-activation)
+    ConvArgs chk;
+    rc = fill_args(d, g, x, w_packed, bias, add1, add2, y, &chk);
+    if (rc != PWG_OK) return rc;
     // few output channels over a long sequence: streaming VALU kernel (see conv1d_small_cout_kernel)
     const size_t lds = ((size_t)d->c_out * d->c_in * d->kernel + SC_TILE + (d->kernel - 1) * d->dilation) * sizeof(float);
     const double out_elems = (double)d->batch * d->c_out * d->t_out;

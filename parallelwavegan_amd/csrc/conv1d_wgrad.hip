@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* __r
 }
 
 // db[c] += sum over one (item, 4096-sample segment) of dy[b][c][:]; grid (channels, items * segments);
-// db is zeroed first (hipMemsetAsync) and the per-segment partial sums are combined with atomics.
+// db is zeroed first (zero_fill kernel) and the per-segment partial sums are combined with atomics.
 constexpr int BG_SEG = 4096;
 __global__ void bias_grad_kernel(const float* dy, float* db, int channels, int n, int segs) {
   __shared__ float red[4];
@@ -442,7 +442,6 @@ struct WnFinish {
   float* dv;
   float* dg;
 };
-static thread_local const WnFinish* g_wn_finish = nullptr;
 
 template <bool WIDE>
 __global__ __launch_bounds__(256) void reduce_slabs_wn_kernel(const float* __restrict__ slabs, long slab_stride,
@@ -631,7 +630,7 @@ static WgPlan wgrad_plan(int co_g, int ci_g, int groups, int k, int stride, int 
 
 template <int TG, bool SMALL, int TT, bool WIN, int MODE>
 static int launch_wgrad_mode(WgArgs a, const WgPlan& p, float* dw_out, float* workspace, size_t ws_floats,
-                        hipStream_t stream, double flops, double bytes) {
+                        hipStream_t stream, double flops, double bytes, const WnFinish* wn) {
   a.xs_stride = p.xs_stride;
   a.chunks_per_item = p.chunks_per_item;
   a.chunks_total = p.chunks_total;
@@ -648,7 +647,6 @@ static int launch_wgrad_mode(WgArgs a, const WgPlan& p, float* dw_out, float* wo
   a.slab_elems = (long)a.co_g * a.groups * a.ci_g * a.k;
   float* db_out = a.db;  // non-null: the bias gradient rides along (row sums of the G tiles)
   a.slab_stride = a.slab_elems + (db_out ? (long)a.co_g * a.groups : 0);
-  const WnFinish* wn = g_wn_finish;
   a.tap_major = 0;
   if (p.splits == 1 && wn == nullptr) {
     a.dw = dw_out;  // single slice: write the gradients directly (torch layout)
@@ -720,10 +718,10 @@ static int launch_wgrad_mode(WgArgs a, const WgPlan& p, float* dw_out, float* wo
 
 template <int TG, bool SMALL, int TT>
 static int launch_wgrad(WgArgs a, const WgPlan& p, float* dw_out, float* workspace, size_t ws_floats,
-                        hipStream_t stream, double flops, double bytes) {
+                        hipStream_t stream, double flops, double bytes, const WnFinish* wn) {
   const bool act = (a.slope_g != 1.f || a.slope_x != 1.f) && !(a.dbg & 8);
 #define WG_GO(WINV, MODEV) \
-  return launch_wgrad_mode<TG, SMALL, TT, WINV, MODEV>(a, p, dw_out, workspace, ws_floats, stream, flops, bytes)
+  return launch_wgrad_mode<TG, SMALL, TT, WINV, MODEV>(a, p, dw_out, workspace, ws_floats, stream, flops, bytes, wn)
   if (a.width != 1) WG_GO(false, 2);  // per-tap windows need width == 1 and stride == 1 (wgrad_plan)
   if (a.stride != 1) WG_GO(false, 3);
   if (p.win) {
@@ -762,9 +760,9 @@ extern "C" size_t pwg_conv1d_backward_weight_workspace_floats(const pwg_conv1d_d
   return p.splits > 1 ? (size_t)p.splits * ((size_t)co_g * d->groups * ci_g * d->kernel + (size_t)co_g * d->groups) : 0;
 }
 
-extern "C" int pwg_conv1d_backward_weight(const pwg_conv1d_desc* d_in, const float* x, const float* dy,
-                                          float* dw, float* db, float* workspace, size_t workspace_floats,
-                                          void* stream_) {
+// wn != nullptr: finish the slabs with the fused weight-norm backward (pwg_conv1d_backward_weight_wn)
+static int backward_weight_impl(const pwg_conv1d_desc* d_in, const float* x, const float* dy, float* dw, float* db,
+                                float* workspace, size_t workspace_floats, void* stream_, const WnFinish* wn) {
   PWG_REQUIRE(d_in && x && dy, PWG_ERR_NULL, "conv1d_backward_weight: NULL pointer");
   const pwg_conv1d_desc flat = flatten_width(*d_in);
   const pwg_conv1d_desc* d = &flat;
@@ -783,7 +781,7 @@ extern "C" int pwg_conv1d_backward_weight(const pwg_conv1d_desc* d_in, const flo
   if (db && !fuse_bias) {
     const int n = d->t_out * d->width;
     const int segs = ceil_div(n, BG_SEG);
-    (void)hipMemsetAsync(db, 0, sizeof(float) * d->c_out, stream);
+    zero_fill(db, d->c_out, stream);
     ProfScope prof(stream, "bias_grad_kernel", 0, 4.0 * y_elems);
     hipLaunchKernelGGL(bias_grad_kernel, dim3(d->c_out, d->batch * segs), dim3(256), 0, stream, dy, db, d->c_out, n,
                        segs);
@@ -837,9 +835,9 @@ extern "C" int pwg_conv1d_backward_weight(const pwg_conv1d_desc* d_in, const flo
                               d->batch);
 #define WG_CASE(TGV, SM)                                                                             \
   switch (p.tt) {                                                                                    \
-    case 128: return launch_wgrad<TGV, SM, 128>(a, p, dw, workspace, workspace_floats, stream, flops, bytes); \
-    case 64: return launch_wgrad<TGV, SM, 64>(a, p, dw, workspace, workspace_floats, stream, flops, bytes);   \
-    default: return launch_wgrad<TGV, SM, 32>(a, p, dw, workspace, workspace_floats, stream, flops, bytes);   \
+    case 128: return launch_wgrad<TGV, SM, 128>(a, p, dw, workspace, workspace_floats, stream, flops, bytes, wn); \
+    case 64: return launch_wgrad<TGV, SM, 64>(a, p, dw, workspace, workspace_floats, stream, flops, bytes, wn);   \
+    default: return launch_wgrad<TGV, SM, 32>(a, p, dw, workspace, workspace_floats, stream, flops, bytes, wn);   \
   }
   if (p.small) {
     switch (p.tg) {
@@ -850,7 +848,7 @@ extern "C" int pwg_conv1d_backward_weight(const pwg_conv1d_desc* d_in, const flo
     }
   }
 #undef WG_CASE
-#define WG_CASE(TGV) return launch_wgrad<TGV, false, 32>(a, p, dw, workspace, workspace_floats, stream, flops, bytes)
+#define WG_CASE(TGV) return launch_wgrad<TGV, false, 32>(a, p, dw, workspace, workspace_floats, stream, flops, bytes, wn)
   switch (p.tg) {  // 64x64 tiles always run 32-column chunks (LDS)
     case 1: WG_CASE(1);
     case 2: WG_CASE(2);
@@ -863,6 +861,10 @@ extern "C" int pwg_conv1d_backward_weight(const pwg_conv1d_desc* d_in, const flo
 #undef WG_CASE
 }
 
+extern "C" int pwg_conv1d_backward_weight(const pwg_conv1d_desc* d, const float* x, const float* dy, float* dw,
+                                          float* db, float* workspace, size_t workspace_floats, void* stream) {
+  return backward_weight_impl(d, x, dy, dw, db, workspace, workspace_floats, stream, nullptr);
+}
 
 // Weight-normalised layers: dv, dg (and db) straight from the reduction slabs -- see reduce_slabs_wn_kernel.
 // v (weight_v, torch layout) and g (weight_g, one value per dim-0 slice) are the forward's parameters.  The
@@ -885,14 +887,13 @@ extern "C" int pwg_conv1d_backward_weight_wn(const pwg_conv1d_desc* d, const flo
   int co_g, ci_g, n_cols;
   const pwg_conv1d_desc flat = flatten_width(*d);
   wgrad_roles(&flat, &co_g, &ci_g, &n_cols);
-  PWG_REQUIRE((size_t)ci_g * d->kernel * sizeof(float) <= 64 * 1024, PWG_ERR_UNSUPPORTED,
+  // (the finishing kernel holds one weight row in dynamic LDS next to 32 B of static LDS: stay below the 64 KiB
+  // default limit with room to spare; functional.py routes longer rows to the two-kernel finish)
+  PWG_REQUIRE((size_t)ci_g * d->kernel * sizeof(float) + 256 <= 64 * 1024, PWG_ERR_UNSUPPORTED,
               "conv1d_backward_weight_wn: a weight row of %d floats exceeds the LDS row buffer", ci_g * d->kernel);
   PWG_REQUIRE(workspace_floats >= pwg_conv1d_backward_weight_wn_workspace_floats(d), PWG_ERR_WORKSPACE,
               "conv1d_backward_weight_wn: workspace too small");
   const WnFinish wn{v, g, dv, dg};
-  g_wn_finish = &wn;
   // (dw argument: any non-NULL pointer selects the weight-gradient path; the slabs live in the workspace)
-  const int rc = pwg_conv1d_backward_weight(d, x, dy, dv, db, workspace, workspace_floats, stream);
-  g_wn_finish = nullptr;
-  return rc;
+  return backward_weight_impl(d, x, dy, dv, db, workspace, workspace_floats, stream, &wn);
 }

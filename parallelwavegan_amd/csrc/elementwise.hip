@@ -833,7 +833,7 @@ extern "C" int pwg_spectral_norm_backward(const float* dw, const float* w_orig, 
   PWG_REQUIRE(rows > 0 && cols > 0, PWG_ERR_BAD_SHAPE, "spectral_norm: bad shape");
   hipStream_t stream = (hipStream_t)stream_;
   const long n = (long)rows * cols;
-  (void)hipMemsetAsync(scratch, 0, sizeof(float), stream);
+  zero_fill(scratch, 1, stream);
   hipLaunchKernelGGL(dot_big_kernel, dim3(grid_for(n, 256, 256)), dim3(256), 0, stream, dw, w_orig, scratch, n);
   hipLaunchKernelGGL(spectral_norm_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, dw, u, v, sigma, scratch,
                      dw_orig, rows, cols);
@@ -882,7 +882,7 @@ extern "C" int pwg_stretch_conv_backward(const float* dy, const float* x, const 
   }
   if (dw) {
     PWG_REQUIRE(x, PWG_ERR_NULL, "stretch_conv_backward: x needed for dw");
-    (void)hipMemsetAsync(dw, 0, sizeof(float) * kernel, (hipStream_t)stream);
+    zero_fill(dw, kernel, (hipStream_t)stream);
     const long n = rows * (long)t_in * scale;
     hipLaunchKernelGGL(stretch_conv_bwd_weight_kernel, dim3(grid_for(n, 256, 512)), dim3(256), 0, (hipStream_t)stream,
                        dy, x, dw, (long)rows, t_in, scale, kernel, pad_left);

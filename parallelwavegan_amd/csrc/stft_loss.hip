@@ -21,6 +21,8 @@
 // convolution (transposed DFT) -- the only spectrum-shaped tensor of the whole loss.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace pwg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -32,7 +34,9 @@ struct StftLossArgs {
   int batch, hop, n_cols, taps, bins, frames, ngroups, ftiles, m_pad;
   float eps;
   float* partial;      // forward: (units, 4) partial sums [S_d, S_y, S_l, 0]
-  const float* g3;     // backward: upstream gradients of (S_d, S_y, S_l), device
+  const float* g2;     // backward: upstream gradients of (sc, mag) = sums[3..4], device
+  const float* sums;   // backward: the forward's five outputs [S_d, S_y, S_l, sc, mag]
+  float inv_n;         // 1 / (B * bins * frames)
   float* dspec;        // backward: (B, 2*bins, frames)
 };
 
@@ -43,7 +47,11 @@ __global__ __launch_bounds__(256) void stft_loss_kernel(StftLossArgs a) {
   const int l31 = lane & 31, lhi = lane >> 5;
   const int units = a.batch * a.ngroups * a.ftiles;
   int unit = blockIdx.x * 4 + wave;
-  if (unit >= units) return;  // (wave-uniform: no block-level synchronisation in this kernel)
+  if (unit >= units) {  // (wave-uniform: no block-level synchronisation in this kernel)
+    // surplus wave of the last workgroup: its slot of the partial sums is read by the finish kernel too
+    if (!BWD && lane < 4) a.partial[(long)(blockIdx.x * 4 + wave) * 4 + lane] = 0.f;
+    return;
+  }
   const int ft = unit % a.ftiles;
   unit /= a.ftiles;
   const int g = unit % a.ngroups;
@@ -107,7 +115,12 @@ __global__ __launch_bounds__(256) void stft_loss_kernel(StftLossArgs a) {
       p[3] = 0.f;
     }
   } else {
-    const float gd = a.g3[0], gl = a.g3[2];
+    // sc = sqrt(S_d) / sqrt(S_y), mag = S_l / n:  d sc / d S_d = 1 / (2 sqrt(S_d) sqrt(S_y)), and 0 at S_d = 0 --
+    // the zero subgradient torch.norm(p="fro") returns there (x == y on every bin; sqrt's own backward would
+    // hand inf * 0 = NaN to every bin)
+    const float s_d = a.sums[0], s_y = a.sums[1];
+    const float gd = s_d > 0.f ? a.g2[0] / (2.f * sqrtf(s_d) * sqrtf(s_y)) : 0.f;
+    const float gl = a.g2[1] * a.inv_n;
     float* dre = a.dspec + ((long)b * 2 * a.bins) * a.frames + col;
     float* dim = dre + (long)a.bins * a.frames;
 #pragma unroll
@@ -130,8 +143,9 @@ __global__ __launch_bounds__(256) void stft_loss_kernel(StftLossArgs a) {
   }
 }
 
-// sums[j] = sum_u partial[u][j]  (one workgroup, fixed order)
-__global__ __launch_bounds__(256) void stft_loss_finish_kernel(const float* partial, int units, float* sums) {
+// sums[j] = sum_u partial[u][j]  (one workgroup, fixed order); sums[3] = spectral convergence
+// sqrt(S_d) / sqrt(S_y) (losses/stft_loss.py:61), sums[4] = log-magnitude L1 mean S_l / n (:82)
+__global__ __launch_bounds__(256) void stft_loss_finish_kernel(const float* partial, int units, float* sums, float inv_n) {
   __shared__ float red[3][4];
   float s[3] = {0.f, 0.f, 0.f};
   for (int u = threadIdx.x; u < units; u += 256) {
@@ -145,7 +159,13 @@ __global__ __launch_bounds__(256) void stft_loss_finish_kernel(const float* part
     if ((threadIdx.x & 63) == 0) red[j][threadIdx.x >> 6] = s[j];
   }
   __syncthreads();
-  if (threadIdx.x < 3) sums[threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+  if (threadIdx.x == 0) {
+    float t[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) t[j] = sums[j] = (red[j][0] + red[j][1]) + (red[j][2] + red[j][3]);
+    sums[3] = sqrtf(t[0]) / sqrtf(t[1]);
+    sums[4] = t[2] * inv_n;
+  }
 }
 
 
@@ -342,7 +362,9 @@ static int fill(StftLossArgs* a, const float* fx, const float* fy, const float* 
   a->m_pad = a->ngroups * 64;
   a->eps = eps;
   a->partial = nullptr;
-  a->g3 = nullptr;
+  a->g2 = nullptr;
+  a->sums = nullptr;
+  a->inv_n = (float)(1.0 / ((double)batch * bins * frames));
   a->dspec = nullptr;
   return PWG_OK;
 }
@@ -371,11 +393,12 @@ extern "C" int pwg_stft_loss_forward(const float* fx, const float* fy, const flo
   // algorithmic: 2 signals x 2 (re, im) x bins x frames x (taps * hop) MACs; bytes: the two folded signals
   const double flops = 2.0 * 4.0 * a.ngroups * 32.0 * a.ftiles * 32.0 * batch * (double)taps * hop;
   const double bytes = 2.0 * 4.0 * (double)batch * hop * n_cols;
-  (void)hipMemsetAsync(workspace, 0, (size_t)blocks * 16 * sizeof(float), stream);
+  // (no memset of the workspace: every wave of every workgroup writes its slot, surplus waves write zeros)
   {
     ProfScope prof(stream, "stft_loss_fwd_kernel", flops, bytes);
     hipLaunchKernelGGL(stft_loss_kernel<false>, dim3(blocks), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(stft_loss_finish_kernel, dim3(1), dim3(256), 0, stream, (const float*)workspace, blocks * 4, sums);
+    hipLaunchKernelGGL(stft_loss_finish_kernel, dim3(1), dim3(256), 0, stream, (const float*)workspace, blocks * 4, sums,
+                       a.inv_n);
   }
   PWG_CHECK_LAUNCH("stft_loss_forward");
   return PWG_OK;
@@ -383,12 +406,13 @@ extern "C" int pwg_stft_loss_forward(const float* fx, const float* fy, const flo
 
 extern "C" int pwg_stft_loss_backward(const float* fx, const float* fy, const float* basis, int32_t batch, int32_t hop,
                                       int32_t n_cols, int32_t taps, int32_t bins, int32_t frames, float eps,
-                                      const float* g3, float* dspec, void* stream_) {
+                                      const float* sums, const float* g2, float* dspec, void* stream_) {
   StftLossArgs a;
   const int rc = fill(&a, fx, fy, basis, batch, hop, n_cols, taps, bins, frames, eps, "stft_loss_backward");
   if (rc != PWG_OK) return rc;
-  PWG_REQUIRE(g3 && dspec, PWG_ERR_NULL, "stft_loss_backward: NULL pointer");
-  a.g3 = g3;
+  PWG_REQUIRE(sums && g2 && dspec, PWG_ERR_NULL, "stft_loss_backward: NULL pointer");
+  a.g2 = g2;
+  a.sums = sums;
   a.dspec = dspec;
   hipStream_t stream = (hipStream_t)stream_;
   const int units = a.batch * a.ngroups * a.ftiles;

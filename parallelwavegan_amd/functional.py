@@ -185,7 +185,7 @@ class FusedConvFn(torch.autograd.Function):
         if need_x:
             dx = ops.conv1d_backward_data(desc, gsum, ctx.holder.bwd(desc), x3).reshape(ctx.x_shape)
         wn_row_bytes = 4 * (ctx.w_shape[1] * ctx.w_shape[2])
-        if ctx.has_g and (need_w or need_g) and wn_row_bytes <= 64 * 1024:
+        if ctx.has_g and (need_w or need_g) and wn_row_bytes + 256 <= 64 * 1024:
             # weight-normalised layer: slabs -> (dv, dg) in one fused finishing kernel
             dv, dg, db = ops.conv1d_backward_weight_wn(desc, x3, gsum, v, g.reshape(-1),
                                                        need_db=need_b and has_bias)

@@ -88,9 +88,9 @@ class STFTMagnitude(torch.nn.Module):
     def forward(self, x):
         return Fn.StftMagFn.apply(self.spectrum(x), self.eps)
 
-    def pair_sums(self, x, y):
-        """Fused single-launch loss statistics of the pair: tensor [sum (|Y|-|X|)^2, sum |Y|^2,
-        sum |log|Y| - log|X||] over (B, bins, frames); differentiable w.r.t. ``x`` (``y`` is a constant)."""
+    def pair_losses(self, x, y):
+        """Fused single-launch losses of the pair: 2-element tensor [spectral convergence ||Y| - |X||_F / ||Y||_F,
+        mean |log|Y| - log|X||] over (B, bins, frames); differentiable w.r.t. ``x`` (``y`` is a constant)."""
         return StftPairSumsFn.apply(x, y.detach(), self)
 
 
@@ -120,27 +120,27 @@ class StftPairSumsFn(torch.autograd.Function):
             _lib.check(L.pwg_frame_fold_forward(_ptr(src), _ptr(dst), b, t, pad, mod.hop_size, n_cols, _stream()),
                        "frame_fold_forward")
         ws = torch.empty(L.pwg_stft_loss_workspace_floats(b, mod.bins, frames), device=x.device, dtype=torch.float32)
-        sums = torch.empty(3, device=x.device, dtype=torch.float32)
+        sums = torch.empty(5, device=x.device, dtype=torch.float32)  # [S_d, S_y, S_l, sc, mag]
         _lib.check(L.pwg_stft_loss_forward(_ptr(fx), _ptr(fy), _ptr(mod.pair_basis), b, mod.hop_size, n_cols, mod.taps,
                                            mod.bins, frames, float(mod.eps), _ptr(ws), _ptr(sums), _stream()),
                    "stft_loss_forward")
-        ctx.save_for_backward(fx, fy)
+        ctx.save_for_backward(fx, fy, sums)
         ctx.mod, ctx.dims = mod, (b, t, frames, n_cols, pad)
-        return sums
+        return sums[3:]
 
     @staticmethod
-    def backward(ctx, g3):
+    def backward(ctx, g2):
         from .. import _lib, ops
         from ..ops import _ptr, _stream
 
-        fx, fy = ctx.saved_tensors
+        fx, fy, sums = ctx.saved_tensors
         mod = ctx.mod
         b, t, frames, n_cols, pad = ctx.dims
-        g3 = g3.contiguous()
+        g2 = g2.contiguous()
         L = _lib.lib()
         dspec = torch.empty(b, 2 * mod.bins, frames, device=fx.device, dtype=torch.float32)
         _lib.check(L.pwg_stft_loss_backward(_ptr(fx), _ptr(fy), _ptr(mod.pair_basis), b, mod.hop_size, n_cols, mod.taps,
-                                            mod.bins, frames, float(mod.eps), _ptr(g3), _ptr(dspec), _stream()),
+                                            mod.bins, frames, float(mod.eps), _ptr(sums), _ptr(g2), _ptr(dspec), _stream()),
                    "stft_loss_backward")
         # d folded = transposed windowed DFT of (d re | d im): the data gradient of the DFT convolution
         desc = ops.make_conv_desc(b, mod.hop_size, 2 * mod.bins, n_cols, frames, mod.taps)

@@ -54,10 +54,9 @@ class STFTLoss(torch.nn.Module):
         """x: predicted (B, T), y: ground truth (B, T) -> (sc_loss, mag_loss)."""
         if self.fused and not (torch.is_grad_enabled() and y.requires_grad):
             # frame -> windowed DFT (MFMA) -> magnitude -> log -> the three sums, for both signals, in one
-            # kernel; the two losses are 0-dim arithmetic on the sums (stft_loss.py:61, :82)
-            s = self.stft_magnitude.pair_sums(x, y)
-            n = x.shape[0] * self.stft_magnitude.bins * self.stft_magnitude.frames(x.shape[1])
-            return torch.sqrt(s[0]) / torch.sqrt(s[1]), s[2] / n
+            # kernel; its finish forms the two losses (stft_loss.py:61, :82) -- no 0-dim ATen arithmetic
+            l2 = self.stft_magnitude.pair_losses(x, y)
+            return l2[0], l2[1]
         x_mag = self.stft_magnitude(x)
         y_mag = self.stft_magnitude(y)
         return self.spectral_convergence_loss(x_mag, y_mag), self.log_stft_magnitude_loss(x_mag, y_mag)

@@ -123,6 +123,7 @@ class _FusedBase(torch.optim.Optimizer):
             d["graph_tables"].append((pin, dev))  # keep the memcpy node's source and target alive, untouched
             return dev, arr.shape[0]
         _reserve(d["reserve"], arr.shape[0])
+        d["rows"] = arr.shape[0]
         key = hash(arr.tobytes())
         if key == d["table_key"] and d["table_dev"] is not None:
             return d["table_dev"], d["n_chunks"]  # same pointers as the previous eager step: table still valid
@@ -130,6 +131,14 @@ class _FusedBase(torch.optim.Optimizer):
         dev = pin.to(device, non_blocking=True)
         d["table_dev"], d["table_key"], d["n_chunks"] = dev, key, arr.shape[0]
         return dev, arr.shape[0]
+
+    def reserve_for_capture(self):
+        """Called by the trainer right BEFORE it starts capturing a step: make sure every group has a pinned
+        chunk-table buffer for that capture (eager steps reserve one, but a capture consumes it, and a second
+        capture -- another batch shape -- may follow without an eager step of this optimizer in between)."""
+        for d in self._dev.values():
+            if d.get("rows"):
+                _reserve(d["reserve"], d["rows"])
 
     # ---- to be provided by subclasses
     def _hyper(self, group, t):
@@ -259,6 +268,7 @@ def clip_grad_norm_(params_and_grads, max_norm):
         _GRAPH_KEEP.append(pin)  # the captured memcpy node re-reads it at every replay
     else:
         _reserve(pool, arr.shape[0])
+        _CLIP_ROWS[id(pool)] = (pool, arr.shape[0])
         table = torch.from_numpy(arr).pin_memory().to(dev, non_blocking=True)  # fresh staging per call
     out = torch.empty(2, device=dev, dtype=torch.float32)
     ws = torch.empty(len(rows), device=dev, dtype=torch.float32)
@@ -269,5 +279,12 @@ def clip_grad_norm_(params_and_grads, max_norm):
     return out
 
 
+def reserve_clip_tables_for_capture():
+    """Counterpart of :meth:`_FusedBase.reserve_for_capture` for the gradient-clipping chunk tables."""
+    for pool, rows in _CLIP_ROWS.values():
+        _reserve(pool, rows)
+
+
 _GRAPH_KEEP = []
 _CLIP_RESERVE = {}
+_CLIP_ROWS = {}

@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 from oracle import ref_shim  # noqa: E402
 from tests.golden import synth  # noqa: E402
 
-OUT = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("GOLDEN_OUT", os.path.dirname(os.path.abspath(__file__)))  # (GOLDEN_OUT: calibration runs)
 warnings.filterwarnings("ignore")
 G_SCALE = 1.25
 
@@ -410,6 +410,87 @@ def mb_melgan_train_steps(name, seed, n_steps=2):
     print(name, {k: round(float(v), 6) for k, v in out.items() if k.startswith("step")})
 
 
+def train_full_shape(name, tag, seed):
+    """ONE ``Trainer._train_step`` of the unmodified reference at a BASELINE configuration's OWN batch shape
+    (C2 6 x 25600, C3 16 x 8192, C4 64 x 16384): the tile / split-K / slab plans the HIP
+    engine selects at these sizes are the ones the benchmark times, and the B = 2 fixtures never exercise them.
+    Same stored quantities as ``_run_reference_trainer`` (losses, per-tensor first-moment norms, <update, moment>)."""
+    import parallel_wavegan.layers as RLy
+    import parallel_wavegan.losses as RL
+    import parallel_wavegan.models as RM
+    from parallel_wavegan.optimizers import RAdam
+
+    yaml_name = {"c2": "parallel_wavegan.v1.yaml", "c3": "hifigan.v1.yaml", "c4": "multi_band_melgan.v2.yaml"}[tag]
+    cfg = _load_yaml(yaml_name)
+    cfg["discriminator_train_start_steps"] = 0
+    cfg["generator_train_start_steps"] = 0
+    b, t, hop = cfg["batch_size"], cfg["batch_max_steps"], cfg["hop_size"]
+    gcls = getattr(RM, cfg.get("generator_type", "ParallelWaveGANGenerator"))
+    dcls = getattr(RM, cfg.get("discriminator_type", "ParallelWaveGANDiscriminator"))
+    g, d = gcls(**cfg["generator_params"]), dcls(**cfg["discriminator_params"])
+    gs, ds = {"c2": (synth.PWG_G_SCALE, 1.4), "c3": (G_SCALE, 1.0), "c4": (synth.MELGAN_G_SCALE, 1.2)}[tag]
+    g.load_state_dict(synth.synth_state_dict(g.state_dict(), seed=seed, g_scale=gs))
+    d.load_state_dict(synth.synth_state_dict(d.state_dict(), seed=seed + 1, g_scale=ds))
+    model = {"generator": g, "discriminator": d}
+    criterion = {"gen_adv": RL.GeneratorAdversarialLoss(**cfg.get("generator_adv_loss_params", {})),
+                 "dis_adv": RL.DiscriminatorAdversarialLoss(**cfg.get("discriminator_adv_loss_params", {}))}
+    if cfg.get("use_stft_loss", True):
+        criterion["stft"] = RL.MultiResolutionSTFTLoss(**cfg["stft_loss_params"])
+    if cfg.get("use_subband_stft_loss", False):
+        criterion["sub_stft"] = RL.MultiResolutionSTFTLoss(**cfg["subband_stft_loss_params"])
+    if cfg["generator_params"]["out_channels"] > 1:
+        criterion["pqmf"] = RLy.PQMF(subbands=cfg["generator_params"]["out_channels"])
+    if cfg.get("use_mel_loss", False):
+        criterion["mel"] = RL.MelSpectrogramLoss(**cfg["mel_loss_params"])
+    if cfg.get("use_feat_match_loss", False):
+        criterion["feat_match"] = RL.FeatureMatchLoss(**cfg.get("feat_match_loss_params", {}))
+    cfg.setdefault("use_stft_loss", True)
+    for k in ("use_subband_stft_loss", "use_mel_loss", "use_feat_match_loss"):
+        cfg.setdefault(k, False)
+    opt_cls = {"RAdam": RAdam, "Adam": torch.optim.Adam}
+    optimizer = {k: opt_cls[cfg.get(f"{k}_optimizer_type", "RAdam")](model[k].parameters(), **cfg[f"{k}_optimizer_params"])
+                 for k in ("generator", "discriminator")}
+    scheduler = {k: getattr(torch.optim.lr_scheduler, cfg.get(f"{k}_scheduler_type", "StepLR"))(
+        optimizer[k], **cfg[f"{k}_scheduler_params"]) for k in ("generator", "discriminator")}
+    acw = cfg["generator_params"].get("aux_context_window", 0)
+    c = synth.synth_input("c", (b, cfg["num_mels"], t // hop + 2 * acw), seed=seed)
+    y = 0.5 * synth.synth_input("y", (b, 1, t), seed=seed)
+    x = (c,)
+    if tag == "c2":
+        x = (synth.synth_input("z", (b, 1, t), seed=seed), c)
+    import time
+
+    t0 = time.time()
+    # The reference forms the spectral-convergence loss with fp32 torch.norm over up to 13 M magnitudes; at these
+    # sizes that accumulation alone is 4e-4 .. 6e-4 away from exact arithmetic (the ratio of the two norms
+    # 1e-5 .. 2e-4).  Stored next to the reference's own values: the same loss from the reference's (fp32)
+    # generator output with the STFT, the clamp, the square root and both norms evaluated in float64.
+    sc64 = {}
+    if "stft" in criterion:
+        def sc_double(crit, xh, yt):
+            xh, yt = xh.reshape(-1, xh.size(-1)).double(), yt.reshape(-1, yt.size(-1)).double()
+            tot = 0.0
+            for f in crit.stft_losses:
+                mags = []
+                for sig in (xh, yt):
+                    sp = torch.stft(sig, f.fft_size, f.shift_size, f.win_length, f.window.double(), return_complex=True)
+                    mags.append(torch.sqrt(torch.clamp(sp.real ** 2 + sp.imag ** 2, min=1e-7)))
+                tot += float(torch.norm(mags[1] - mags[0], p="fro") / torch.norm(mags[1], p="fro"))
+            return tot / len(crit.stft_losses)
+
+        with torch.no_grad():
+            y_hat = g(*x)
+            if "pqmf" in criterion:
+                sc64["sub"] = sc_double(criterion["sub_stft"], y_hat, criterion["pqmf"].analysis(y))
+                y_hat = criterion["pqmf"].synthesis(y_hat)
+            sc64["full"] = sc_double(criterion["stft"], y_hat.squeeze(1), y.squeeze(1))
+    out = _run_reference_trainer(cfg, model, criterion, optimizer, scheduler, [(x, y)], 1)
+    for k, v in sc64.items():
+        out[f"sc64/{k}"] = np.float64(v)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), meta=np.array([b, t, seed]), **out)
+    print(name, f"{time.time() - t0:.0f} s", {k: round(float(v), 6) for k, v in out.items() if k.startswith("step")})
+
+
 def causal_variants(name, seed):
     """Forward outputs of the use_causal_conv=True generators and of the residual PWG discriminator."""
     import parallel_wavegan.models as RM
@@ -504,11 +585,14 @@ JOBS = {
     "losses": lambda: losses("losses", 31),
     "adv_losses": lambda: adv_losses("adv_losses", 33),
     "hifigan_v1_train": lambda: hifigan_train_steps("hifigan_v1_train", 41),
+    "c2_train_full": lambda: train_full_shape("c2_train_full", "c2", 171),
+    "c3_train_full": lambda: train_full_shape("c3_train_full", "c3", 141),
+    "c4_train_full": lambda: train_full_shape("c4_train_full", "c4", 181),
 }
 
 if __name__ == "__main__":
     ref_shim.install()
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", os.cpu_count())))
     names = sys.argv[1:] or list(JOBS)
     for n in names:
         JOBS[n]()

@@ -146,7 +146,19 @@ def test_hip_graph_two_batch_shapes_without_host_syncs(device):
     scalars (lr, bias corrections) staged by the host must not be overwritten before their upload ran."""
     from tests.golden import synth
 
-    order = [0, 0, 0, 1, 1, 1, 0, 1, 0, 1, 1, 0]  # step 3 of each shape captures; later ones replay
+    _two_shapes(device, [0, 0, 0, 1, 1, 1, 0, 1, 0, 1, 1, 0])  # step 3 of each shape captures; later ones replay
+
+
+def test_hip_graph_two_batch_shapes_interleaved(device):
+    """The same with the shapes alternating from the start (a 2-rank epoch over few utterances: full batch, partial
+    batch, full, partial ...): the two captures follow each other with no eager optimizer step in between, so each
+    needs its own pinned chunk-table staging (reserved right before the capture)."""
+    _two_shapes(device, [0, 1, 0, 1, 0, 1, 1, 0, 0, 1])
+
+
+def _two_shapes(device, order):
+    from tests.golden import synth
+
     finals = {}
     for use_graph in (False, True):
         tr, _, model, opt = build_trainer(device, 43, 1.25, 2, len(order))

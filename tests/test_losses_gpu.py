@@ -133,6 +133,19 @@ def test_fused_stft_loss_is_deterministic_and_handles_ragged_tiles(device):
         assert _rel(g_fused.cpu().numpy(), x.grad.cpu().numpy()) <= 2e-3
 
 
+def test_fused_stft_loss_of_identical_signals_has_a_zero_gradient(device):
+    """x == y: ||Y| - |X||_F = 0.  torch.norm(p="fro") returns a zero subgradient there (stft_loss.py:61); sqrt's own
+    backward would give inf, and inf * 0 = NaN in every bin."""
+    from parallelwavegan_amd.losses.stft_loss import STFTLoss
+
+    y = (0.5 * synth.synth_input("fy", (2, 3000), seed=9)).to(device)
+    x = y.clone().requires_grad_()
+    sc, mag = STFTLoss(512, 120, 400).to(device)(x, y)
+    assert sc.item() == 0.0 and mag.item() == 0.0
+    (sc + mag).backward()
+    assert torch.isfinite(x.grad).all() and float(x.grad.abs().max()) == 0.0
+
+
 def test_fused_mel_loss_log_bases_and_ragged_shapes(device):
     """log10 / log2 / ln, a mel count that is not a multiple of 32, frame counts off the tile grid: the fused
     kernel equals the op-by-op chain in value and gradient, and two runs are bit-identical."""

@@ -24,3 +24,45 @@ def max_abs(a, b):
     b = torch.as_tensor(b).detach().cpu().double()
     assert a.shape == b.shape, (a.shape, b.shape)
     return (a - b).abs().max().item()
+
+
+class poison_empty:
+    """Context manager: every floating-point ``torch.empty`` / ``torch.empty_like`` / ``Tensor.new_empty`` on a
+    GPU returns NaN-filled memory (the fill is an ordinary kernel, so it is also recorded in captured hipGraphs
+    and re-run at every replay).  A kernel that reads a workspace element nobody wrote -- harmless on a fresh
+    process where new memory happens to be zero, non-finite once the caching allocator recycles blocks -- then
+    fails deterministically (C2's ``losses_finite: false`` only inside the long bench process)."""
+
+    def __enter__(self):
+        self._orig = (torch.empty, torch.empty_like, torch.Tensor.new_empty)
+        o_empty, o_like, o_new = self._orig
+
+        def fill(t):
+            if t.is_cuda and t.is_floating_point() and t.numel():
+                t.fill_(float("nan"))
+            return t
+
+        torch.empty = lambda *a, **k: fill(o_empty(*a, **k))
+        torch.empty_like = lambda *a, **k: fill(o_like(*a, **k))
+        torch.Tensor.new_empty = lambda self_, *a, **k: fill(o_new(self_, *a, **k))
+        return self
+
+    def __exit__(self, *exc):
+        torch.empty, torch.empty_like, torch.Tensor.new_empty = self._orig
+        return False
+
+
+class poison_lds:
+    """Context manager: NaN-fill every CU's LDS before each MFMA kernel launch (``pwg_debug_poison_lds``)."""
+
+    def __enter__(self):
+        from parallelwavegan_amd import _lib
+
+        self._was = _lib.lib().pwg_debug_poison_lds(1)
+        return self
+
+    def __exit__(self, *exc):
+        from parallelwavegan_amd import _lib
+
+        _lib.lib().pwg_debug_poison_lds(self._was)
+        return False

@@ -8,7 +8,7 @@ from parallelwavegan_amd import ops
 
 CFG = {0:(128,128,8),1:(128,128,16),2:(128,128,4),3:(64,256,8),4:(64,256,16),5:(32,256,8),6:(32,256,16),7:(32,512,8),
        8:(32,512,16),9:(128,64,8),10:(32,128,8),11:(64,256,4),12:(64,128,8),13:(64,64,8),14:(128,32,8),15:(64,64,16),
-       16:(32,128,16),17:(64,64,4)}
+       16:(32,128,16),17:(64,64,4),18:(128,256,4),19:(128,256,8)}
 
 def timeit(fn, reps=10):
     for _ in range(2): fn()
