@@ -70,6 +70,18 @@ void maybe_poison_lds(hipStream_t stream);
 // correctness depended on such a node (the unwritten tail of the partial-sum array).  Kernel nodes only.
 void zero_fill(float* p, long n, hipStream_t stream);
 
+// gconv.hip: grouped k = 41 strided convolutions with 4 / 8 input channels per group on the 16 x 16 x 4 MFMA
+// (`d` is always the FORWARD descriptor of the layer)
+bool gconv_forward_applicable(const pwg_conv1d_desc* d, const float* add1, const float* add2);
+int gconv_forward(const pwg_conv1d_desc* d, const float* x, const float* wp, const float* bias, float* y, hipStream_t stream);
+bool gconv_dgrad_applicable(const pwg_conv1d_desc* d);
+int gconv_backward_data(const pwg_conv1d_desc* d, const float* dy, const float* wp_bwd, const float* x_fwd, const float* accum,
+                        float* dx, hipStream_t stream);
+bool gconv_wgrad_applicable(const pwg_conv1d_desc* d);
+size_t gconv_wgrad_workspace_floats(const pwg_conv1d_desc* d);
+int gconv_backward_weight(const pwg_conv1d_desc* d, const float* x, const float* dy, float* dw, float* db, float* workspace,
+                          size_t ws_floats, hipStream_t stream);
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 

@@ -1259,6 +1259,7 @@ extern "C" int pwg_conv1d_forward(const pwg_conv1d_desc* d_in, const float* x, c
   Geometry g;
   int rc = make_geometry(d, &g);
   if (rc != PWG_OK) return rc;
+  if (gconv_forward_applicable(d, add1, add2)) return gconv_forward(d, x, w_packed, bias, y, (hipStream_t)stream);
   if (!d->transposed && d->groups == 1 && d->width == 1 && d->stride == 1 && d->pad_mode == PWG_PAD_ZERO &&
       d->c_out <= 4 && d->c_out * d->c_in * d->kernel <= SC_MAXW && !add1 && !add2 && d->out_div == 1.0f &&
       d->t_out >= 4096 && (d->kernel - 1) * d->dilation <= 1024 &&
@@ -1331,6 +1332,7 @@ extern "C" int pwg_conv1d_backward_data(const pwg_conv1d_desc* d, const float* d
               "conv1d_backward_data: only zero padding (pad reflect/replicate inputs explicitly)");
   PWG_REQUIRE(d->pre_act == PWG_ACT_NONE || x != nullptr, PWG_ERR_NULL,
               "conv1d_backward_data: the forward input is needed for the pre-activation derivative");
+  if (gconv_dgrad_applicable(d)) return gconv_backward_data(d, dy, w_packed_bwd, x, accum, dx, (hipStream_t)stream);
   pwg_conv1d_desc dd;
   dual_desc(d, &dd);
   dd = flatten_width(dd);

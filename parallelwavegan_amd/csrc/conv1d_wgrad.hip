@@ -756,6 +756,7 @@ extern "C" size_t pwg_conv1d_backward_weight_workspace_floats(const pwg_conv1d_d
   int co_g, ci_g, n_cols;
   wgrad_roles(d, &co_g, &ci_g, &n_cols);
   const WgPlan p = wgrad_plan(co_g, ci_g, d->groups, d->kernel, d->stride, d->dilation, d->width, n_cols, d->batch);
+  if (gconv_wgrad_applicable(d)) return gconv_wgrad_workspace_floats(d);
   // one slab per reduction slice: dW plus the fused bias row
   return p.splits > 1 ? (size_t)p.splits * ((size_t)co_g * d->groups * ci_g * d->kernel + (size_t)co_g * d->groups) : 0;
 }
@@ -788,6 +789,19 @@ static int backward_weight_impl(const pwg_conv1d_desc* d_in, const float* x, con
     PWG_CHECK_LAUNCH("bias_grad");
   }
   if (!dw) return PWG_OK;
+  if (gconv_wgrad_applicable(d)) {
+    // few channels per group: 16 x 16 x 4 MFMA kernel of gconv.hip (bias gradient fused when dy is the G operand)
+    float* db_fused = fuse_bias ? db : nullptr;
+    if (wn == nullptr) return gconv_backward_weight(d, x, dy, dw, db_fused, workspace, workspace_floats, stream);
+    const size_t need = gconv_wgrad_workspace_floats(d);
+    PWG_REQUIRE(workspace && workspace_floats >= need, PWG_ERR_WORKSPACE,
+                "conv1d_backward_weight_wn: workspace of %zu floats needed, %zu given", need, workspace_floats);
+    const size_t w_elems = (size_t)d->c_out * (d->c_in / d->groups) * d->kernel;
+    float* dw_tmp = workspace + (need - w_elems - d->c_out);  // behind the slabs
+    const int rc = gconv_backward_weight(d, x, dy, dw_tmp, db_fused, workspace, need - w_elems - d->c_out, stream);
+    if (rc != PWG_OK) return rc;
+    return pwg_weight_norm_backward(dw_tmp, wn->v, wn->g, wn->dv, wn->dg, d->c_out, (int)(w_elems / d->c_out), stream);
+  }
   WgArgs a;
   const float slope = d->pre_act == PWG_ACT_LEAKY_RELU ? d->pre_slope : (d->pre_act == PWG_ACT_RELU ? 0.f : 1.f);
   PWG_REQUIRE(slope >= 0.f && slope <= 1.f, PWG_ERR_UNSUPPORTED,
@@ -876,6 +890,7 @@ extern "C" size_t pwg_conv1d_backward_weight_wn_workspace_floats(const pwg_conv1
   int co_g, ci_g, n_cols;
   wgrad_roles(d, &co_g, &ci_g, &n_cols);
   const WgPlan p = wgrad_plan(co_g, ci_g, d->groups, d->kernel, d->stride, d->dilation, d->width, n_cols, d->batch);
+  if (gconv_wgrad_applicable(d)) return gconv_wgrad_workspace_floats(d);
   // (+1: room for the summed gradient when the two-kernel finish is used)
   return (size_t)(p.splits + 1) * ((size_t)co_g * d->groups * ci_g * d->kernel + (size_t)co_g * d->groups);
 }
