@@ -215,6 +215,39 @@ int pwg_resunit_pack_weight(int32_t channels, int32_t kernel, const float* w, co
 int pwg_resunit_forward(const pwg_resunit_desc* d, const float* x, const float* w1_packed, const float* b1,
                         const float* w2_packed, const float* b2, const float* add2, float* y, void* stream);
 
+/* One gated residual layer of the Parallel WaveGAN generator as ONE launch (csrc/wavenet.hip):
+ *   z = conv_{k=3,dilation}(x) + b_dil + conv1x1_aux(c);  g = tanh(z[:64]) * sigmoid(z[64:]);
+ *   skips_out = (conv1x1_skip(g) + b_skip + skips) * skip_mul;   x_out = (conv1x1_out(g) + b_out + x) * out_mul
+ * replacing the five ATen calls of WaveNetResidualBlock.forward (layers/residual_block.py:102-140) plus the
+ * running skip sum of the generator (models/parallel_wavegan.py:164-169).  Built for the PWG.v1 geometry
+ * (64 residual / 128 gate / 64 skip / 80 aux channels, kernel 3, non-causal); pwg_wavenet_layer_supported says so.
+ * x, skips, x_out, skips_out, g_out: (batch, 64, t); c: (batch, 80, t) (the upsampled mel); z_out: (batch, 128, t).
+ * skips may be NULL (first layer); skips_out may alias skips; x_out must not alias x.  z_out / g_out (both or
+ * neither; NULL in inference) receive the gate input and output for the backward pass.
+ * `packed`: pwg_wavenet_pack_weights image of the four torch-layout weights w_dil (128, 64, 3), w_aux (128, 80, 1),
+ * w_skip (64, 64, 1), w_out (64, 64, 1), each with an optional weight-norm row scale.                          */
+typedef struct pwg_wavenet_desc {
+  int32_t batch;
+  int32_t t;
+  int32_t residual_channels;
+  int32_t gate_channels;
+  int32_t skip_channels;
+  int32_t aux_channels;
+  int32_t kernel;
+  int32_t dilation;
+  int32_t causal;
+  float out_mul;   /* sqrt(0.5) */
+  float skip_mul;  /* 1, or sqrt(1 / layers) in the last layer */
+} pwg_wavenet_desc;
+int pwg_wavenet_layer_supported(const pwg_wavenet_desc* d);
+size_t pwg_wavenet_packed_weight_floats(const pwg_wavenet_desc* d);
+int pwg_wavenet_pack_weights(const pwg_wavenet_desc* d, const float* w_dil, const float* scale_dil, const float* w_aux,
+                             const float* scale_aux, const float* w_skip, const float* scale_skip, const float* w_out,
+                             const float* scale_out, float* packed, void* stream);
+int pwg_wavenet_layer_forward(const pwg_wavenet_desc* d, const float* x, const float* c, const float* skips,
+                              const float* packed, const float* b_dil, const float* b_skip, const float* b_out,
+                              float* x_out, float* skips_out, float* z_out, float* g_out, void* stream);
+
 /* Old-style torch.nn.utils.weight_norm (dim=0) scale: scale[i] = g[i]/||v[i,...]||_2
  * replaces torch._weight_norm at every conv call site.
  * v: (n0, inner) flattened, g: (n0).                                          */

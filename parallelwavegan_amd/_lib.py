@@ -40,6 +40,24 @@ class ConvDesc(ctypes.Structure):
     ]
 
 
+class WaveNetDesc(ctypes.Structure):
+    """Mirror of ``pwg_wavenet_desc`` (include/pwg_kernels.h)."""
+
+    _fields_ = [
+        ("batch", ctypes.c_int32),
+        ("t", ctypes.c_int32),
+        ("residual_channels", ctypes.c_int32),
+        ("gate_channels", ctypes.c_int32),
+        ("skip_channels", ctypes.c_int32),
+        ("aux_channels", ctypes.c_int32),
+        ("kernel", ctypes.c_int32),
+        ("dilation", ctypes.c_int32),
+        ("causal", ctypes.c_int32),
+        ("out_mul", ctypes.c_float),
+        ("skip_mul", ctypes.c_float),
+    ]
+
+
 class ResUnitDesc(ctypes.Structure):
     """Mirror of ``pwg_resunit_desc`` (include/pwg_kernels.h)."""
 
@@ -114,6 +132,10 @@ SIGNATURES = {
     "pwg_resunit_packed_weight_floats": (ctypes.c_size_t, [_i32, _i32]),
     "pwg_resunit_pack_weight": (ctypes.c_int, [_i32, _i32, _vp, _vp, _vp, _vp]),
     "pwg_resunit_forward": (ctypes.c_int, [ctypes.POINTER(ResUnitDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pwg_wavenet_layer_supported": (ctypes.c_int, [ctypes.POINTER(WaveNetDesc)]),
+    "pwg_wavenet_packed_weight_floats": (ctypes.c_size_t, [ctypes.POINTER(WaveNetDesc)]),
+    "pwg_wavenet_pack_weights": (ctypes.c_int, [ctypes.POINTER(WaveNetDesc)] + [_vp] * 10),
+    "pwg_wavenet_layer_forward": (ctypes.c_int, [ctypes.POINTER(WaveNetDesc)] + [_vp] * 12),
     "pwg_act_backward": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _f32, _vp]),
     "pwg_add3_div": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _vp]),
     "pwg_wave_to_pcm16": (ctypes.c_int, [_vp, _vp, _i64, _vp]),

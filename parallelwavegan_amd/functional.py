@@ -86,10 +86,19 @@ class PreparedWeights:
     keeps one instance per parameter epoch, so every forward / backward of that epoch -- e.g. D(y) and
     D(G(c)) of a discriminator phase -- shares a single scale + pack + pack launch sequence."""
 
-    __slots__ = ("key", "w", "scale", "fwd", "_bwd", "_res")
+    __slots__ = ("key", "w", "scale", "_fwd", "_fwd_desc", "_bwd", "_res")
 
-    def __init__(self, key, w, scale, fwd):
-        self.key, self.w, self.scale, self.fwd, self._bwd, self._res = key, w, scale, fwd, None, None
+    def __init__(self, key, w, scale, fwd=None, fwd_desc=None):
+        """``fwd``: the packed forward image, or None with ``fwd_desc`` (any descriptor of the layer) to build it
+        on first use -- layers that only run inside a fused multi-layer kernel never need it."""
+        self.key, self.w, self.scale, self._fwd, self._fwd_desc, self._bwd, self._res = key, w, scale, fwd, fwd_desc, None, None
+
+    @property
+    def fwd(self):
+        if self._fwd is None:
+            with torch.no_grad():
+                self._fwd = ops.pack_weight(self._fwd_desc, self.w, self.scale)
+        return self._fwd
 
     def res(self):
         """MFMA A-operand image for the one-launch residual unit (csrc/resunit.hip), built on first use."""
@@ -208,6 +217,118 @@ class FusedConvFn(torch.autograd.Function):
         dadd1 = gsum.reshape(gshape) if has_add1 and ctx.needs_input_grad[3] else None
         dadd2 = gsum.reshape(gshape) if has_add2 and ctx.needs_input_grad[4] else None
         return dx, dw, db, dadd1, dadd2, None, None, None, dg
+
+
+def conv_param_grads(desc, x3, gsum, w_shape3, w_orig_shape, v, g, need_w, need_g, need_b):
+    """(dw or dv, dg, db) of a convolution from its input ``x3`` and the gradient ``gsum`` w.r.t. its
+    pre-activation output: the weight-gradient kernel + the weight-norm finish when ``g`` is given."""
+    dw = db = dg = None
+    has_g = g is not None
+    wn_row_bytes = 4 * (w_shape3[1] * w_shape3[2])
+    if has_g and (need_w or need_g) and wn_row_bytes + 256 <= 64 * 1024:
+        dv, dg, db = ops.conv1d_backward_weight_wn(desc, x3, gsum, v, g.reshape(-1), need_db=need_b)
+        dw = dv.reshape(w_orig_shape)
+        dg = dg.reshape(g.shape)
+    elif need_w or need_g or need_b:
+        dw, db = ops.conv1d_backward_weight(desc, x3, gsum, w_shape3, need_dw=need_w or need_g, need_db=need_b)
+        if dw is not None and has_g:
+            dv = torch.empty_like(v)
+            dg = torch.empty_like(g)
+            n0 = v.shape[0]
+            _lib.check(_L().pwg_weight_norm_backward(_ptr(dw), _ptr(v), _ptr(g), _ptr(dv), _ptr(dg), n0,
+                                                     v.numel() // n0, _stream()), "weight_norm_backward")
+            dw = dv
+        if dw is not None:
+            dw = dw.reshape(w_orig_shape)
+    return dw, dg, db
+
+
+class WaveNetLayerFn(torch.autograd.Function):
+    """One gated residual layer of the Parallel WaveGAN generator: forward = ONE launch (csrc/wavenet.hip, also
+    writes the gate input z and output g for this backward); backward = the data / weight gradient kernels of
+    its four convolutions and the gate (layers/residual_block.py:102-140 of the reference).
+
+    ``block``: the :class:`layers.WaveNetResidualBlock` (weights, descriptors, cached images).  Tensor
+    arguments after it are the block's parameters in the order of ``block.fused_params()`` -- they are passed so
+    that autograd routes their gradients; values are read through ``block``."""
+
+    @staticmethod
+    def forward(ctx, x, c, skips, block, skip_scale, *params):
+        x, c = _c(x), _c(c)
+        skips = None if skips is None else _c(skips)
+        _require_device(x, c, skips)
+        desc = block.fused_desc(x.shape[0], x.shape[2], skip_scale)
+        convs = block.fused_convs()
+        x_out, s_out, z, gt = ops.wavenet_layer_forward(
+            desc, x, c, skips, block.fused_image(), *[None if cv.bias is None else cv.bias.detach()
+                                                       for cv in (convs[0], convs[2], convs[3])], save=True)
+        ctx.block, ctx.desc = block, desc
+        ctx.holders = [cv.prepared() for cv in convs]  # (the parameter values this forward used)
+        ctx.has_skips = skips is not None
+        ctx.save_for_backward(x, c, z, gt)
+        ctx.set_materialize_grads(False)
+        return x_out, s_out
+
+    @staticmethod
+    def backward(ctx, dx_out, ds_out):
+        x, c, z, gt = ctx.saved_tensors
+        block, desc = ctx.block, ctx.desc
+        conv_d, conv_a, conv_s, conv_o = block.fused_convs()
+        h_d, h_a, h_s, h_o = ctx.holders
+        b, t = x.shape[0], x.shape[2]
+        need = ctx.needs_input_grad
+        # gradients w.r.t. the pre-scale sums of the two 1x1 convolutions
+        go = gs = None
+        if dx_out is not None:
+            go = torch.empty_like(x)
+            _lib.check(_L().pwg_act_backward(_ptr(_c(dx_out)), None, _ptr(go), go.numel(), 0, 0.0, float(desc.out_mul),
+                                             _stream()), "act_backward")
+        if ds_out is not None:
+            gs = _c(ds_out)
+            if desc.skip_mul != 1.0:
+                tmp = torch.empty_like(gs)
+                _lib.check(_L().pwg_act_backward(_ptr(gs), None, _ptr(tmp), tmp.numel(), 0, 0.0, float(desc.skip_mul),
+                                                 _stream()), "act_backward")
+                gs = tmp
+        d_o, d_s = conv_o.make_desc(b, t), conv_s.make_desc(b, t)
+        d_d, d_a = conv_d.make_desc(b, t), conv_a.make_desc(b, t)
+        # d gate output = Wo^T go + Ws^T gs
+        dgt = None
+        if go is not None:
+            dgt = ops.conv1d_backward_data(d_o, go, h_o.bwd(d_o))
+        if gs is not None:
+            dgt = ops.conv1d_backward_data(d_s, gs, h_s.bwd(d_s), accum=dgt)
+        dz = torch.empty_like(z)
+        _lib.check(_L().pwg_gate_backward(_ptr(z), _ptr(dgt), _ptr(dz), b, z.shape[1] // 2, t, _stream()), "gate_backward")
+        dx = dc = None
+        if need[0]:
+            dx = ops.conv1d_backward_data(d_d, dz, h_d.bwd(d_d), accum=go)  # (+ the residual path)
+        if need[1]:
+            dc = ops.conv1d_backward_data(d_a, dz, h_a.bwd(d_a))
+        grads = []
+        pi = 5
+        for cv, hd, dsc, xin, gsum in ((conv_d, h_d, d_d, x, dz), (conv_a, h_a, d_a, c, dz), (conv_s, h_s, d_s, gt, gs),
+                                       (conv_o, h_o, d_o, gt, go)):
+            has_g = cv.has_weight_norm
+            n_par = 1 + int(has_g) + int(cv.bias is not None)
+            if gsum is None:
+                grads += [None] * n_par
+                pi += n_par
+                continue
+            need_w = need[pi]
+            need_g = has_g and need[pi + 1]
+            need_b = cv.bias is not None and need[pi + 1 + int(has_g)]
+            v = hd.w
+            g = cv.weight_g.detach() if has_g else None
+            dw, dg, db = conv_param_grads(dsc, xin, gsum, tuple(v.shape), tuple(cv.raw_weight.shape), v, g, need_w, need_g,
+                                          need_b)
+            grads.append(dw)
+            if has_g:
+                grads.append(dg)
+            if cv.bias is not None:
+                grads.append(db)
+            pi += n_par
+        return (dx, dc, (gs if ctx.has_skips else None), None, None) + tuple(grads)
 
 
 class Add3DivFn(torch.autograd.Function):

@@ -182,10 +182,10 @@ class _ConvNd(torch.nn.Module):
                 if self.has_weight_norm:
                     v = self._w3(self.weight_v.detach())
                     scale = ops.weight_norm_scale(v, self.weight_g.detach().reshape(-1).contiguous())
-                    self._cache_packed = Fn.PreparedWeights(key, v, scale, ops.pack_weight(desc, v, scale))
+                    self._cache_packed = Fn.PreparedWeights(key, v, scale, None, desc)
                 else:
                     w = self._w3(self.effective_weight())
-                    self._cache_packed = Fn.PreparedWeights(key, w, None, ops.pack_weight(desc, w))
+                    self._cache_packed = Fn.PreparedWeights(key, w, None, None, desc)
             self._cache_key = key
         return self._cache_packed
 

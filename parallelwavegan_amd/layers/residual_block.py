@@ -57,9 +57,68 @@ class WaveNetResidualBlock(torch.nn.Module):
         self.conv1x1_out = Conv1d1x1(gate_out_channels, residual_channels, bias=bias)
         self.conv1x1_skip = Conv1d1x1(gate_out_channels, skip_channels, bias=bias)
 
+    fuse_layer = True  # one launch per layer where csrc/wavenet.hip covers the geometry (PWG.v1: 64 / 128 / 64 / 80)
+
+    # ---- the one-launch layer (csrc/wavenet.hip)
+    def fused_convs(self):
+        return (self.conv, self.conv1x1_aux, self.conv1x1_skip, self.conv1x1_out)
+
+    def fused_params(self):
+        """Parameters in the order WaveNetLayerFn returns their gradients."""
+        ps = []
+        for cv in self.fused_convs():
+            ps.append(cv.raw_weight)
+            if cv.has_weight_norm:
+                ps.append(cv.weight_g)
+            if cv.bias is not None:
+                ps.append(cv.bias)
+        return ps
+
+    def fused_desc(self, batch, t, skip_scale=1.0):
+        return ops.make_wavenet_desc(batch, t, self.conv.dilation, self.conv.in_channels, self.conv.out_channels,
+                                     self.conv1x1_skip.out_channels,
+                                     0 if self.conv1x1_aux is None else self.conv1x1_aux.in_channels,
+                                     self.conv.kernel_size, self.use_causal_conv, math.sqrt(0.5), skip_scale)
+
+    def fused_image(self):
+        """MFMA A-operand image of the layer's four weights for the current parameter values."""
+        convs = self.fused_convs()
+        key = tuple(cv._params_key() for cv in convs)
+        if getattr(self, "_fused_key", None) != key:
+            hs = [cv.prepared() for cv in convs]
+            with torch.no_grad():
+                self._fused_img = ops.wavenet_pack_weights(self.fused_desc(1, 64), hs[0].w, hs[0].scale, hs[1].w,
+                                                           hs[1].scale, hs[2].w, hs[2].scale, hs[3].w, hs[3].scale)
+            self._fused_key = key
+        return self._fused_img
+
+    def _fusable(self, x, c):
+        if not self.fuse_layer or c is None or self.conv1x1_aux is None or x.dim() != 3 or not x.is_cuda:
+            return False
+        if self.use_causal_conv or (self.dropout > 0.0 and self.training):
+            return False
+        if any(cv.has_spectral_norm or cv.pad_mode != "zero" for cv in self.fused_convs()):
+            return False
+        if self.conv1x1_out.out_channels != self.conv.in_channels:
+            return False
+        return ops.wavenet_layer_supported(self.fused_desc(x.shape[0], x.shape[2]))
+
     def forward(self, x, c, skips=None, skip_scale=1.0):
         """Returns (x_out, skips + s) -- the running skip sum is an addend of the skip conv's epilogue
         (``skip_scale`` is the final ``sqrt(1/layers)`` of the generator, applied by the last block)."""
+        if self._fusable(x, c):
+            needs_grad = torch.is_grad_enabled() and (x.requires_grad or c.requires_grad
+                                                      or (skips is not None and skips.requires_grad)
+                                                      or any(p.requires_grad for p in self.fused_params()))
+            if needs_grad:
+                return Fn.WaveNetLayerFn.apply(x, c, skips, self, skip_scale, *self.fused_params())
+            with torch.no_grad():
+                convs = self.fused_convs()
+                b_d, b_s, b_o = (None if cv.bias is None else cv.bias.detach() for cv in (convs[0], convs[2], convs[3]))
+                x_out, s_out, _, _ = ops.wavenet_layer_forward(self.fused_desc(x.shape[0], x.shape[2], skip_scale),
+                                                               x.contiguous(), c.contiguous(), skips, self.fused_image(),
+                                                               b_d, b_s, b_o, skips_out=skips)
+                return x_out, s_out
         aux = self.conv1x1_aux(c) if (c is not None and self.conv1x1_aux is not None) else None
         # F.dropout on the dilated conv's input only; the residual path keeps x (residual_block.py:114-116)
         z = self.conv(self._drop(x), add1=aux)

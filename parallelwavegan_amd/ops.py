@@ -7,7 +7,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, ResUnitDesc
+from ._lib import ConvDesc, ResUnitDesc, WaveNetDesc
 
 ACT = {None: _lib.PWG_ACT_NONE, "none": _lib.PWG_ACT_NONE, "leaky_relu": _lib.PWG_ACT_LEAKY_RELU,
        "tanh": _lib.PWG_ACT_TANH, "relu": _lib.PWG_ACT_RELU}
@@ -144,6 +144,43 @@ def resunit_forward(desc, x, w1_packed, b1, w2_packed=None, b2=None, add2=None, 
     _lib.check(_lib.lib().pwg_resunit_forward(ctypes.byref(desc), _ptr(x), _ptr(w1_packed), _ptr(b1), _ptr(w2_packed),
                                               _ptr(b2), _ptr(add2), _ptr(out), _stream()), "resunit_forward")
     return out
+
+
+def make_wavenet_desc(batch, t, dilation, residual_channels=64, gate_channels=128, skip_channels=64, aux_channels=80,
+                      kernel=3, causal=False, out_mul=1.0, skip_mul=1.0):
+    return WaveNetDesc(int(batch), int(t), int(residual_channels), int(gate_channels), int(skip_channels),
+                       int(aux_channels), int(kernel), int(dilation), int(bool(causal)), float(out_mul), float(skip_mul))
+
+
+def wavenet_layer_supported(desc):
+    """Does the one-launch WaveNet layer (csrc/wavenet.hip) cover this geometry?"""
+    return bool(_lib.lib().pwg_wavenet_layer_supported(ctypes.byref(desc)))
+
+
+def wavenet_pack_weights(desc, w_dil, s_dil, w_aux, s_aux, w_skip, s_skip, w_out, s_out):
+    """The four torch-layout weights of a layer (+ optional weight-norm row scales) -> one MFMA A-operand image."""
+    _require_device(w_dil, s_dil, w_aux, s_aux, w_skip, s_skip, w_out, s_out)
+    out = torch.empty(_lib.lib().pwg_wavenet_packed_weight_floats(ctypes.byref(desc)), device=w_dil.device,
+                      dtype=torch.float32)
+    _lib.check(_lib.lib().pwg_wavenet_pack_weights(ctypes.byref(desc), _ptr(w_dil), _ptr(s_dil), _ptr(w_aux), _ptr(s_aux),
+                                                   _ptr(w_skip), _ptr(s_skip), _ptr(w_out), _ptr(s_out), _ptr(out),
+                                                   _stream()), "wavenet_pack_weights")
+    return out
+
+
+def wavenet_layer_forward(desc, x, c, skips, packed, b_dil, b_skip, b_out, save=False, skips_out=None):
+    """One gated residual layer in one launch -> (x_out, skips_out, z, g); ``z`` / ``g`` only with ``save``
+    (training: the backward pass needs them).  ``skips_out`` may be ``skips`` itself (in-place running sum)."""
+    _require_device(x, c, skips, packed, b_dil, b_skip, b_out, skips_out)
+    x_out = torch.empty_like(x)
+    if skips_out is None:
+        skips_out = torch.empty_like(x)
+    z = torch.empty((x.shape[0], desc.gate_channels, x.shape[2]), device=x.device, dtype=torch.float32) if save else None
+    g = torch.empty_like(x) if save else None
+    _lib.check(_lib.lib().pwg_wavenet_layer_forward(ctypes.byref(desc), _ptr(x), _ptr(c), _ptr(skips), _ptr(packed),
+                                                    _ptr(b_dil), _ptr(b_skip), _ptr(b_out), _ptr(x_out), _ptr(skips_out),
+                                                    _ptr(z), _ptr(g), _stream()), "wavenet_layer_forward")
+    return x_out, skips_out, z, g
 
 
 def pack_weight_bwd(desc, w, scale=None):
