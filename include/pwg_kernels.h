@@ -247,6 +247,21 @@ int pwg_wavenet_pack_weights(const pwg_wavenet_desc* d, const float* w_dil, cons
 int pwg_wavenet_layer_forward(const pwg_wavenet_desc* d, const float* x, const float* c, const float* skips,
                               const float* packed, const float* b_dil, const float* b_skip, const float* b_out,
                               float* x_out, float* skips_out, float* z_out, float* g_out, void* stream);
+/* Data path of the layer's backward pass in two launches (the weight gradients use pwg_conv1d_backward_weight*):
+ *   gate_backward: dz (batch, 128, t) = d loss / d z from dx_out, ds_out (gradients w.r.t. x_out / skips_out; dx_out
+ *     may be NULL) and the saved z -- the two 1x1 data gradients (K = 128), the out_mul / skip_mul scales and the
+ *     tanh * sigmoid derivative; also writes go = out_mul * dx_out (the residual-path gradient and the out-conv
+ *     weight-gradient operand; NULL with dx_out).
+ *   data_backward: dx = dilated-conv data gradient of dz (+ go) and dc = aux 1x1 data gradient of dz (either may be NULL).
+ * `packed_bwd`: pwg_wavenet_pack_weights_bwd image (depends on d->out_mul and d->skip_mul).                       */
+size_t pwg_wavenet_packed_weight_bwd_floats(const pwg_wavenet_desc* d);
+int pwg_wavenet_pack_weights_bwd(const pwg_wavenet_desc* d, const float* w_dil, const float* scale_dil, const float* w_aux,
+                                 const float* scale_aux, const float* w_skip, const float* scale_skip, const float* w_out,
+                                 const float* scale_out, float* packed, void* stream);
+int pwg_wavenet_gate_backward(const pwg_wavenet_desc* d, const float* z, const float* dx_out, const float* ds_out,
+                              const float* packed_bwd, float* dz, float* go, void* stream);
+int pwg_wavenet_data_backward(const pwg_wavenet_desc* d, const float* dz, const float* go, const float* packed_bwd, float* dx,
+                              float* dc, void* stream);
 
 /* Old-style torch.nn.utils.weight_norm (dim=0) scale: scale[i] = g[i]/||v[i,...]||_2
  * replaces torch._weight_norm at every conv call site.

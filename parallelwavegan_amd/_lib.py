@@ -136,6 +136,10 @@ SIGNATURES = {
     "pwg_wavenet_packed_weight_floats": (ctypes.c_size_t, [ctypes.POINTER(WaveNetDesc)]),
     "pwg_wavenet_pack_weights": (ctypes.c_int, [ctypes.POINTER(WaveNetDesc)] + [_vp] * 10),
     "pwg_wavenet_layer_forward": (ctypes.c_int, [ctypes.POINTER(WaveNetDesc)] + [_vp] * 12),
+    "pwg_wavenet_packed_weight_bwd_floats": (ctypes.c_size_t, [ctypes.POINTER(WaveNetDesc)]),
+    "pwg_wavenet_pack_weights_bwd": (ctypes.c_int, [ctypes.POINTER(WaveNetDesc)] + [_vp] * 10),
+    "pwg_wavenet_gate_backward": (ctypes.c_int, [ctypes.POINTER(WaveNetDesc)] + [_vp] * 7),
+    "pwg_wavenet_data_backward": (ctypes.c_int, [ctypes.POINTER(WaveNetDesc)] + [_vp] * 6),
     "pwg_act_backward": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _f32, _vp]),
     "pwg_add3_div": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _vp]),
     "pwg_wave_to_pcm16": (ctypes.c_int, [_vp, _vp, _i64, _vp]),

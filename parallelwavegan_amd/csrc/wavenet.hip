@@ -52,7 +52,20 @@ struct WnArgs {
   float* g_out;         // (B, 64, T) or NULL
   int T, dil, pad;      // pad: samples left of the first tap (d, or 2 d for the causal form)
   float out_mul, skip_mul;
+  int vec_ok;  // x_out / skips / skips_out are 16-B aligned
+  int dbg;  // timing experiments only (PWG_WN_DBG): 1 = phase-1 weights loaded once, 2 = no tanh / exp, 4 = no epilogue
+            // loads / stores, 8 = no operand DMA
 };
+
+// tanh(t) * sigmoid(s) on the hardware exp2 / rcp (1 ulp each): sigmoid(v) = 1 / (1 + 2^(-v log2 e)),
+// tanh(t) = 2 sigmoid(2 t) - 1; saturates correctly (2^inf = inf -> rcp = 0).  Absolute error ~1e-7, against
+// 8 % of the kernel for libm's tanhf + expf (profiles/r03_wavenet_ablation.txt).
+__device__ __forceinline__ float gate_fast(float t, float s) {
+  const float L2E = 1.4426950408889634f;
+  const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-s * L2E));
+  const float th = 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.f * L2E * t)) - 1.f;
+  return th * sg;
+}
 
 template <int AUX>
 __global__ __launch_bounds__(256, 2) void wavenet_layer_kernel(WnArgs a) {
@@ -74,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void wavenet_layer_kernel(WnArgs a) {
   {
     __amdgpu_buffer_rsrc_t x_rs = uniform_buffer_rsrc(a.x + (long)b * WN_R * T, (unsigned)(WN_R * T) * 4u);
     __amdgpu_buffer_rsrc_t c_rs = uniform_buffer_rsrc(a.c + (long)b * AUX * T, (unsigned)(AUX * T) * 4u);
-    for (int q = wave; q < ROWS / 4; q += 4) {  // 4 rows (1 KiB of LDS) per wave instruction
+    for (int q = wave; q < ((a.dbg & 8) ? 0 : ROWS / 4); q += 4) {  // 4 rows (1 KiB of LDS) per wave instruction
       const int r0 = 4 * q;
       const bool is_x = r0 < WN_K * WN_R;
       const int tap = r0 / WN_R;
@@ -131,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void wavenet_layer_kernel(WnArgs a) {
     for (int j = 0; j < 4; ++j) B0[j] = bl[(2 * j) * WN_COLS];
 #pragma unroll
     for (int q = 0; q < NQ1; ++q) {
-      const int qn = q + 2 < NQ1 ? q + 2 : NQ1 - 1;
+      const int qn = (a.dbg & 1) ? 0 : (q + 2 < NQ1 ? q + 2 : NQ1 - 1);
       A[(q + 2) % 3][0] = wa[(long)qn * 4 * 64];
       A[(q + 2) % 3][1] = wb[(long)qn * 4 * 64];
       float(&Bc)[4] = (q & 1) ? B1 : B0;
@@ -155,25 +168,64 @@ __global__ __launch_bounds__(256, 2) void wavenet_layer_kernel(WnArgs a) {
   const int n = n0 + cn * 32 + l31;
   const bool n_ok = n < T;
   __syncthreads();
+  float* scr = tile + 2 * WN_R * WN_COLS + wave * (2 * 32 * 36);  // wave-private scratch in the dead rows 128..
+  const int trow = lane >> 3, tcol = (lane & 7) * 4;
+  const int nq = n0 + cn * 32 + tcol;
+  const bool vec = ((T & 3) == 0) && a.vec_ok;
   {
-    const long zb = (long)b * WN_G * T + n;
-    const long gb = (long)b * WN_R * T + n;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = h * 32 + 8 * (r >> 2) + 4 * lhi + (r & 3);
+      const int rl = 8 * (r >> 2) + 4 * lhi + (r & 3);
       const float zt = acc[0][r] + bt[r], zs = acc[1][r] + bs[r];
-      const float g = tanhf(zt) * (1.f / (1.f + expf(-zs)));
-      tile[row * WN_COLS + cn * 32 + l31] = g;
-      if (a.z_out && n_ok) {
-        a.z_out[zb + (long)row * T] = zt;
-        a.z_out[zb + (long)(WN_R + row) * T] = zs;
+      const float g = (a.dbg & 2) ? zt * zs : gate_fast(zt, zs);
+      tile[(h * 32 + rl) * WN_COLS + cn * 32 + l31] = g;
+      if (a.z_out) {  // (training: the gate input goes out through the transposition scratch, 16-B stores)
+        scr[rl * 36 + l31] = zt;
+        scr[32 * 36 + rl * 36 + l31] = zs;
       }
-      if (a.g_out && n_ok) a.g_out[gb + (long)row * T] = g;
       acc[0][r] = 0.f;
       acc[1][r] = 0.f;
     }
+    if (a.z_out) {
+      const long zb = (long)b * WN_G * T + nq;
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const int rl = ps * 8 + trow;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const float4 v = *reinterpret_cast<const float4*>(scr + half * 32 * 36 + rl * 36 + tcol);
+          const long o = zb + (long)(half * WN_R + h * 32 + rl) * T;
+          if (vec) {
+            if (nq < T) *reinterpret_cast<float4*>(a.z_out + o) = v;
+          } else {
+            const float e4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (nq + e < T) a.z_out[o + e] = e4[e];
+          }
+        }
+      }
+    }
   }
   __syncthreads();
+  if (a.g_out) {
+    // the gate output tile is row-major in LDS: 64 rows x 16 float4, 4 per lane
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = i * 256 + tid;
+      const int row = idx >> 4, c4 = (idx & 15) * 4;
+      const float4 v = *reinterpret_cast<const float4*>(tile + row * WN_COLS + c4);
+      const long o = ((long)b * WN_R + row) * T + n0 + c4;
+      if (vec) {
+        if (n0 + c4 < T) *reinterpret_cast<float4*>(a.g_out + o) = v;
+      } else {
+        const float e4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n0 + c4 + e < T) a.g_out[o + e] = e4[e];
+      }
+    }
+  }
 
   // ---- phase 2: skip rows [32 h, +32) and out rows [32 h, +32) over K = 64 rows of g
   {
@@ -201,22 +253,50 @@ __global__ __launch_bounds__(256, 2) void wavenet_layer_kernel(WnArgs a) {
   }
 
   // ---- epilogue: D layout col = lane & 31 (time), rows as above
-  if (n_ok) {
-    const long ob = (long)b * WN_R * T + n;
-    float sk[16];
+  if (a.dbg & 4) {
+    if (acc[0][0] == 12345.678f && acc[1][3] == 1.f) a.x_out[0] = 1.f;
+    return;
+  }
+  // Each wave transposes its two 32 x 32 result tiles through a private scratch (rows 128.. of the operand tile: the
+  // last tap window and the aux rows are dead after phase 1) so that a lane owns 4 consecutive samples of a row:
+  // 16-B loads of the skip sum, 16-B stores of both outputs (the D layout gives a lane ONE sample of 16 rows, i.e.
+  // 48 dword accesses per lane: 14 % of the kernel).  The arithmetic per element is unchanged.
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = h * 32 + 8 * (r >> 2) + 4 * lhi + (r & 3);
-      sk[r] = a.skips ? a.skips[ob + (long)row * T] : 0.f;
-    }
+  for (int r = 0; r < 16; ++r) {
+    const int rl = 8 * (r >> 2) + 4 * lhi + (r & 3);
+    const float xc = tile[(WN_R + h * 32 + rl) * WN_COLS + cn * 32 + l31];  // centre window = x[n]
+    scr[rl * 36 + l31] = acc[0][r] + bsk[r];
+    scr[32 * 36 + rl * 36 + l31] = (acc[1][r] + bo[r] + xc) * a.out_mul;
+  }
+  // (wave-private scratch: no workgroup barrier, the wave's own LDS accesses are ordered)
+  const long ob = (long)b * WN_R * T + nq;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = h * 32 + 8 * (r >> 2) + 4 * lhi + (r & 3);
-      const float xc = tile[(WN_R + row) * WN_COLS + cn * 32 + l31];  // centre window = x[n] (non-causal: tap 1)
-      float s = acc[0][r] + bsk[r] + sk[r];
-      if (a.skip_mul != 1.0f) s *= a.skip_mul;
-      a.skips_out[ob + (long)row * T] = s;
-      a.x_out[ob + (long)row * T] = (acc[1][r] + bo[r] + xc) * a.out_mul;
+  for (int ps = 0; ps < 4; ++ps) {
+    const int rl = ps * 8 + trow;
+    const long o = ob + (long)(h * 32 + rl) * T;
+    float4 sv = *reinterpret_cast<const float4*>(scr + rl * 36 + tcol);
+    const float4 ov = *reinterpret_cast<const float4*>(scr + 32 * 36 + rl * 36 + tcol);
+    if (vec) {
+      if (nq < T) {  // (T % 4 == 0: a float4 is inside the sequence or outside it)
+        if (a.skips) {
+          const float4 k = *reinterpret_cast<const float4*>(a.skips + o);
+          sv.x += k.x; sv.y += k.y; sv.z += k.z; sv.w += k.w;
+        }
+        if (a.skip_mul != 1.0f) { sv.x *= a.skip_mul; sv.y *= a.skip_mul; sv.z *= a.skip_mul; sv.w *= a.skip_mul; }
+        *reinterpret_cast<float4*>(a.skips_out + o) = sv;
+        *reinterpret_cast<float4*>(a.x_out + o) = ov;
+      }
+    } else {
+      const float se[4] = {sv.x, sv.y, sv.z, sv.w}, oe[4] = {ov.x, ov.y, ov.z, ov.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (nq + e < T) {
+          float v = se[e] + (a.skips ? a.skips[o + e] : 0.f);
+          if (a.skip_mul != 1.0f) v *= a.skip_mul;
+          a.skips_out[o + e] = v;
+          a.x_out[o + e] = oe[e];
+        }
+      }
     }
   }
 }
@@ -248,6 +328,324 @@ __global__ void wavenet_pack_kernel(const float* w_dil, const float* s_dil, cons
       v = w_skip[(long)row * WN_R + kc] * (s_skip ? s_skip[row] : 1.f);
     } else {
       v = w_out[(long)(row - WN_S) * WN_R + kc] * (s_out ? s_out[row - WN_S] : 1.f);
+    }
+    out[i] = v;
+  }
+}
+
+
+// =====================================================================================================================
+// backward, data path.  Two launches per layer instead of six (scale of dx_out, two 1x1 data gradients, gate backward,
+// dilated data gradient, aux data gradient):
+//
+//   wavenet_gate_bwd_kernel : dg = Wo^T (out_mul dx_out) + Ws^T (skip_mul ds_out)   (K = 128, 64 rows)
+//                             dz = [dg * sg * (1 - th^2) ; dg * th * sg * (1 - sg)],  th = tanh(z[:64]), sg = sigmoid(z[64:])
+//                             go = out_mul * dx_out  (the residual-path / out-conv weight-gradient operand)
+//                             HBM-bound: 1792 B per sample for 16 KFLOP.
+//   wavenet_dgrad_kernel    : dx[ci][n] = sum_{t, co} Wd[co][ci][t] dz[co][n - (t - 1) d] + go[ci][n]      (K = 384, 64 rows)
+//                             dc[a][n]  = sum_co Wa[co][a] dz[co][n]                                       (K = 128, 80 rows)
+//                             with the three dz windows resident in LDS (384 rows x 32 columns, three workgroups per CU).
+// =====================================================================================================================
+struct WnBwdArgs {
+  const float* z;       // (B, 128, T)
+  const float* dx_out;  // (B, 64, T) or NULL (the last layer's x_out is unused)
+  const float* ds_out;  // (B, 64, T)
+  const float* dz_in;   // dgrad kernel: (B, 128, T)
+  const float* go_in;   // dgrad kernel: (B, 64, T) or NULL
+  const float* w;       // image of this kernel
+  float* dz;            // gate kernel out (B, 128, T)
+  float* go;            // gate kernel out (B, 64, T) or NULL
+  float* dx;            // dgrad kernel out (B, 64, T) or NULL
+  float* dc;            // dgrad kernel out (B, AUX, T) or NULL
+  int T, dil, aux;
+  float out_mul;
+  int vec_ok;
+};
+
+__global__ __launch_bounds__(256, 2) void wavenet_gate_bwd_kernel(WnBwdArgs a) {
+  constexpr int NQ = 16;  // K = 128: [ds_out rows | dx_out rows]
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [128][64] + 4 x [32][36] scratch
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = wave >> 1, cn = wave & 1;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int b = blockIdx.y;
+  const int n0 = blockIdx.x * WN_COLS;
+  const int T = a.T;
+  {
+    const float* any = a.ds_out;
+    __amdgpu_buffer_rsrc_t s_rs = uniform_buffer_rsrc(a.ds_out + (long)b * WN_S * T, (unsigned)(WN_S * T) * 4u);
+    __amdgpu_buffer_rsrc_t o_rs = uniform_buffer_rsrc((a.dx_out ? a.dx_out : any) + (long)b * WN_R * T,
+                                                      a.dx_out ? (unsigned)(WN_R * T) * 4u : 0u);  // NULL: every load is out of range = 0
+    for (int q = wave; q < 32; q += 4) {
+      const int r0 = 4 * q;
+      const bool is_s = r0 < WN_S;
+      const int ch0 = is_s ? r0 : r0 - WN_S;
+      if (__builtin_amdgcn_readfirstlane((n0 + WN_COLS <= T) ? 1 : 0)) {
+        const unsigned off = (unsigned)((ch0 + (lane >> 4)) * T + n0 + 4 * (lane & 15)) * 4u;
+        if (is_s) __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rs, (lds_ptr_t)(tile + r0 * WN_COLS), 16, off, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(o_rs, (lds_ptr_t)(tile + r0 * WN_COLS), 16, off, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int f = n0 + lane;
+          const unsigned off = f < T ? (unsigned)((ch0 + rr) * T + f) * 4u : 0xFFFFFFFCu;
+          if (is_s) __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rs, (lds_ptr_t)(tile + (r0 + rr) * WN_COLS), 4, off, 0, 0, 0);
+          else __builtin_amdgcn_raw_ptr_buffer_load_lds(o_rs, (lds_ptr_t)(tile + (r0 + rr) * WN_COLS), 4, off, 0, 0, 0);
+        }
+      }
+    }
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const float4* wa = reinterpret_cast<const float4*>(a.w) + (h * 64 + lane);  // image [q][2 tiles][lane][4]
+  float4 A[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) A[q] = wa[q * 2 * 64];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  {
+    const float* bl = tile + lhi * WN_COLS + cn * 32 + l31;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const float av[4] = {A[q].x, A[q].y, A[q].z, A[q].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bl[(8 * q + 2 * j) * WN_COLS], acc, 0, 0, 0);
+    }
+  }
+  // dg tile -> wave-private scratch -> a lane owns 4 consecutive samples of a row
+  float* scr = tile + WN_G * WN_COLS + wave * (32 * 36);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) scr[(8 * (r >> 2) + 4 * lhi + (r & 3)) * 36 + l31] = acc[r];
+  const int trow = lane >> 3, tcol = (lane & 7) * 4;
+  const int nq = n0 + cn * 32 + tcol;
+  const bool vec = ((T & 3) == 0) && a.vec_ok;
+  const float L2E = 1.4426950408889634f;
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    const int rl = ps * 8 + trow;
+    const int row = h * 32 + rl;
+    const float4 dg4 = *reinterpret_cast<const float4*>(scr + rl * 36 + tcol);
+    const long ot = ((long)b * WN_G + row) * T + nq, os = ot + (long)WN_R * T;
+    float zt[4], zs[4];
+    if (vec) {
+      if (nq >= T) continue;
+      const float4 t4 = *reinterpret_cast<const float4*>(a.z + ot), s4 = *reinterpret_cast<const float4*>(a.z + os);
+      zt[0] = t4.x; zt[1] = t4.y; zt[2] = t4.z; zt[3] = t4.w;
+      zs[0] = s4.x; zs[1] = s4.y; zs[2] = s4.z; zs[3] = s4.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        zt[e] = nq + e < T ? a.z[ot + e] : 0.f;
+        zs[e] = nq + e < T ? a.z[os + e] : 0.f;
+      }
+    }
+    const float dg[4] = {dg4.x, dg4.y, dg4.z, dg4.w};
+    float dt[4], dsg[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-zs[e] * L2E));
+      const float th = 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.f * L2E * zt[e])) - 1.f;
+      dt[e] = dg[e] * sg * (1.f - th * th);
+      dsg[e] = dg[e] * th * sg * (1.f - sg);
+    }
+    if (vec) {
+      *reinterpret_cast<float4*>(a.dz + ot) = make_float4(dt[0], dt[1], dt[2], dt[3]);
+      *reinterpret_cast<float4*>(a.dz + os) = make_float4(dsg[0], dsg[1], dsg[2], dsg[3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (nq + e < T) {
+          a.dz[ot + e] = dt[e];
+          a.dz[os + e] = dsg[e];
+        }
+    }
+  }
+  if (a.go && a.dx_out) {
+    // go = out_mul * dx_out from the staged rows 64..127 (row-major in LDS): 64 rows x 16 float4, 4 per lane
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = i * 256 + tid;
+      const int row = idx >> 4, c4 = (idx & 15) * 4;
+      float4 v = *reinterpret_cast<const float4*>(tile + (WN_S + row) * WN_COLS + c4);
+      v.x *= a.out_mul; v.y *= a.out_mul; v.z *= a.out_mul; v.w *= a.out_mul;
+      const long o = ((long)b * WN_R + row) * T + n0 + c4;
+      if (vec) {
+        if (n0 + c4 < T) *reinterpret_cast<float4*>(a.go + o) = v;
+      } else {
+        const float e4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n0 + c4 + e < T) a.go[o + e] = e4[e];
+      }
+    }
+  }
+}
+
+constexpr int WD_COLS = 32;  // columns per workgroup of the data-gradient kernel
+
+// D += A (image records `wa`, stride `rec_stride` float4 per record) x B (LDS rows starting at `bl`) over nq records
+template <int NTL>
+__device__ __forceinline__ void wn_contract(f32x16 (&acc)[NTL], const float4* const (&wa)[NTL], int rec_stride, int nq,
+                                            const float* bl) {
+  float4 A0[NTL], A1[NTL];
+#pragma unroll
+  for (int i = 0; i < NTL; ++i) A0[i] = wa[i][0];
+  for (int q = 0; q < nq; q += 2) {
+#pragma unroll
+    for (int i = 0; i < NTL; ++i) A1[i] = wa[i][(long)(q + 1 < nq ? q + 1 : q) * rec_stride];
+    {
+      float Bv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Bv[j] = bl[(8 * q + 2 * j) * WD_COLS];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < NTL; ++i) {
+          const float av = j == 0 ? A0[i].x : j == 1 ? A0[i].y : j == 2 ? A0[i].z : A0[i].w;
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Bv[j], acc[i], 0, 0, 0);
+        }
+    }
+    if (q + 1 < nq) {
+#pragma unroll
+      for (int i = 0; i < NTL; ++i) A0[i] = wa[i][(long)(q + 2 < nq ? q + 2 : q + 1) * rec_stride];
+      float Bv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Bv[j] = bl[(8 * (q + 1) + 2 * j) * WD_COLS];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < NTL; ++i) {
+          const float av = j == 0 ? A1[i].x : j == 1 ? A1[i].y : j == 2 ? A1[i].z : A1[i].w;
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Bv[j], acc[i], 0, 0, 0);
+        }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void wavenet_dgrad_kernel(WnBwdArgs a) {
+  constexpr int ROWS = WN_K * WN_G;  // 384: window t holds dz[:, n + (1 - t) d]
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [ROWS][32]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int b = blockIdx.y;
+  const int n0 = blockIdx.x * WD_COLS;
+  const int T = a.T;
+  {
+    __amdgpu_buffer_rsrc_t z_rs = uniform_buffer_rsrc(a.dz_in + (long)b * WN_G * T, (unsigned)(WN_G * T) * 4u);
+    for (int q = wave; q < ROWS / 8; q += 4) {  // 8 rows of 32 floats (1 KiB) per wave instruction
+      const int r0 = 8 * q;
+      const int t = r0 / WN_G;
+      const int f0 = n0 + (1 - t) * a.dil;
+      const int ch0 = r0 - t * WN_G;
+      if (__builtin_amdgcn_readfirstlane((f0 >= 0 && f0 + WD_COLS <= T) ? 1 : 0)) {
+        const unsigned off = (unsigned)((ch0 + (lane >> 3)) * T + f0 + 4 * (lane & 7)) * 4u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(z_rs, (lds_ptr_t)(tile + r0 * WD_COLS), 16, off, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {  // 2 rows per instruction on the per-sample path
+          const int f = f0 + l31;
+          const unsigned off = (f >= 0 && f < T) ? (unsigned)((ch0 + 2 * rr + lhi) * T + f) * 4u : 0xFFFFFFFCu;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(z_rs, (lds_ptr_t)(tile + (r0 + 2 * rr) * WD_COLS), 4, off, 0, 0, 0);
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int n = n0 + l31;
+  const bool n_ok = n < T;
+  const float4* w4 = reinterpret_cast<const float4*>(a.w);
+  const float* bl = tile + lhi * WD_COLS + l31;
+  if (wave < 2) {
+    // dx rows [32 wave, +32) over all three windows (K = 384): image [48][2 tiles][lane][4]
+    f32x16 acc[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+    const float4* const wa[1] = {w4 + wave * 64 + lane};
+    if (a.dx) wn_contract<1>(acc, wa, 2 * 64, ROWS / 8, bl);
+    if (a.dx && n_ok) {
+      const long ob = (long)b * WN_R * T + n;
+      float gv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wave * 32 + 8 * (r >> 2) + 4 * lhi + (r & 3);
+        gv[r] = a.go_in ? a.go_in[ob + (long)row * T] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wave * 32 + 8 * (r >> 2) + 4 * lhi + (r & 3);
+        a.dx[ob + (long)row * T] = acc[0][r] + gv[r];
+      }
+    }
+  } else if (a.dc) {
+    // dc rows over the centre window (K = 128, rows 128..255 of the tile): image [16][3 tiles][lane][4] behind the dx image
+    const float4* wc = w4 + (ROWS / 8) * 2 * 64;
+    const float* blc = bl + WN_G * WD_COLS;
+    const long ob = (long)b * a.aux * T + n;
+    if (wave == 2) {
+      f32x16 acc[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+      const float4* const wa[2] = {wc + lane, wc + 64 + lane};
+      wn_contract<2>(acc, wa, 3 * 64, WN_G / 8, blc);
+      if (n_ok) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = i * 32 + 8 * (r >> 2) + 4 * lhi + (r & 3);
+            if (row < a.aux) a.dc[ob + (long)row * T] = acc[i][r];
+          }
+      }
+    } else {
+      f32x16 acc[1];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+      const float4* const wa[1] = {wc + 2 * 64 + lane};
+      wn_contract<1>(acc, wa, 3 * 64, WN_G / 8, blc);
+      if (n_ok) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = 64 + 8 * (r >> 2) + 4 * lhi + (r & 3);
+          if (row < a.aux) a.dc[ob + (long)row * T] = acc[0][r];
+        }
+      }
+    }
+  }
+}
+
+// backward images, one buffer: [gate image 16 x 2 tiles][dx image 48 x 2 tiles][dc image 16 x 3 tiles] (x 256 floats)
+//   gate: row m = gate-output channel, kc < 64: w_skip[kc][m] * skip_mul, else w_out[kc - 64][m] * out_mul
+//   dx  : row m = residual channel ci, kc = t * 128 + co: w_dil[co][ci][t]
+//   dc  : row m = aux channel (zero for m >= aux), kc = co: w_aux[co][m]
+__global__ void wavenet_pack_bwd_kernel(const float* w_dil, const float* s_dil, const float* w_aux, const float* s_aux,
+                                        const float* w_skip, const float* s_skip, const float* w_out, const float* s_out,
+                                        float* out, int aux, float out_mul, float skip_mul) {
+  const int n_gate = 16 * 2 * 256, n_dx = 48 * 2 * 256, n_dc = 16 * 3 * 256;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_gate + n_dx + n_dc; i += gridDim.x * blockDim.x) {
+    const int part = i < n_gate ? 0 : (i < n_gate + n_dx ? 1 : 2);
+    const int e = part == 0 ? i : (part == 1 ? i - n_gate : i - n_gate - n_dx);
+    const int tiles = part == 2 ? 3 : 2;
+    const int j = e & 3, lane = (e >> 2) & 63;
+    const int tl = (e >> 8) % tiles, q = (e >> 8) / tiles;
+    const int m = tl * 32 + (lane & 31);
+    const int kc = 2 * (4 * q + j) + (lane >> 5);
+    float v = 0.f;
+    if (part == 0) {
+      v = kc < WN_S ? w_skip[(long)kc * WN_R + m] * (s_skip ? s_skip[kc] : 1.f) * skip_mul
+                    : w_out[(long)(kc - WN_S) * WN_R + m] * (s_out ? s_out[kc - WN_S] : 1.f) * out_mul;
+    } else if (part == 1) {
+      const int t = kc / WN_G, co = kc % WN_G;
+      v = w_dil[((long)co * WN_R + m) * WN_K + t] * (s_dil ? s_dil[co] : 1.f);
+    } else if (m < aux) {
+      v = w_aux[(long)kc * aux + m] * (s_aux ? s_aux[kc] : 1.f);
     }
     out[i] = v;
   }
@@ -312,6 +710,10 @@ int pwg_wavenet_layer_forward(const pwg_wavenet_desc* d, const float* x, const f
   a.pad = d->causal ? 2 * d->dilation : d->dilation;
   a.out_mul = d->out_mul;
   a.skip_mul = d->skip_mul;
+  static const int dbg = getenv("PWG_WN_DBG") ? atoi(getenv("PWG_WN_DBG")) : 0;
+  a.dbg = dbg;
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  a.vec_ok = al16(x_out) && al16(skips) && al16(skips_out) && al16(z_out) && al16(g_out);
   PWG_REQUIRE(!d->causal, PWG_ERR_UNSUPPORTED, "wavenet_layer_forward: the causal form is not built (residual = last tap window)");
   constexpr int AUX = 80;
   const size_t lds = (size_t)(WN_K * WN_R + AUX) * WN_COLS * sizeof(float);
@@ -331,6 +733,81 @@ int pwg_wavenet_layer_forward(const pwg_wavenet_desc* d, const float* x, const f
     hipLaunchKernelGGL(kern, dim3(ceil_div(d->t, WN_COLS), d->batch), dim3(256), lds, stream, a);
   }
   PWG_CHECK_LAUNCH("wavenet_layer_forward");
+  return PWG_OK;
+}
+
+size_t pwg_wavenet_packed_weight_bwd_floats(const pwg_wavenet_desc* d) {
+  if (!wavenet_ok(d)) return 0;
+  return (size_t)(16 * 2 + 48 * 2 + 16 * 3) * 256;
+}
+
+int pwg_wavenet_pack_weights_bwd(const pwg_wavenet_desc* d, const float* w_dil, const float* scale_dil, const float* w_aux,
+                                 const float* scale_aux, const float* w_skip, const float* scale_skip, const float* w_out,
+                                 const float* scale_out, float* packed, void* stream) {
+  PWG_REQUIRE(wavenet_ok(d), PWG_ERR_UNSUPPORTED, "wavenet_pack_weights_bwd: unsupported layer geometry");
+  PWG_REQUIRE(w_dil && w_aux && w_skip && w_out && packed, PWG_ERR_NULL, "wavenet_pack_weights_bwd: NULL pointer");
+  const int total = (int)pwg_wavenet_packed_weight_bwd_floats(d);
+  hipLaunchKernelGGL(wavenet_pack_bwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, w_dil, scale_dil,
+                     w_aux, scale_aux, w_skip, scale_skip, w_out, scale_out, packed, d->aux_channels, d->out_mul, d->skip_mul);
+  PWG_CHECK_LAUNCH("wavenet_pack_weights_bwd");
+  return PWG_OK;
+}
+
+int pwg_wavenet_gate_backward(const pwg_wavenet_desc* d, const float* z, const float* dx_out, const float* ds_out,
+                              const float* packed_bwd, float* dz, float* go, void* stream_) {
+  PWG_REQUIRE(wavenet_ok(d), PWG_ERR_UNSUPPORTED, "wavenet_gate_backward: unsupported layer geometry");
+  PWG_REQUIRE(z && ds_out && packed_bwd && dz, PWG_ERR_NULL, "wavenet_gate_backward: NULL pointer");
+  PWG_REQUIRE((dx_out == nullptr) == (go == nullptr), PWG_ERR_NULL, "wavenet_gate_backward: go goes with dx_out");
+  hipStream_t stream = (hipStream_t)stream_;
+  WnBwdArgs a = {};
+  a.z = z;
+  a.dx_out = dx_out;
+  a.ds_out = ds_out;
+  a.w = packed_bwd;
+  a.dz = dz;
+  a.go = go;
+  a.T = d->t;
+  a.dil = d->dilation;
+  a.aux = d->aux_channels;
+  a.out_mul = d->out_mul;
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  a.vec_ok = al16(z) && al16(dz) && al16(go);
+  const size_t lds = (size_t)(WN_G * WN_COLS + 4 * 32 * 36) * sizeof(float);
+  const double samples = (double)d->batch * d->t;
+  maybe_poison_lds(stream);
+  {
+    ProfScope prof(stream, "wavenet_gate_bwd_kernel", 2.0 * samples * WN_R * (WN_S + WN_R),
+                   4.0 * samples * (WN_S + (dx_out ? 2 * WN_R : 0) + 2 * WN_G));
+    hipLaunchKernelGGL(wavenet_gate_bwd_kernel, dim3(ceil_div(d->t, WN_COLS), d->batch), dim3(256), lds, stream, a);
+  }
+  PWG_CHECK_LAUNCH("wavenet_gate_backward");
+  return PWG_OK;
+}
+
+int pwg_wavenet_data_backward(const pwg_wavenet_desc* d, const float* dz, const float* go, const float* packed_bwd, float* dx,
+                              float* dc, void* stream_) {
+  PWG_REQUIRE(wavenet_ok(d), PWG_ERR_UNSUPPORTED, "wavenet_data_backward: unsupported layer geometry");
+  PWG_REQUIRE(dz && packed_bwd && (dx || dc), PWG_ERR_NULL, "wavenet_data_backward: NULL pointer");
+  hipStream_t stream = (hipStream_t)stream_;
+  WnBwdArgs a = {};
+  a.dz_in = dz;
+  a.go_in = go;
+  a.w = packed_bwd + 16 * 2 * 256;
+  a.dx = dx;
+  a.dc = dc;
+  a.T = d->t;
+  a.dil = d->dilation;
+  a.aux = d->aux_channels;
+  const size_t lds = (size_t)WN_K * WN_G * WD_COLS * sizeof(float);
+  const double samples = (double)d->batch * d->t;
+  maybe_poison_lds(stream);
+  {
+    ProfScope prof(stream, prof_shape_name("wavenet_dgrad_kernel", "B%d T%d d%d", d->batch, d->t, d->dilation),
+                   2.0 * samples * WN_G * ((dx ? WN_K * WN_R : 0) + (dc ? d->aux_channels : 0)),
+                   4.0 * samples * (WN_G + (dx ? WN_R : 0) + (go ? WN_R : 0) + (dc ? d->aux_channels : 0)));
+    hipLaunchKernelGGL(wavenet_dgrad_kernel, dim3(ceil_div(d->t, WD_COLS), d->batch), dim3(256), lds, stream, a);
+  }
+  PWG_CHECK_LAUNCH("wavenet_data_backward");
   return PWG_OK;
 }
 

@@ -277,34 +277,22 @@ class WaveNetLayerFn(torch.autograd.Function):
         h_d, h_a, h_s, h_o = ctx.holders
         b, t = x.shape[0], x.shape[2]
         need = ctx.needs_input_grad
-        # gradients w.r.t. the pre-scale sums of the two 1x1 convolutions
-        go = gs = None
-        if dx_out is not None:
-            go = torch.empty_like(x)
-            _lib.check(_L().pwg_act_backward(_ptr(_c(dx_out)), None, _ptr(go), go.numel(), 0, 0.0, float(desc.out_mul),
-                                             _stream()), "act_backward")
-        if ds_out is not None:
-            gs = _c(ds_out)
-            if desc.skip_mul != 1.0:
-                tmp = torch.empty_like(gs)
-                _lib.check(_L().pwg_act_backward(_ptr(gs), None, _ptr(tmp), tmp.numel(), 0, 0.0, float(desc.skip_mul),
-                                                 _stream()), "act_backward")
-                gs = tmp
         d_o, d_s = conv_o.make_desc(b, t), conv_s.make_desc(b, t)
         d_d, d_a = conv_d.make_desc(b, t), conv_a.make_desc(b, t)
-        # d gate output = Wo^T go + Ws^T gs
-        dgt = None
-        if go is not None:
-            dgt = ops.conv1d_backward_data(d_o, go, h_o.bwd(d_o))
-        if gs is not None:
-            dgt = ops.conv1d_backward_data(d_s, gs, h_s.bwd(d_s), accum=dgt)
-        dz = torch.empty_like(z)
-        _lib.check(_L().pwg_gate_backward(_ptr(z), _ptr(dgt), _ptr(dz), b, z.shape[1] // 2, t, _stream()), "gate_backward")
-        dx = dc = None
-        if need[0]:
-            dx = ops.conv1d_backward_data(d_d, dz, h_d.bwd(d_d), accum=go)  # (+ the residual path)
-        if need[1]:
-            dc = ops.conv1d_backward_data(d_a, dz, h_a.bwd(d_a))
+        dx_out = None if dx_out is None else _c(dx_out)
+        if ds_out is None:  # (cannot happen in the generator: every layer's skip sum reaches the loss)
+            ds_out = torch.zeros_like(x)
+        ds_out = _c(ds_out)
+        # data path: two launches (csrc/wavenet.hip): dz and go = out_mul * dx_out, then dx (+ go) and dc
+        img = block.fused_image_bwd(desc.skip_mul)
+        dz, go = ops.wavenet_gate_backward(desc, z, dx_out, ds_out, img)
+        dx, dc = ops.wavenet_data_backward(desc, dz, go, img, need_dx=need[0], need_dc=need[1])
+        # gradient w.r.t. the pre-scale sum of the skip convolution (its weight-gradient operand / the incoming skips)
+        gs = ds_out
+        if desc.skip_mul != 1.0:
+            gs = torch.empty_like(ds_out)
+            _lib.check(_L().pwg_act_backward(_ptr(ds_out), None, _ptr(gs), gs.numel(), 0, 0.0, float(desc.skip_mul),
+                                             _stream()), "act_backward")
         grads = []
         pi = 5
         for cv, hd, dsc, xin, gsum in ((conv_d, h_d, d_d, x, dz), (conv_a, h_a, d_a, c, dz), (conv_s, h_s, d_s, gt, gs),

@@ -92,6 +92,19 @@ class WaveNetResidualBlock(torch.nn.Module):
             self._fused_key = key
         return self._fused_img
 
+    def fused_image_bwd(self, skip_scale=1.0):
+        """Backward-pass image (gate / dilated / aux data gradients) for the current parameter values."""
+        convs = self.fused_convs()
+        key = (float(skip_scale),) + tuple(cv._params_key() for cv in convs)
+        if getattr(self, "_fused_bwd_key", None) != key:
+            hs = [cv.prepared() for cv in convs]
+            with torch.no_grad():
+                self._fused_bwd_img = ops.wavenet_pack_weights_bwd(self.fused_desc(1, 64, skip_scale), hs[0].w, hs[0].scale,
+                                                                   hs[1].w, hs[1].scale, hs[2].w, hs[2].scale, hs[3].w,
+                                                                   hs[3].scale)
+            self._fused_bwd_key = key
+        return self._fused_bwd_img
+
     def _fusable(self, x, c):
         if not self.fuse_layer or c is None or self.conv1x1_aux is None or x.dim() != 3 or not x.is_cuda:
             return False

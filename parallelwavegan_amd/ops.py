@@ -183,6 +183,41 @@ def wavenet_layer_forward(desc, x, c, skips, packed, b_dil, b_skip, b_out, save=
     return x_out, skips_out, z, g
 
 
+def wavenet_pack_weights_bwd(desc, w_dil, s_dil, w_aux, s_aux, w_skip, s_skip, w_out, s_out):
+    """Backward-pass image of a layer (gate / dilated / aux data gradients; folds desc.out_mul and desc.skip_mul)."""
+    _require_device(w_dil, s_dil, w_aux, s_aux, w_skip, s_skip, w_out, s_out)
+    out = torch.empty(_lib.lib().pwg_wavenet_packed_weight_bwd_floats(ctypes.byref(desc)), device=w_dil.device,
+                      dtype=torch.float32)
+    _lib.check(_lib.lib().pwg_wavenet_pack_weights_bwd(ctypes.byref(desc), _ptr(w_dil), _ptr(s_dil), _ptr(w_aux), _ptr(s_aux),
+                                                       _ptr(w_skip), _ptr(s_skip), _ptr(w_out), _ptr(s_out), _ptr(out),
+                                                       _stream()), "wavenet_pack_weights_bwd")
+    return out
+
+
+def wavenet_gate_backward(desc, z, dx_out, ds_out, packed_bwd):
+    """(dz, go): gradient w.r.t. the gate input and the scaled residual-path gradient ``out_mul * dx_out`` (None
+    when ``dx_out`` is None)."""
+    _require_device(z, dx_out, ds_out, packed_bwd)
+    dz = torch.empty_like(z)
+    go = None if dx_out is None else torch.empty_like(dx_out)
+    _lib.check(_lib.lib().pwg_wavenet_gate_backward(ctypes.byref(desc), _ptr(z), _ptr(dx_out), _ptr(ds_out),
+                                                    _ptr(packed_bwd), _ptr(dz), _ptr(go), _stream()), "wavenet_gate_backward")
+    return dz, go
+
+
+def wavenet_data_backward(desc, dz, go, packed_bwd, need_dx=True, need_dc=True):
+    """(dx, dc) = data gradients of the dilated convolution (+ go) and of the aux 1x1 convolution."""
+    _require_device(dz, go, packed_bwd)
+    b, t = dz.shape[0], dz.shape[2]
+    dx = torch.empty((b, desc.residual_channels, t), device=dz.device, dtype=torch.float32) if need_dx else None
+    dc = torch.empty((b, desc.aux_channels, t), device=dz.device, dtype=torch.float32) if need_dc else None
+    if dx is None and dc is None:
+        return None, None
+    _lib.check(_lib.lib().pwg_wavenet_data_backward(ctypes.byref(desc), _ptr(dz), _ptr(go), _ptr(packed_bwd), _ptr(dx),
+                                                    _ptr(dc), _stream()), "wavenet_data_backward")
+    return dx, dc
+
+
 def pack_weight_bwd(desc, w, scale=None):
     """Weight image for the data-gradient direction of ``desc`` (forward descriptor)."""
     _require_device(w, scale)
