@@ -68,8 +68,9 @@ def hifigan_macs_per_sample(cfg):
 # CPU baselines (the oracle = torch-CPU restatement of the reference's ATen call sequence; the
 # reference package itself does not exist on the GPU box, hence kind "port")
 # ------------------------------------------------------------------------------------------------
-def cpu_baseline(g_params, budget_s=12.0):
-    """B=1, 100 mel frames per call (bin/decode.py is utterance-at-a-time)."""
+def cpu_baseline(g_params, budget_s=(6.0, 14.0)):
+    """B=1 per call (bin/decode.py is utterance-at-a-time), at 100 AND 800 mel frames; ``value`` is
+    the 800-frame rate -- the utterance length of the GPU workload."""
     from oracle import torch_cpu
     from parallelwavegan_amd.models import HiFiGANGenerator
 
@@ -77,38 +78,44 @@ def cpu_baseline(g_params, budget_s=12.0):
     g = HiFiGANGenerator(**g_params)
     g.remove_weight_norm()
     sd = {k: v.detach() for k, v in g.state_dict().items()}
-    frames = 100
-    c = torch.randn(1, 80, frames)
 
-    def once():
+    def once(c):
         t0 = time.time()
         y = torch_cpu.hifigan_generator(sd, c, **g_params)
         return time.time() - t0, y
 
+    per_len = {}
     with torch.no_grad():
         # torch's default (= all cores) oversubscribes these small convs on a many-core host, so
-        # probe a few intra-op thread counts briefly and keep the fastest for the timed sample
+        # probe a few intra-op thread counts briefly and keep the fastest for the timed samples
+        c100 = torch.randn(1, 80, 100)
         probe = {}
         for nt in sorted({min(cores, n) for n in (8, 16, 32, 64)}):
             torch.set_num_threads(nt)
-            once()
-            probe[nt] = min(once()[0], once()[0])
+            once(c100)
+            probe[nt] = min(once(c100)[0], once(c100)[0])
         nthreads = min(probe, key=probe.get)
         torch.set_num_threads(nthreads)
-        best, n, t_start = float("inf"), 0, time.time()
-        while n < 3 or (time.time() - t_start < budget_s and n < 200):
-            dt, y = once()
-            best = min(best, dt)
-            n += 1
+        for frames, budget in zip((100, 800), budget_s):
+            c = torch.randn(1, 80, frames)
+            best, n, t_start = float("inf"), 0, time.time()
+            while n < 3 or (time.time() - t_start < budget and n < 200):
+                dt, y = once(c)
+                best = min(best, dt)
+                n += 1
+            per_len[frames] = {"samples_per_s": y.numel() / best, "best_s": best, "calls": n,
+                               "rtf": best / (y.numel() / 22050.0)}
     return {
-        "value": y.numel() / best,
+        "value": per_len[800]["samples_per_s"],
         "unit": "samples/s",
         "cores": torch.get_num_threads(),
         "kind": "port",
+        "frames_100": per_len[100],
+        "frames_800": per_len[800],
         "sample": f"oracle.torch_cpu.hifigan_generator (torch-CPU restatement of the reference's ATen sequence, "
                   f"pinned to reference fixtures; not the reference package, which is absent on this box), "
-                  f"B=1 x {frames} frames, best of {n} calls, {nthreads} of {cores} host threads "
-                  f"(fastest of {sorted(probe)})",
+                  f"B=1 x 800 frames, best of {per_len[800]['calls']} calls (100 frames: best of {per_len[100]['calls']}), "
+                  f"{nthreads} of {cores} host threads (fastest of {sorted(probe)})",
     }
 
 
@@ -229,17 +236,27 @@ def bench_train(args, tag, dev, rank, world, dist, steps, warmup, detail=True):
     # (same graphs, same kernels; the ranks' parameters drift apart afterwards, which timing ignores)
     dist_info = None
     if tr.reducers:
-        for r in tr.reducers.values():
-            r.skip_comm = True
-        t_nocomm = timed(steps)
-        for r in tr.reducers.values():
-            r.skip_comm = False
+        # the same steps again with all collectives off, and with only one of the two exchanges off: the
+        # exposed (not overlapped) time of the generator's and of the discriminator's exchange separately
+        def timed_without(keys):
+            for k in keys:
+                tr.reducers[k].skip_comm = True
+            t = timed(steps)
+            for k in keys:
+                tr.reducers[k].skip_comm = False
+            return t
+
+        t_nocomm = timed_without(list(tr.reducers))
+        t_without = {k: timed_without([k]) for k in tr.reducers}
         dist_info = {
             "backend": dist.get_backend(),
+            "world_size": dist.get_world_size(),
             "exchanged_MB_per_step": {k: round(r.bytes / 1e6, 1) for k, r in tr.reducers.items()},
             "exchange_groups": {k: len(r.groups) for k, r in tr.reducers.items()},
             "buckets": {k: len(r.buckets) for k, r in tr.reducers.items()},
             "ms_per_step_without_collectives": t_nocomm / steps * 1e3,
+            "ms_per_step_without_exchange_of": {k: v / steps * 1e3 for k, v in t_without.items()},
+            "rccl": rccl_log_summary(),
         }
     tr._flush_pending()
     # every loss of every step (warm-up included) was kept on the device (Trainer.loss_history): say WHICH loss
@@ -290,6 +307,8 @@ def bench_train(args, tag, dev, rank, world, dist, steps, warmup, detail=True):
         }
         if dist_info is not None:
             dist_info["exposed_comm_ms"] = ms - dist_info["ms_per_step_without_collectives"]
+            dist_info["exposed_comm_ms_per_exchange"] = {k: ms - v
+                                                         for k, v in dist_info["ms_per_step_without_exchange_of"].items()}
             out["dist"] = dist_info
             out["exposed_comm_ms"] = dist_info["exposed_comm_ms"]
         if prof is not None:
@@ -369,6 +388,56 @@ def bench_pwg_inference(dev, steps=10, warmup=3, batch=16, frames=400):
     return out
 
 
+RCCL_LOG = {"path": None}
+
+
+def enable_rccl_log(rank):
+    """RCCL prints the topology it detected and, per collective size, the algorithm / protocol its tuner picks
+    (NCCL_DEBUG=INFO, subsystems INIT + TUNING) into a per-process file that rank 0 parses after the run: the first
+    multi-GPU line then PROVES how many ranks took part and that the 283 MB exchange did not fall back to a
+    single-link ring.  Honours values the caller already exported."""
+    import tempfile
+
+    path = os.path.join(tempfile.gettempdir(), f"pwg_rccl_rank{rank}_{os.getpid()}.log")
+    os.environ.setdefault("NCCL_DEBUG", "INFO")
+    os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,TUNING,GRAPH")
+    os.environ.setdefault("NCCL_DEBUG_FILE", path)
+    RCCL_LOG["path"] = os.environ["NCCL_DEBUG_FILE"]
+
+
+def rccl_log_summary(max_lines=6):
+    """What this rank's RCCL log says: ranks of the communicator, channels, transports seen, algorithm / protocol
+    choices of the tuner.  None when there is no log (gloo run, logging redirected elsewhere)."""
+    import re
+
+    path = RCCL_LOG["path"]
+    if not path or not os.path.exists(path):
+        return None
+    nranks, channels, algos, transports, samples = None, None, {}, set(), []
+    try:
+        with open(path, errors="replace") as f:
+            for line in f:
+                m = re.search(r"nranks (\d+)", line)
+                if m:
+                    nranks = int(m.group(1))
+                m = re.search(r"(\d+) coll channels", line)
+                if m:
+                    channels = int(m.group(1))
+                for t in ("P2P/IPC", "P2P/direct", "via SHM", "via NET", "P2P/CUMEM"):
+                    if t in line:
+                        transports.add(t)
+                m = re.search(r"(AllReduce|Broadcast)[^\n]*?[Aa]lgo(?:rithm)?\s*[:=]?\s*(\w+)[^\n]*?[Pp]roto(?:col)?\s*[:=]?\s*(\w+)", line)
+                if m:
+                    key = f"{m.group(1)}:{m.group(2)}/{m.group(3)}"
+                    algos[key] = algos.get(key, 0) + 1
+                    if len(samples) < max_lines:
+                        samples.append(line.strip()[-200:])
+    except OSError:
+        return None
+    return {"log": path, "nranks": nranks, "coll_channels": channels, "transports": sorted(transports),
+            "algo_proto_counts": algos, "sample_lines": samples}
+
+
 def self_launch(args):
     """``python bench.py --gpus N`` without a launcher: one rank per GPU through the package's launcher."""
     from parallelwavegan_amd.distributed import launch
@@ -413,6 +482,8 @@ def main():
         # "nccl" is RCCL on ROCm.  RCCL refuses two ranks on one device, so when there are fewer GPUs
         # than ranks (single-GPU smoke run of the multi-rank path) the collectives go through gloo.
         backend = os.environ.get("PWG_DIST_BACKEND", "nccl" if n_dev >= world else "gloo")
+        if backend == "nccl":
+            enable_rccl_log(rank)
         # (gloo's C++ side prints its connection banner to stdout: keep stdout for the one JSON line)
         sys.stdout.flush()
         saved = os.dup(1)
@@ -432,6 +503,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ["PWG_FORCE_COLLECTIVES"] = "1"
+        if os.environ.get("PWG_DIST_BACKEND", "nccl") == "nccl":
+            enable_rccl_log(0)
         dist.init_process_group(os.environ.get("PWG_DIST_BACKEND", "nccl"), rank=0, world_size=1)
 
     from parallelwavegan_amd import ops
@@ -499,7 +572,7 @@ def main():
         name, r = max(prof.results.items(), key=lambda kv: kv[1]["ms"])
         achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
         traffic, traffic_src = None, None
-        for pmc_name in ("r02_pmc_hbm_traffic.json",):
+        for pmc_name in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):
             pmc_file = os.path.join(ROOT, "profiles", pmc_name)
             if os.path.exists(pmc_file) and args.batch == 16 and args.frames == 800:
                 # HBM bytes per launch of this kernel on THIS workload, from separate rocprofv3 --pmc passes

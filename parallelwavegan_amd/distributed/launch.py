@@ -5,8 +5,12 @@ egs/*/voc1/run.sh stage 2: ``launch.py --nproc_per_node N -c parallel-wavegan-tr
 
 Differences that matter on an MI355X node:
 
-* every rank gets ``LOCAL_RANK`` *and* (unless ``--use_env``) ``--local_rank=N`` like the reference, plus
-  ``HSA_ENABLE_IPC_MODE_LEGACY=0`` (RCCL's xGMI peer mappings need dmabuf IPC on this driver stack);
+* every rank gets ``LOCAL_RANK`` *and* (unless ``--use_env``) ``--local_rank=N`` like the reference;
+* ``HSA_ENABLE_IPC_MODE_LEGACY=0`` is set when the caller has not set it.  Evidence: the platform notes of this
+  ROCm 7.2 image state that the host driver supports only dmabuf IPC and that RCCL / cross-process device-memory
+  sharing otherwise fail with ``hipIpcGetMemHandle: invalid argument``; the image itself exports the variable, so
+  this default only matters for environments built from scratch (``env -i``, service managers).  It is a
+  ``setdefault``: an explicit value of the caller always wins;
 * the ranks are supervised together: the first rank that fails takes the others down (the reference
   waits for the ranks one after the other, so a crashed rank 1 leaves rank 0 blocked in a collective
   forever), and the launcher's exit status is that rank's;
