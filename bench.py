@@ -399,7 +399,8 @@ def enable_rccl_log(rank):
     import tempfile
 
     path = os.path.join(tempfile.gettempdir(), f"pwg_rccl_rank{rank}_{os.getpid()}.log")
-    os.environ.setdefault("NCCL_DEBUG", "INFO")
+    if os.environ.get("NCCL_DEBUG", "").upper() not in ("INFO", "TRACE"):  # (the GPU boxes export NCCL_DEBUG=VERSION)
+        os.environ["NCCL_DEBUG"] = "INFO"
     os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,TUNING,GRAPH")
     os.environ.setdefault("NCCL_DEBUG_FILE", path)
     RCCL_LOG["path"] = os.environ["NCCL_DEBUG_FILE"]
@@ -428,7 +429,10 @@ def rccl_log_summary(max_lines=6):
                         transports.add(t)
                 m = re.search(r"(AllReduce|Broadcast)[^\n]*?[Aa]lgo(?:rithm)?\s*[:=]?\s*(\w+)[^\n]*?[Pp]roto(?:col)?\s*[:=]?\s*(\w+)", line)
                 if m:
-                    key = f"{m.group(1)}:{m.group(2)}/{m.group(3)}"
+                    algo = {"0": "Tree", "1": "Ring", "2": "CollNetDirect", "3": "CollNetChain", "4": "NVLS", "5": "NVLSTree",
+                            "6": "PAT"}.get(m.group(2), m.group(2))
+                    proto = {"0": "LL", "1": "LL128", "2": "Simple"}.get(m.group(3), m.group(3))
+                    key = f"{m.group(1)}:{algo}/{proto}"
                     algos[key] = algos.get(key, 0) + 1
                     if len(samples) < max_lines:
                         samples.append(line.strip()[-200:])
@@ -466,6 +470,12 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+
+    # stdout carries exactly ONE line, the result: whatever libraries print there (RCCL's version banner, gloo's
+    # connection messages ...) is sent to stderr for the whole run; the JSON line goes to the saved descriptor
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -699,7 +709,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(g_params)
             if train is not None:
                 train["cpu_baseline"] = cpu_train_baseline(load_conf("hifigan.v1"))
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -181,12 +181,16 @@ class Trainer(object):
             y_ = self.criterion["pqmf"].synthesis(y_mb_)
         return y_, y_mb_
 
-    def _step_optimizer(self, key, loss):
+    def _step_optimizer(self, key, loss, roots=None):
         """Backward, [yield (key, group) = gradient-exchange point(s)], clip, update.  The caller
         completes the exchange at the yields (eagerly: RCCL calls are never captured in a hipGraph).
-        While a hipGraph is being captured and the reducer has several exchange groups, the backward
-        pass is issued group by group (``inputs=`` restricted autograd calls over independent
-        sub-networks) with a yield after each, so that every group becomes its own graph segment."""
+        When the reducer has several exchange groups (hipGraph data-parallel mode), the backward pass is
+        issued group by group -- ``inputs=`` restricted autograd calls over independent sub-networks --
+        with a yield after each, so that every group becomes its own graph segment while capturing.
+        ``roots``: tensors that separate the loss arithmetic from the sub-networks (the discriminators'
+        logits): the loss is differentiated down to them ONCE and every group's backward starts there, so
+        the shared loss nodes are neither re-executed nor re-captured per group.  Eager warm-up steps take
+        the same grouped path, i.e. the captured kernel sequence has run eagerly before."""
         cfg = self.config
         opt = self.optimizer[key]
         params = list(self._module(key).parameters())
@@ -195,12 +199,18 @@ class Trainer(object):
         reducer = self.reducers[key] if self.reducers else None
         if reducer is not None:
             reducer.prepare()
-        if reducer is not None and self._capturing and len(reducer.groups) > 1:
+        if reducer is not None and len(reducer.groups) > 1:
             last = len(reducer.groups) - 1
+            starts, seeds = [loss], None
+            if roots:
+                roots = [t for t in roots if t.requires_grad]
+                seeds = list(torch.autograd.grad(loss, roots, retain_graph=True, allow_unused=True))
+                starts = [t for t, g in zip(roots, seeds) if g is not None]
+                seeds = [g for g in seeds if g is not None]
             for gi, gparams in enumerate(reducer.groups):
                 inputs = [p for p in gparams if p.requires_grad]
                 if inputs:
-                    torch.autograd.backward(loss, inputs=inputs, retain_graph=gi < last)
+                    torch.autograd.backward(starts, seeds, inputs=inputs, retain_graph=gi < last)
                 yield (key, gi)
         else:
             loss.backward()
@@ -295,7 +305,10 @@ class Trainer(object):
                                     if self._pending else None)
                     segments.append((graph, exchange))
                     if exchange is not None:
-                        self.reducers[exchange[0]].finish()  # capture pass: nothing ran, nothing to exchange
+                        # capture pass: nothing ran, nothing to exchange -- and with ``defer`` set (above) finish()
+                        # only resets the reducer's bookkeeping, it neither launches nor waits for a collective
+                        assert self.reducers[exchange[0]].defer
+                        self.reducers[exchange[0]].finish()
             finally:
                 self._capturing = False
                 for r in (self.reducers or {}).values():
@@ -362,9 +375,12 @@ class Trainer(object):
         self._check_train_finish()
 
     def _device_step(self, x, y):
-        """One optimisation step, eagerly: the gradient exchanges run where the step yields."""
-        for key, _ in self._device_step_iter(x, y):
-            self.reducers[key].finish()
+        """One optimisation step, eagerly: the gradient exchanges run where the step yields (the buckets of
+        an exchange group go out from the hooks as they fill; the optimizer waits at the key's last yield)."""
+        for key, gi in self._device_step_iter(x, y):
+            r = self.reducers[key]
+            if gi is None or gi == len(r.groups) - 1:
+                r.finish()
 
     def _device_step_iter(self, x, y):
         """Generator over the step's gradient-exchange points (yields ("generator" | "discriminator",
@@ -441,7 +457,11 @@ class Trainer(object):
             self._log("train/real_loss", real_loss)
             self._log("train/fake_loss", fake_loss)
             self._log("train/discriminator_loss", dis_loss)
-            yield from self._step_optimizer("discriminator", dis_loss)
+            # (the loss depends on the sub-discriminators only through their final outputs)
+            roots = None
+            if isinstance(p_, (list, tuple)) and p_ and isinstance(p_[0], (list, tuple)):
+                roots = [out[-1] for out in list(p) + list(p_) if out is not None and torch.is_tensor(out[-1])]
+            yield from self._step_optimizer("discriminator", dis_loss, roots=roots)
 
     def _train_epoch(self):
         for train_steps_per_epoch, batch in enumerate(self.data_loader["train"], 1):
