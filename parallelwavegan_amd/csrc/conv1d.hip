@@ -1042,7 +1042,15 @@ static int choose_cfg(const Geometry& g, int W, int batch, int groups, bool dma,
   // LOSE 5-10 % to 128x128x4 at C = 256 and 3-5 % to 64x256x4 at C = 128 (profiles/r03_conv_sweep.txt): with one
   // workgroup per CU nothing overlaps a workgroup's epilogue / first-chunk latency.  Kept as sweepable
   // configurations (pwg_conv1d_forward_cfg), never chosen.
-  // 11 = 64x256x4 for exactly 128 rows: two row blocks re-read x, still 3-7 % faster than 128x128x4 there.
+  // 11 = 64x256x4: the row blocks re-read x, still 3-7 % faster than 128x128x4 at 128 rows and 3-4 % at 256 rows
+  // for k >= 7 (tools/bench_cfgs.py: 103 / 108 vs 99 / 105 TFLOP/s at k = 7 / 11, C = 256): its weight chunk -- the
+  // bulk of a chunk's DMA instructions -- is half as long.
+  // Tried in round 3 and NOT kept (both measured on the real kernel, tools/bench_conv.py / bench_cfgs.py):
+  //   * a 4-wave 128x256 tile with 2 x 4 accumulator tiles per wave: hipcc spills 171 VGPRs at the 256-register
+  //     cap that two workgroups per CU need (18 - 60 TFLOP/s);
+  //   * a fifth "loader" wave per workgroup that issues every LDS-DMA of the next chunk while the four compute
+  //     waves only contract: one wave cannot issue a chunk's 26 - 30 DMA instructions and wait for them in the time
+  //     the others need for 24 - 88 MFMAs each: 49 - 94 TFLOP/s against 86 - 119 (gpurun_out/r3/conv_loader.txt).
   static const Cand big_few[] = {{9, 0.95f}, {0, 0.85f}, {12, 0.85f}, {13, 0.75f}, {14, 0.6f}, {2, 0.8f},
                                  {15, 0.8f}, {16, 0.82f}, {11, 0.97f}};
   static const Cand big_many[] = {{2, 1.0f}, {9, 0.9f}, {12, 0.85f}, {13, 0.75f}, {14, 0.6f}, {15, 0.8f}, {16, 0.82f},
@@ -1056,7 +1064,7 @@ static int choose_cfg(const Geometry& g, int W, int batch, int groups, bool dma,
   int ncand;
   if (m > 64) {
     cand = k <= 4 ? big_few : big_many;
-    ncand = (k <= 4 ? 9 : 8) - (m > 128 ? 1 : 0);  // (the last entry, 64x256x4, only for m <= 128)
+    ncand = (k <= 4 ? 9 : 8) - ((m > 128 && k <= 4) ? 1 : 0);  // (few taps: 64x256x4 only for m <= 128)
   } else if (m > 32) {
     cand = k <= 4 ? mid_few : mid_many;  // (k = 7 at C = 64: 64x256x4 103 vs 32x128x8 95 TFLOP/s, profiles/r02_conv_sweep.txt)
     ncand = 4;
