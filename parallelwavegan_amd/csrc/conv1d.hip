@@ -480,7 +480,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WM * WN >= 8 ? 1 : (WM * W
     const int n_w0 = n0 + wave_n * (WN * 32);
     const bool vec_ok = a.epi_vec && single_phase && W == 1 && a.out_off == 0 && a.out_stride == 1 && m_w0 + WM * 32 <= a.m_g && n_w0 + WN * 32 <= a.n_cols;
     if (__builtin_amdgcn_readfirstlane(vec_ok ? 1 : 0)) {
-      float* scratch = smem + 2 * buf_floats + wave * (32 * 36);
+      // Scratch placement: the chunk buffer that the LAST chunk did not use is dead -- every wave passed the last
+      // chunk's barrier, i.e. finished the chunk before it -- so when it is large enough the scratch lives there
+      // and the launch needs no LDS beyond the two chunk buffers (128x128x8 at k = 7: 70 KB instead of 88 KB, two
+      // workgroups per CU); small buffers keep a separate scratch behind them.
+      const bool alias_scr = buf_floats >= NWAVES * (32 * 36) && nchunks >= 2;
+      float* scratch = (alias_scr ? smem + (nchunks & 1) * buf_floats : smem + 2 * buf_floats) + wave * (32 * 36);
       const int trow = lane >> 3;        // + 8 * pass
       const int tcol = (lane & 7) * 4;
       const long tile_base = ybase + (long)(g * a.cout_g + m_w0) * a.y_cstride + n_w0;  // wave-uniform
@@ -864,6 +869,14 @@ static void (*pick_dma_kernel(bool fast, int act))(ConvArgs) {
   return conv1d_mfma_dma_kernel<WM, WN, WAVES_M, WAVES_N, CK, false, 2>;
 }
 
+// LDS behind the two chunk buffers for the epilogue's transposition scratch: none for split-K launches (their
+// epilogue stores raw partial sums, no transposition) and none when the scratch fits the dead chunk buffer (mirrors
+// the kernel's `alias_scr`: unsplit launches have nchunks = ceil(cin_g / CK) in every workgroup)
+static size_t scratch_bytes_needed(size_t buf_bytes, size_t scr_bytes, int cin_g, int ck, int ksplit) {
+  if (ksplit > 1) return 0;
+  return (buf_bytes >= scr_bytes && ceil_div(cin_g, ck) >= 2) ? 0 : scr_bytes;
+}
+
 template <int WM, int WN, int WAVES_M, int WAVES_N, int CK, bool DMA>
 static int launch_conv(const ConvArgs& a0, const Geometry& g, int batch, int groups, hipStream_t stream) {
   constexpr int BM = 32 * WM * WAVES_M;
@@ -880,8 +893,10 @@ static int launch_conv(const ConvArgs& a0, const Geometry& g, int batch, int gro
   const int act = a.pre_act == PWG_ACT_NONE ? 0
                   : (a.pre_act == PWG_ACT_LEAKY_RELU && a.pre_slope > 0.f && a.pre_slope < 1.f) ? 1 : 2;
   const size_t buf = ((size_t)CK * a.xs_stride + (size_t)g.k_phase * CK * BM) * sizeof(float);
-  // DMA kernel: two chunk buffers + one 32 x 36 float transposition scratch per wave (16-B epilogue)
-  const size_t lds = DMA ? 2 * buf + (size_t)WAVES_M * WAVES_N * 32 * 36 * sizeof(float) : buf;
+  // DMA kernel: two chunk buffers + one 32 x 36 float transposition scratch per wave (16-B epilogue), which lives
+  // in the dead chunk buffer when that is large enough (and the reduction has >= 2 chunks per slice)
+  const size_t scr = (size_t)WAVES_M * WAVES_N * 32 * 36 * sizeof(float);
+  const size_t lds = DMA ? 2 * buf + scratch_bytes_needed(buf, scr, g.cin_g, CK, a.ksplit) : buf;
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
   a.epi_vec = DMA && a.width == 1 && (a.y_cstride % 4) == 0 && al16(a.y) && al16(a.add1) && al16(a.add2) &&
               al16(a.mask_src) && (((size_t)a.y_bstride) % 4) == 0;
@@ -997,7 +1012,8 @@ static size_t cfg_lds(int id, const Geometry& g, int W, bool dma) {
   int xs = dma ? round_up(xs_len, 64) : round_up(xs_len, 4);
   if (dma && g.stride == 1 && W == 1 && (g.k_phase - 1) * g.dil <= 64) xs = c.bn + 64;  // FAST row stride (upper bound)
   const size_t buf = ((size_t)c.ck * xs + (size_t)g.k_phase * c.ck * c.bm) * sizeof(float);
-  return dma ? 2 * buf + (size_t)c.waves * 32 * 36 * sizeof(float) : buf;
+  const size_t scr = (size_t)c.waves * 32 * 36 * sizeof(float);
+  return dma ? 2 * buf + scratch_bytes_needed(buf, scr, g.cin_g, c.ck, 1) : buf;
 }
 
 static int launch_cfg(int id, bool dma, const ConvArgs& a, const Geometry& g, int batch, int groups,
