@@ -148,7 +148,8 @@ __global__ __launch_bounds__(256, 2) void gconv_fwd_kernel(GcArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 template <int CIG, int K, int S, int COGS, int NT>
 __global__ __launch_bounds__(256, 2) void gconv_dgrad_kernel(GcArgs a) {
-  static_assert(CIG * S == 16, "one 16-row MFMA tile holds every (input channel, phase) of a group");
+  static_assert((CIG * S) % 16 == 0, "whole 16-row MFMA tiles of (input channel, phase) rows");
+  constexpr int MT = CIG * S / 16;              // row tiles: rows m = ci * S + r, tile mt holds m in [16 mt, 16 mt + 16)
   constexpr int J = (K + S - 1) / S;            // taps of a phase convolution
   constexpr int COLS = 16 * NT;                 // q columns per pass (COLS * S output samples per channel)
   constexpr int L = COLS + J - 1;
@@ -188,14 +189,16 @@ __global__ __launch_bounds__(256, 2) void gconv_dgrad_kernel(GcArgs a) {
 
   // A[m = (ci, r)][k = co] per phase tap, from the dual's packed image [g][tap'][co (16)][m' = r * CIG + ci (128)];
   // tap' multiplies G[q - (J - 1) + tap']
-  float w[J][COGS];
-  {
-    const int ci = n / S, r = n % S;
+  float w[MT][J][COGS];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = 16 * mt + n;
+    const int ci = m / S, r = m % S;
     const float* wg = a.wp + (long)g * J * 16 * 128 + r * CIG + ci;
 #pragma unroll
     for (int tap = 0; tap < J; ++tap)
 #pragma unroll
-      for (int ks = 0; ks < COGS; ++ks) w[tap][ks] = wg[(tap * 16 + ks * 4 + kk) * 128];
+      for (int ks = 0; ks < COGS; ++ks) w[mt][tap][ks] = wg[(tap * 16 + ks * 4 + kk) * 128];
   }
   const long x_item = (long)a.groups * CIG * a.t_in;
   const long xb = (long)b * x_item + (long)g * CIG * a.t_in;
@@ -206,28 +209,36 @@ __global__ __launch_bounds__(256, 2) void gconv_dgrad_kernel(GcArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float* buf = gs + (p & 1) * BUF;
     if (p + 1 < a.passes_per_wave && q0 + COLS < n_cols) issue(q0 + COLS, gs + ((p + 1) & 1) * BUF);
-    f32x4 acc[NT];
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* gl = buf + kk * RS + n;  // + ks * 4 * RS + tile * 16 + tap'
 #pragma unroll
     for (int tap = 0; tap < J; ++tap)
 #pragma unroll
       for (int ks = 0; ks < COGS; ++ks)
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[tap][ks], gl[ks * 4 * RS + t * 16 + tap], acc[t], 0, 0, 0);
-    // D rows 4 * kk + reg = (ci, r): the lane holds rows m = 4 * kk .. 4 * kk + 3 of column q
+        for (int t = 0; t < NT; ++t) {
+          const float bv = gl[ks * 4 * RS + t * 16 + tap];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[mt][tap][ks], bv, acc[mt][t], 0, 0, 0);
+        }
+    // D rows 16 * mt + 4 * kk + reg = (ci, r): the lane holds 4 consecutive rows of column q
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int q = q0 + t * 16 + n;
       if (S == 4) {
-        // S = 4: ci = kk, r = reg -> four consecutive samples u0 .. u0 + 3 of one channel row (16-B aligned when
-        // pad % 4 == 0, t_in % 4 == 0 and the tensors are: a.vec_ok, decided by the host)
+        // S = 4: ci = 4 * mt + kk, r = reg -> four consecutive samples u0 .. u0 + 3 of one channel row (16-B aligned
+        // when pad % 4 == 0, t_in % 4 == 0 and the tensors are: a.vec_ok, decided by the host)
         const int u0 = q * 4 - a.pad;
-        const long o = xb + (long)kk * a.t_in + u0;
+        const long o = xb + (long)(4 * mt + kk) * a.t_in + u0;
         if (q < n_cols && u0 >= 0 && u0 + 3 < a.t_in && a.vec_ok) {
-          f32x4 v = acc[t];
+          f32x4 v = acc[mt][t];
           if (a.mask) {
             const f32x4 m = *reinterpret_cast<const f32x4*>(a.mask + o);
 #pragma unroll
@@ -244,12 +255,12 @@ __global__ __launch_bounds__(256, 2) void gconv_dgrad_kernel(GcArgs a) {
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = 4 * kk + r;
+        const int m = 16 * mt + 4 * kk + r;
         const int ci = m / S, ph = m % S;
         const int u = q * S + ph - a.pad;
         if (q < n_cols && u >= 0 && u < a.t_in) {
           const long o = xb + (long)ci * a.t_in + u;
-          float v = acc[t][r];
+          float v = acc[mt][t][r];
           if (a.mask) v *= (a.mask[o] > 0.f ? 1.f : a.mask_slope);
           if (a.accum) v += a.accum[o];
           a.y[o] = v;
@@ -399,7 +410,7 @@ static bool gconv_geometry_ok(const pwg_conv1d_desc* d) {
   if (d->transposed || d->width != 1 || d->dilation != 1 || d->pad_mode != PWG_PAD_ZERO || d->kernel != 41) return false;
   if (d->groups < 2 || d->c_in % d->groups || d->c_out % d->groups) return false;
   const int cig = d->c_in / d->groups, cog = d->c_out / d->groups;
-  if (!((cig == 4 && d->stride == 4) || (cig == 8 && d->stride == 2))) return false;
+  if (!((cig == 4 && d->stride == 4) || (cig == 8 && (d->stride == 2 || d->stride == 4)))) return false;
   if (cog != 8 && cog != 16) return false;
   if ((long)d->batch * d->c_in * d->t_in * 4 >= 0xFFFFFFF0L || (long)d->batch * d->c_out * d->t_out * 4 >= 0xFFFFFFF0L) return false;
   static const bool off = getenv("PWG_NO_GCONV") != nullptr;  // (A/B switch for tools/bench_gconv.py)
@@ -465,10 +476,16 @@ int gconv_forward(const pwg_conv1d_desc* d, const float* x, const float* wp, con
     auto kern = gconv_fwd_kernel<4, 41, 4, NT>;
     if (int rc = raise_lds(kern, lds, "gconv_forward")) return rc;
     hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
-  } else {
+  } else if (d->stride == 2) {
     constexpr int RS = ((16 * NT * 2 + 41 - 2 + 63) / 64) * 64 + 1;
     const size_t lds = (size_t)4 * 2 * 8 * RS * sizeof(float);
     auto kern = gconv_fwd_kernel<8, 41, 2, NT>;
+    if (int rc = raise_lds(kern, lds, "gconv_forward")) return rc;
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
+  } else {
+    constexpr int RS = ((16 * NT * 4 + 41 - 4 + 63) / 64) * 64 + 1;
+    const size_t lds = (size_t)4 * 2 * 8 * RS * sizeof(float);
+    auto kern = gconv_fwd_kernel<8, 41, 4, NT>;
     if (int rc = raise_lds(kern, lds, "gconv_forward")) return rc;
     hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
   }
@@ -522,6 +539,18 @@ int gconv_backward_data(const pwg_conv1d_desc* d, const float* dy, const float* 
     } else {
       const size_t lds = (size_t)4 * 2 * 8 * RS * sizeof(float);
       auto kern = gconv_dgrad_kernel<4, 41, 4, 2, NT>;
+      if (int rc = raise_lds(kern, lds, "gconv_backward_data")) return rc;
+      hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
+    }
+  } else if (d->stride == 4) {
+    if (cog == 16) {
+      const size_t lds = (size_t)4 * 2 * 16 * RS * sizeof(float);
+      auto kern = gconv_dgrad_kernel<8, 41, 4, 4, NT>;
+      if (int rc = raise_lds(kern, lds, "gconv_backward_data")) return rc;
+      hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
+    } else {
+      const size_t lds = (size_t)4 * 2 * 8 * RS * sizeof(float);
+      auto kern = gconv_dgrad_kernel<8, 41, 4, 2, NT>;
       if (int rc = raise_lds(kern, lds, "gconv_backward_data")) return rc;
       hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
     }
@@ -602,10 +631,16 @@ int gconv_backward_weight(const pwg_conv1d_desc* d, const float* x, const float*
       auto kern = gconv_wgrad_kernel<4, 41, 4>;
       if (int rc = raise_lds(kern, lds, "gconv_backward_weight")) return rc;
       hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
-    } else {
+    } else if (d->stride == 2) {
       constexpr int RSX = ((64 * 2 + 41 - 2 + 63) / 64) * 64 + 1;
       const size_t lds = (size_t)4 * 2 * (8 * RSX + 16 * 66) * sizeof(float);
       auto kern = gconv_wgrad_kernel<8, 41, 2>;
+      if (int rc = raise_lds(kern, lds, "gconv_backward_weight")) return rc;
+      hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
+    } else {
+      constexpr int RSX = ((64 * 4 + 41 - 4 + 63) / 64) * 64 + 1;
+      const size_t lds = (size_t)4 * 2 * (8 * RSX + 16 * 66) * sizeof(float);
+      auto kern = gconv_wgrad_kernel<8, 41, 4>;
       if (int rc = raise_lds(kern, lds, "gconv_backward_weight")) return rc;
       hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
     }

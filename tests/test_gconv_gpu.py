@@ -26,6 +26,8 @@ CASES = [
     (2, 256, 512, 64, 260, 4, None, 0.2),   # layer 3: 8 output channels per group
     (2, 32, 64, 4, 333, 2, 0.1, 0.1),       # HiFi-GAN MSD pattern: 8 -> 16 per group, stride 2
     (1, 16, 16, 2, 77, 2, None, None),      # 8 -> 8 per group
+    (2, 128, 256, 16, 600, 4, None, 0.1),   # HiFi-GAN MSD layer 2 as the recipe has it: 8 -> 16 per group, stride 4
+    (1, 16, 16, 2, 131, 4, 0.2, None),      # 8 -> 8 per group, stride 4
     (2, 8, 32, 2, 41, 4, None, 0.2),        # T_out = 11: a single partial tile
     (5, 4 * 5, 16 * 5, 5, 4096 + 3, 4, None, 0.2),  # several passes per wave, odd group count
 ]

@@ -19,7 +19,8 @@ def timeit(fn, reps=20):
 
 ROWS = [("C4 L1 16->64 g4", 64, 16, 64, 4, 16384, 4), ("C4 L1 scale1", 64, 16, 64, 4, 8192, 4), ("C4 L2 64->256 g16", 64, 64, 256, 16, 4096, 4),
         ("C4 L3 256->512 g64", 64, 256, 512, 64, 1024, 4), ("C4 L3 scale2", 64, 256, 512, 64, 256, 4),
-        ("C3 MSD L2 128->256 g16 s2", 16, 128, 256, 16, 4096, 2), ("C3 MSD L2 scale2", 16, 128, 256, 16, 1024, 2)]
+        ("C3 MSD L2 128->256 g16 s4", 16, 128, 256, 16, 2048, 4), ("C3 MSD L2 scale2", 16, 128, 256, 16, 513, 4),
+        ("(8->16 per group, s2)", 16, 128, 256, 16, 4096, 2)]
 dev = torch.device("cuda:0")
 for name, B, cin, cout, g, T, s in ROWS:
     t_out = (T + 40 - 41) // s + 1
