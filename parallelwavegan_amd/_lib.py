@@ -104,6 +104,7 @@ SIGNATURES = {
     "pwg_abi_version": (ctypes.c_int, []),
     "pwg_target_arch": (ctypes.c_int, []),
     "pwg_debug_poison_lds": (ctypes.c_int, [ctypes.c_int]),
+    "pwg_set_concurrency_hint": (ctypes.c_float, [ctypes.c_float]),
     "pwg_prof_enable": (ctypes.c_int, [ctypes.c_int]),
     "pwg_prof_reset": (ctypes.c_int, []),
     "pwg_prof_num_kernels": (ctypes.c_int, []),

@@ -70,6 +70,9 @@ void maybe_poison_lds(hipStream_t stream);
 // correctness depended on such a node (the unwritten tail of the partial-sum array).  Kernel nodes only.
 void zero_fill(float* p, long n, hipStream_t stream);
 
+// 1.0 = a launch has the chip to itself; < 1: it shares it with concurrent launches (pwg_set_concurrency_hint)
+float concurrency_hint();
+
 // gconv.hip: grouped k = 41 strided convolutions with 4 / 8 input channels per group on the 16 x 16 x 4 MFMA
 // (`d` is always the FORWARD descriptor of the layer)
 bool gconv_forward_applicable(const pwg_conv1d_desc* d, const float* add1, const float* add2);

@@ -1041,6 +1041,10 @@ struct Cand {
   int id;
   float speed;
 };
+// (pwg_set_concurrency_hint; PWG_CONV_FILL_SCALE overrides it for experiments)
+static float g_fill_scale = 1.0f;
+static const float g_fill_scale_env = getenv("PWG_CONV_FILL_SCALE") ? (float)atof(getenv("PWG_CONV_FILL_SCALE")) : 0.f;
+float concurrency_hint() { return g_fill_scale_env > 0.f ? g_fill_scale_env : g_fill_scale; }
 
 // ksplit (optional out): number of reduction slices.  A workgroup walks its ci-chunks serially and a
 // chunk costs at least one DMA + barrier round trip (~2.7 us measured) however little MFMA work it
@@ -1118,7 +1122,9 @@ static int choose_cfg(const Geometry& g, int W, int batch, int groups, bool dma,
       const int split = max_split(c, blocks);
       // (very long filters -- k = 41 grouped layers -- carry >= 5000 MFMA cycles per chunk: one workgroup
       // per CU already hides the DMA round trip, so 256 workgroups count as a full chip there)
-      const float full = (k >= 32 || c.waves == 8) ? 256.f : 512.f;
+      // g_fill_scale: concurrency hint (pwg_conv1d_set_concurrency): inside a captured step the launches of the
+      // parallel sub-discriminator branches share the chip, so one launch need not fill it alone
+      const float full = ((k >= 32 || c.waves == 8) ? 256.f : 512.f) * concurrency_hint();
       const float fill = blocks * split >= full ? 1.f : (float)(blocks * split) / full;
       const float useful = (float)g.n_cols / (float)(ntiles * c.bn) * (float)m / (float)(ceil_div(m, c.bm) * c.bm);
       const float score = fill * useful * cand[i].speed * (split > 1 ? 0.9f : 1.f);
@@ -1374,6 +1380,12 @@ extern "C" int pwg_conv1d_backward_data(const pwg_conv1d_desc* d, const float* d
 }
 
 extern "C" int pwg_conv1d_num_tile_configs(void) { return kNumCfgs; }
+
+extern "C" float pwg_set_concurrency_hint(float fill_scale) {
+  const float was = g_fill_scale;
+  if (fill_scale > 0.f && fill_scale <= 1.f) g_fill_scale = fill_scale;
+  return was;
+}
 
 extern "C" int pwg_conv1d_forward_cfg(const pwg_conv1d_desc* d_in, const float* x, const float* w_packed,
                                       const float* bias, const float* add1, const float* add2, float* y,

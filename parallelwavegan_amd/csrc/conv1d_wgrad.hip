@@ -619,7 +619,10 @@ static WgPlan wgrad_plan(int co_g, int ci_g, int groups, int k, int stride, int 
   p.tiles = ceil_div(co_g, bt) * ceil_div(ci_g, bt) * groups;
   // one wave of resident workgroups (register-limited: 2 per CU with 6-7 accumulators, else 3), all
   // with the same amount of work; at least 256 columns of reduction per workgroup
-  const int resident = 256 * (env_res > 0 ? env_res : ((!p.small && p.tg >= 6) ? 2 : 3));
+  // (with concurrent launches -- the parallel sub-discriminator branches of a captured step -- two resident
+  // workgroups per CU per launch are enough, and every slice saved is a slab less to write and reduce)
+  const int res_default = (!p.small && p.tg >= 6) ? 2 : (concurrency_hint() < 1.f ? 2 : 3);
+  const int resident = 256 * (env_res > 0 ? env_res : res_default);
   int splits = resident / (p.tiles * p.tap_groups);
   const int min_chunks = 256 / p.tt > 1 ? 256 / p.tt : 1;
   if (splits > p.chunks_total / min_chunks) splits = p.chunks_total / min_chunks;
