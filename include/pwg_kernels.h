@@ -268,6 +268,23 @@ int pwg_wavenet_gate_backward(const pwg_wavenet_desc* d, const float* z, const f
                               const float* packed_bwd, float* dz, float* go, void* stream);
 int pwg_wavenet_data_backward(const pwg_wavenet_desc* d, const float* dz, const float* go, const float* packed_bwd, float* dx,
                               float* dc, void* stream);
+/* The layer's parameter gradients in three launches: two contractions over time -- dz (128 rows) against the three
+ * tap windows of x and c (272 rows), and [gs = skip_mul * ds_out ; go] (128 rows) against the saved gate output g (64
+ * rows) -- into per-slice slabs, and one finish kernel that sums the slices in a fixed order and writes, per
+ * convolution (grads[0..3] = dilated, aux, skip, out; torch weight layouts (rows, in, k)): the weight gradient (v NULL)
+ * or, for a weight-normalised convolution w = g v / |v|, the gradients w.r.t. v and g; and the bias gradient.
+ * go and grads[3].dw are NULL together (last layer); dg / db may be NULL.  Deterministic.                            */
+typedef struct pwg_wavenet_param_grad {
+  const float* v;  /* weight-norm direction tensor (shape of the weight), or NULL for a plain weight */
+  const float* g;  /* weight-norm magnitudes (rows), NULL iff v is NULL */
+  float* dw;       /* out: gradient w.r.t. the weight (v NULL) or w.r.t. v */
+  float* dg;       /* out: gradient w.r.t. g, or NULL */
+  float* db;       /* out: bias gradient, or NULL */
+} pwg_wavenet_param_grad;
+size_t pwg_wavenet_weight_backward_workspace_floats(const pwg_wavenet_desc* d);
+int pwg_wavenet_weight_backward(const pwg_wavenet_desc* d, const float* dz, const float* x, const float* c, const float* gs,
+                                const float* go, const float* g, const pwg_wavenet_param_grad* grads, float* workspace,
+                                size_t workspace_floats, void* stream);
 
 /* Old-style torch.nn.utils.weight_norm (dim=0) scale: scale[i] = g[i]/||v[i,...]||_2
  * replaces torch._weight_norm at every conv call site.

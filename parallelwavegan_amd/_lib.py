@@ -58,6 +58,13 @@ class WaveNetDesc(ctypes.Structure):
     ]
 
 
+class WaveNetParamGrad(ctypes.Structure):
+    """Mirror of ``pwg_wavenet_param_grad`` (include/pwg_kernels.h)."""
+
+    _fields_ = [("v", ctypes.c_void_p), ("g", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("dg", ctypes.c_void_p),
+                ("db", ctypes.c_void_p)]
+
+
 class ResUnitDesc(ctypes.Structure):
     """Mirror of ``pwg_resunit_desc`` (include/pwg_kernels.h)."""
 
@@ -141,6 +148,9 @@ SIGNATURES = {
     "pwg_wavenet_pack_weights_bwd": (ctypes.c_int, [ctypes.POINTER(WaveNetDesc)] + [_vp] * 10),
     "pwg_wavenet_gate_backward": (ctypes.c_int, [ctypes.POINTER(WaveNetDesc)] + [_vp] * 7),
     "pwg_wavenet_data_backward": (ctypes.c_int, [ctypes.POINTER(WaveNetDesc)] + [_vp] * 6),
+    "pwg_wavenet_weight_backward_workspace_floats": (ctypes.c_size_t, [ctypes.POINTER(WaveNetDesc)]),
+    "pwg_wavenet_weight_backward": (ctypes.c_int, [ctypes.POINTER(WaveNetDesc)] + [_vp] * 6
+                                    + [ctypes.POINTER(WaveNetParamGrad), _vp, ctypes.c_size_t, _vp]),
     "pwg_act_backward": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _f32, _vp]),
     "pwg_add3_div": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _vp]),
     "pwg_wave_to_pcm16": (ctypes.c_int, [_vp, _vp, _i64, _vp]),

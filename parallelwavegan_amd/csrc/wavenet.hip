@@ -651,6 +651,258 @@ __global__ void wavenet_pack_bwd_kernel(const float* w_dil, const float* s_dil, 
   }
 }
 
+
+// =====================================================================================================================
+// backward, weight path.  The layer's four weight gradients are two "(128 rows) x (N rows) over time" contractions:
+//
+//   [dW_dil | dW_aux | db_dil] = dz   (128 x T)  x  [x(n - d); x(n); x(n + d); c(n)]  (272 x T)^T     (+ row sums of dz)
+//   [dW_skip ; dW_out | db]    = [gs; go] (128)  x  g (64 x T)^T
+//
+// As separate k = 1 / k = 3 launches of the general weight-gradient kernel they are LDS-DMA-issue bound (64 dword-DMA
+// instructions per 64 MFMAs: 34 - 38 TFLOP/s); here a workgroup (8 waves) stages BOTH operands of a 64-column chunk
+// through registers -- 16-B global loads, written to LDS time-major ([column][row], odd row stride), so that the
+// MFMA operand reads "32 rows at one column" are 32 consecutive words -- and owns the whole 128 x N output: 36 (or 8)
+// accumulator tiles, 1152 MFMAs per chunk for 13 loads + 50 ds_write per thread.  Slices of the (item, chunk) range
+// write private slabs; one reduce kernel sums them in order and scatters to the torch layouts (deterministic).
+// =====================================================================================================================
+constexpr int WW_COLS = 64;
+struct WwArgs {
+  const float* m_src[2];  // M operand: stacked row groups of (B, rows, T) tensors, 128 rows in total; NULL = zeros
+  int m_rows[2];
+  const float* n_src[4];  // N operand row groups, each read at column n + shift
+  int n_rows[4];
+  int n_shift[4];
+  float* slabs;           // [slices][128][NROWS + 1]
+  int T, chunks_per_item, chunks_total, chunks_per_slice;
+};
+
+template <int NROWS>
+__global__ __launch_bounds__(512, 1) void wavenet_wgrad_kernel(WwArgs a) {
+  constexpr int ROWS = WN_G + NROWS;            // staged rows: M operand first, then the N operand
+  constexpr int RS2 = ROWS + 1;                 // words between consecutive columns (odd)
+  constexpr int NLD = (ROWS * 16 + 511) / 512;  // 16-B loads per thread and chunk
+  constexpr int NCT = (NROWS + 31) / 32;        // column tiles of the output
+  constexpr int NTL = NCT > 2 ? 5 : 1;          // tiles per wave (N = 272: waves 0-3 own 5, waves 4-7 own 4)
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [64][RS2] (+ 32 floats of slack)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rt = wave & 3, cg = wave >> 2;
+  const int ct0 = NCT > 2 ? cg * 5 : cg;
+  const int ntl = NCT > 2 ? (cg == 0 ? 5 : NCT - 5) : 1;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int T = a.T;
+  const int c_begin = blockIdx.x * a.chunks_per_slice;
+  const int c_end = min(c_begin + a.chunks_per_slice, a.chunks_total);
+
+  // row -> (source row pointer for item 0, item stride, shift); evaluated per load slot once (chunk-invariant)
+  const float* rptr[NLD];
+  int rshift[NLD], ritem[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int e = i * 512 + tid;
+    int row = e >> 4;
+    const float* p = nullptr;
+    int shift = 0, rows_of = 0;
+    if (row < WN_G) {
+      int r = row;
+#pragma unroll
+      for (int gI = 0; gI < 2; ++gI) {
+        if (r >= 0 && r < a.m_rows[gI]) { p = a.m_src[gI] ? a.m_src[gI] + (long)r * T : nullptr; rows_of = a.m_rows[gI]; }
+        r -= a.m_rows[gI];
+      }
+    } else if (row < ROWS) {
+      int r = row - WN_G;
+#pragma unroll
+      for (int gI = 0; gI < 4; ++gI) {
+        if (r >= 0 && r < a.n_rows[gI]) { p = a.n_src[gI] + (long)r * T; shift = a.n_shift[gI]; rows_of = a.n_rows[gI]; }
+        r -= a.n_rows[gI];
+      }
+    }
+    rptr[i] = p;
+    rshift[i] = shift + 4 * (e & 15);
+    ritem[i] = rows_of * T;  // floats between consecutive items of that tensor
+  }
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  float4 stage[NLD];
+  auto load_chunk = [&](int c) {
+    const int b = c / a.chunks_per_item;
+    const int n0 = (c - b * a.chunks_per_item) * WW_COLS;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float* p = rptr[i];
+      const int col = n0 + rshift[i];
+      if (p != nullptr && n0 + 4 * ((i * 512 + tid) & 15) < T) {  // (columns past the item's end stay zero for BOTH operands)
+        p += (long)b * ritem[i];
+        if (col >= 0 && col + 3 < T) {
+          const f4u u = *reinterpret_cast<const f4u*>(p + col);
+          v = make_float4(u[0], u[1], u[2], u[3]);
+        } else {
+          if (col >= 0 && col < T) v.x = p[col];
+          if (col + 1 >= 0 && col + 1 < T) v.y = p[col + 1];
+          if (col + 2 >= 0 && col + 2 < T) v.z = p[col + 2];
+          if (col + 3 >= 0 && col + 3 < T) v.w = p[col + 3];
+        }
+      }
+      stage[i] = v;
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = i * 512 + tid;
+      const int row = e >> 4, q = e & 15;
+      if (row < ROWS) {
+        float* d = tile + (4 * q) * RS2 + row;
+        d[0] = stage[i].x;
+        d[RS2] = stage[i].y;
+        d[2 * RS2] = stage[i].z;
+        d[3 * RS2] = stage[i].w;
+      }
+    }
+  };
+
+  f32x16 acc[NTL];
+#pragma unroll
+  for (int t = 0; t < NTL; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;
+
+  if (c_begin < c_end) load_chunk(c_begin);
+  for (int c = c_begin; c < c_end; ++c) {
+    __syncthreads();  // every wave is done reading the previous chunk
+    store_chunk();
+    __syncthreads();
+    if (c + 1 < c_end) load_chunk(c + 1);  // in flight under this chunk's MFMAs
+    const float* al = tile + lhi * RS2 + rt * 32 + l31;
+    const float* bl = tile + lhi * RS2 + WN_G + ct0 * 32 + l31;
+#pragma unroll 4
+    for (int st = 0; st < WW_COLS / 2; ++st) {
+      const float av = al[2 * st * RS2];
+      bsum += av;
+      float bv[NTL];
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) bv[t] = bl[2 * st * RS2 + (t < ntl ? t : 0) * 32];
+#pragma unroll
+      for (int t = 0; t < NTL; ++t)
+        if (NTL == 1 || t < 4 || ntl == 5) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+    }
+  }
+  // slab of this slice: [128][NROWS + 1]; D layout col = lane & 31, row = 8 * (r >> 2) + 4 * lhi + (r & 3)
+  float* slab = a.slabs + (long)blockIdx.x * WN_G * (NROWS + 1);
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) {
+    if (t < ntl) {
+      const int col = (ct0 + t) * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = rt * 32 + 8 * (r >> 2) + 4 * lhi + (r & 3);
+        if (col < NROWS) slab[(long)m * (NROWS + 1) + col] = acc[t][r];
+      }
+    }
+  }
+  bsum += __shfl_xor(bsum, 32, 64);
+  if (cg == 0 && lhi == 0) slab[(long)(rt * 32 + l31) * (NROWS + 1) + NROWS] = bsum;
+}
+
+// Finish: one workgroup per output row (128 rows of [dil | aux | bias] + 128 rows of [skip or out | bias]) sums the
+// row over the slices (3 or 12 slice lanes per column, lane partials added in order: deterministic), then one wave per
+// convolution turns the row into the parameter gradients: plain copy (torch layout), or the weight-norm backward
+//   w = g v / |v|  =>  dg = <dw, v> / |v| ;  dv = (g / |v|) (dw - v <dw, v> / |v|^2)          (utils of torch.nn.utils.weight_norm)
+struct WfArgs {
+  const float* slab0;
+  const float* slab1;
+  int slices;
+  pwg_wavenet_param_grad conv[4];  // dil, aux, skip, out
+};
+constexpr int WF_N0 = WN_K * WN_R + 80 + 1;  // 273
+constexpr int WF_N1 = WN_R + 1;              // 65
+constexpr int WF_THREADS = 832;              // 13 waves >= 3 * 273 and >= 12 * 65
+
+__device__ __forceinline__ void wf_finish_row(const pwg_wavenet_param_grad& cv, const float* tot, int n, int row, int lane,
+                                              bool tap_major) {
+  if (cv.dw == nullptr) return;
+  float dwv[3], vv[3];
+  float svv = 0.f, sdv = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int e = lane + 64 * k;  // torch index inside the row: (ci, tap) with tap fastest
+    dwv[k] = vv[k] = 0.f;
+    if (e < n) {
+      dwv[k] = tot[tap_major ? (e % WN_K) * WN_R + e / WN_K : e];
+      if (cv.v) {
+        vv[k] = cv.v[(long)row * n + e];
+        svv += vv[k] * vv[k];
+        sdv += vv[k] * dwv[k];
+      }
+    }
+  }
+  float c1 = 1.f, c2 = 0.f;
+  if (cv.v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      svv += __shfl_xor(svv, o, 64);
+      sdv += __shfl_xor(sdv, o, 64);
+    }
+    const float norm = sqrtf(svv);
+    if (lane == 0 && cv.dg) cv.dg[row] = sdv / norm;
+    c1 = cv.g[row] / norm;
+    c2 = sdv / svv;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int e = lane + 64 * k;
+    if (e < n) cv.dw[(long)row * n + e] = c1 * (dwv[k] - vv[k] * c2);
+  }
+}
+
+__global__ __launch_bounds__(WF_THREADS) void wavenet_wgrad_finish_kernel(WfArgs a) {
+  __shared__ float part[3 * WF_N0];
+  __shared__ float tot[WF_N0];
+  const int layer = blockIdx.x >> 7, m = blockIdx.x & 127;
+  const int cols = layer == 0 ? WF_N0 : WF_N1;
+  const int SL = layer == 0 ? 3 : 12;
+  const int tid = threadIdx.x;
+  const int sl = tid / cols, col = tid - sl * cols;
+  const long sstride = (long)WN_G * cols;
+  const float* src = (layer == 0 ? a.slab0 : a.slab1) + (long)m * cols + col;
+  if (sl < SL) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four loads in flight
+    int j = sl;
+    for (; j + 3 * SL < a.slices; j += 4 * SL) {
+      s0 += src[(long)j * sstride];
+      s1 += src[(long)(j + SL) * sstride];
+      s2 += src[(long)(j + 2 * SL) * sstride];
+      s3 += src[(long)(j + 3 * SL) * sstride];
+    }
+    for (; j < a.slices; j += SL) s0 += src[(long)j * sstride];
+    part[sl * cols + col] = (s0 + s1) + (s2 + s3);
+  }
+  __syncthreads();
+  if (tid < cols) {
+    float t = part[tid];
+    for (int q = 1; q < SL; ++q) t += part[q * cols + tid];
+    tot[tid] = t;
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
+  if (layer == 0) {
+    if (wave == 0) wf_finish_row(a.conv[0], tot, WN_K * WN_R, m, lane, true);
+    if (wave == 1) wf_finish_row(a.conv[1], tot + WN_K * WN_R, 80, m, lane, false);
+    if (tid == 128) {
+      if (a.conv[0].db) a.conv[0].db[m] = tot[WF_N0 - 1];
+      if (a.conv[1].db) a.conv[1].db[m] = tot[WF_N0 - 1];
+    }
+  } else {
+    const pwg_wavenet_param_grad& cv = a.conv[m < WN_S ? 2 : 3];
+    const int mm = m < WN_S ? m : m - WN_S;
+    if (wave == 0) wf_finish_row(cv, tot, WN_R, mm, lane, false);
+    if (tid == 64 && cv.db) cv.db[mm] = tot[WF_N1 - 1];
+  }
+}
+
 static bool wavenet_ok(const pwg_wavenet_desc* d) {
   if (!d) return false;
   if (d->residual_channels != WN_R || d->gate_channels != WN_G || d->skip_channels != WN_S || d->kernel != WN_K) return false;
@@ -808,6 +1060,86 @@ int pwg_wavenet_data_backward(const pwg_wavenet_desc* d, const float* dz, const 
     hipLaunchKernelGGL(wavenet_dgrad_kernel, dim3(ceil_div(d->t, WD_COLS), d->batch), dim3(256), lds, stream, a);
   }
   PWG_CHECK_LAUNCH("wavenet_data_backward");
+  return PWG_OK;
+}
+
+static int ww_slices(const pwg_wavenet_desc* d, int* chunks_per_slice) {
+  const int chunks = d->batch * ceil_div(d->t, WW_COLS);
+  int per = ceil_div(chunks, 256);  // one workgroup (8 waves) per CU
+  if (per < 2) per = chunks >= 2 ? 2 : 1;
+  *chunks_per_slice = per;
+  return ceil_div(chunks, per);
+}
+
+size_t pwg_wavenet_weight_backward_workspace_floats(const pwg_wavenet_desc* d) {
+  if (!wavenet_ok(d)) return 0;
+  int per;
+  const int slices = ww_slices(d, &per);
+  return (size_t)slices * WN_G * ((size_t)(WN_K * WN_R + d->aux_channels + 1) + (WN_R + 1));
+}
+
+int pwg_wavenet_weight_backward(const pwg_wavenet_desc* d, const float* dz, const float* x, const float* c, const float* gs,
+                                const float* go, const float* g, const pwg_wavenet_param_grad* grads, float* workspace,
+                                size_t workspace_floats, void* stream_) {
+  PWG_REQUIRE(wavenet_ok(d), PWG_ERR_UNSUPPORTED, "wavenet_weight_backward: unsupported layer geometry");
+  PWG_REQUIRE(dz && x && c && gs && g && grads && workspace, PWG_ERR_NULL, "wavenet_weight_backward: NULL pointer");
+  PWG_REQUIRE(grads[0].dw && grads[1].dw && grads[2].dw, PWG_ERR_NULL, "wavenet_weight_backward: NULL weight gradient");
+  PWG_REQUIRE((go == nullptr) == (grads[3].dw == nullptr), PWG_ERR_NULL, "wavenet_weight_backward: grads[3] goes with go");
+  for (int i = 0; i < 4; ++i)
+    PWG_REQUIRE((grads[i].v == nullptr) == (grads[i].g == nullptr) && (grads[i].v != nullptr || grads[i].dg == nullptr), PWG_ERR_NULL,
+                "wavenet_weight_backward: grads[%d]: v, g (and dg) go together", i);
+  PWG_REQUIRE(workspace_floats >= pwg_wavenet_weight_backward_workspace_floats(d), PWG_ERR_WORKSPACE,
+              "wavenet_weight_backward: workspace too small");
+  PWG_REQUIRE(!d->causal, PWG_ERR_UNSUPPORTED, "wavenet_weight_backward: the causal form is not built");
+  hipStream_t stream = (hipStream_t)stream_;
+  int per;
+  const int slices = ww_slices(d, &per);
+  constexpr int N0 = WN_K * WN_R + 80, N1 = WN_R;
+  float* slab0 = workspace;
+  float* slab1 = workspace + (size_t)slices * WN_G * (N0 + 1);
+  WwArgs a = {};
+  a.T = d->t;
+  a.chunks_per_item = ceil_div(d->t, WW_COLS);
+  a.chunks_total = d->batch * a.chunks_per_item;
+  a.chunks_per_slice = per;
+  const double samples = (double)d->batch * d->t;
+  maybe_poison_lds(stream);
+  {
+    a.m_src[0] = dz; a.m_rows[0] = WN_G; a.m_src[1] = nullptr; a.m_rows[1] = 0;
+    for (int t = 0; t < WN_K; ++t) { a.n_src[t] = x; a.n_rows[t] = WN_R; a.n_shift[t] = (t - 1) * d->dilation; }
+    a.n_src[3] = c; a.n_rows[3] = d->aux_channels; a.n_shift[3] = 0;
+    a.slabs = slab0;
+    const size_t lds = ((size_t)WW_COLS * (WN_G + N0 + 1) + 32) * sizeof(float);
+    void (*kern)(WwArgs) = wavenet_wgrad_kernel<N0>;
+    if (!lds_limit_is_set(reinterpret_cast<const void*>(kern), lds)) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      PWG_REQUIRE(e == hipSuccess, PWG_ERR_LAUNCH, "wavenet_weight_backward: cannot raise the LDS limit: %s", hipGetErrorString(e));
+    }
+    ProfScope prof(stream, "wavenet_wgrad_kernel<dil+aux>", 2.0 * samples * WN_G * N0, 4.0 * samples * (WN_G + WN_R + d->aux_channels));
+    hipLaunchKernelGGL(kern, dim3(slices), dim3(512), lds, stream, a);
+    PWG_CHECK_LAUNCH("wavenet_weight_backward");
+  }
+  {
+    a.m_src[0] = gs; a.m_rows[0] = WN_S; a.m_src[1] = go; a.m_rows[1] = WN_R;
+    a.n_src[0] = g; a.n_rows[0] = WN_R; a.n_shift[0] = 0;
+    for (int t = 1; t < 4; ++t) { a.n_src[t] = g; a.n_rows[t] = 0; a.n_shift[t] = 0; }
+    a.slabs = slab1;
+    const size_t lds = ((size_t)WW_COLS * (WN_G + N1 + 1) + 32) * sizeof(float);
+    static_assert(((size_t)WW_COLS * (WN_G + N1 + 1) + 32) * sizeof(float) <= 64 * 1024, "skip+out tile fits the default LDS limit");
+    ProfScope prof(stream, "wavenet_wgrad_kernel<skip+out>", 2.0 * samples * WN_G * N1, 4.0 * samples * (WN_G + WN_R));
+    hipLaunchKernelGGL(wavenet_wgrad_kernel<N1>, dim3(slices), dim3(512), lds, stream, a);
+    PWG_CHECK_LAUNCH("wavenet_weight_backward");
+  }
+  {
+    WfArgs f = {};
+    f.slab0 = slab0;
+    f.slab1 = slab1;
+    f.slices = slices;
+    for (int i = 0; i < 4; ++i) f.conv[i] = grads[i];
+    ProfScope prof(stream, "wavenet_wgrad_finish_kernel", 0, 4.0 * slices * WN_G * (double)(N0 + N1 + 2));
+    hipLaunchKernelGGL(wavenet_wgrad_finish_kernel, dim3(2 * WN_G), dim3(WF_THREADS), 0, stream, f);
+    PWG_CHECK_LAUNCH("wavenet_wgrad_finish");
+  }
   return PWG_OK;
 }
 

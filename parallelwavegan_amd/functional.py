@@ -4,6 +4,7 @@ gradients of tensors used more than once; it performs no convolution/loss arithm
 """
 import ctypes
 import math
+import os
 
 import torch
 
@@ -295,8 +296,16 @@ class WaveNetLayerFn(torch.autograd.Function):
                                              _stream()), "act_backward")
         grads = []
         pi = 5
-        for cv, hd, dsc, xin, gsum in ((conv_d, h_d, d_d, x, dz), (conv_a, h_a, d_a, c, dz), (conv_s, h_s, d_s, gt, gs),
-                                       (conv_o, h_o, d_o, gt, go)):
+        fused_w = None
+        if os.environ.get("PWG_NO_WAVENET_WGRAD", "0") != "1":
+            # weight path: every parameter gradient of the layer in three launches (csrc/wavenet.hip)
+            fused_w = ops.wavenet_weight_backward(
+                desc, dz, x, c, gs, go, gt,
+                convs=[(hd.w if cv.has_weight_norm else None,
+                        cv.weight_g.detach().reshape(-1) if cv.has_weight_norm else None, cv.bias is not None)
+                       for cv, hd in ((conv_d, h_d), (conv_a, h_a), (conv_s, h_s), (conv_o, h_o))])
+        for i, (cv, hd, dsc, xin, gsum) in enumerate(((conv_d, h_d, d_d, x, dz), (conv_a, h_a, d_a, c, dz),
+                                                      (conv_s, h_s, d_s, gt, gs), (conv_o, h_o, d_o, gt, go))):
             has_g = cv.has_weight_norm
             n_par = 1 + int(has_g) + int(cv.bias is not None)
             if gsum is None:
@@ -308,8 +317,13 @@ class WaveNetLayerFn(torch.autograd.Function):
             need_b = cv.bias is not None and need[pi + 1 + int(has_g)]
             v = hd.w
             g = cv.weight_g.detach() if has_g else None
-            dw, dg, db = conv_param_grads(dsc, xin, gsum, tuple(v.shape), tuple(cv.raw_weight.shape), v, g, need_w, need_g,
-                                          need_b)
+            if fused_w is not None:
+                dw, dg, db = fused_w[i]
+                dw = dw.reshape(cv.raw_weight.shape)
+                dg = None if dg is None else dg.reshape(g.shape)
+            else:
+                dw, dg, db = conv_param_grads(dsc, xin, gsum, tuple(v.shape), tuple(cv.raw_weight.shape), v, g, need_w,
+                                              need_g, need_b)
             grads.append(dw)
             if has_g:
                 grads.append(dg)

@@ -218,6 +218,41 @@ def wavenet_data_backward(desc, dz, go, packed_bwd, need_dx=True, need_dc=True):
     return dx, dc
 
 
+def wavenet_weight_backward(desc, dz, x, c, gs, go, g, convs=None):
+    """Parameter gradients of the layer's four convolutions (csrc/wavenet.hip: two contraction launches + one finish
+    launch).  ``convs`` = four ``(v, g, has_bias)`` entries (dilated, aux, skip, out): ``v``/``g`` the weight-norm
+    tensors or None for a plain weight.  Returns four ``(dw_or_dv, dg, db)`` tuples in torch layouts
+    ((128,64,3), (128,aux,1), (64,64,1), (64,64,1)); the last is (None, None, None) when ``go`` is None (the
+    layer's residual output is unused)."""
+    if convs is None:
+        convs = ((None, None, True), (None, None, False), (None, None, True), (None, None, True))
+    _require_device(dz, x, c, gs, go, g, *[t for cv in convs for t in cv[:2]])
+    dev = dz.device
+    r, gch, sch, aux = desc.residual_channels, desc.gate_channels, desc.skip_channels, desc.aux_channels
+    shapes = ((gch, r, desc.kernel), (gch, aux, 1), (sch, r, 1), (r, r, 1))
+    arr = (_lib.WaveNetParamGrad * 4)()
+    outs = []
+    for i, ((v, gg, has_b), shp) in enumerate(zip(convs, shapes)):
+        if i == 3 and go is None:
+            outs.append((None, None, None))
+            continue
+        if v is not None and (tuple(v.shape) != shp or gg is None or gg.numel() != shp[0] or not v.is_contiguous()
+                              or not gg.is_contiguous()):
+            raise ValueError(f"wavenet_weight_backward: conv {i}: weight-norm tensors do not match {shp}")
+        dw = torch.empty(shp, device=dev, dtype=torch.float32)
+        dg = torch.empty_like(gg) if v is not None else None
+        db = torch.empty(shp[0], device=dev, dtype=torch.float32) if has_b else None
+        arr[i].v, arr[i].g, arr[i].dw, arr[i].dg, arr[i].db = _ptr(v), _ptr(gg), _ptr(dw), _ptr(dg), _ptr(db)
+        outs.append((dw, dg, db))
+    n = _lib.lib().pwg_wavenet_weight_backward_workspace_floats(ctypes.byref(desc))
+    if n == 0:
+        _lib.check(-1, "wavenet_weight_backward_workspace_floats")
+    ws = torch.empty(n, device=dev, dtype=torch.float32)
+    _lib.check(_lib.lib().pwg_wavenet_weight_backward(ctypes.byref(desc), _ptr(dz), _ptr(x), _ptr(c), _ptr(gs), _ptr(go),
+                                                      _ptr(g), arr, _ptr(ws), n, _stream()), "wavenet_weight_backward")
+    return outs
+
+
 def pack_weight_bwd(desc, w, scale=None):
     """Weight image for the data-gradient direction of ``desc`` (forward descriptor)."""
     _require_device(w, scale)

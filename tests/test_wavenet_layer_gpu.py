@@ -84,3 +84,81 @@ def test_fused_layer_autograd_matches_unfused(dil, skip_scale, first, device):
         xo, so = blk(x0, c0, skips=s_in, skip_scale=skip_scale)
     assert _rel(xo, res[False]["xo"]) <= 3e-5 and _rel(so, res[False]["so"]) <= 3e-5
     assert s_in is None or so.data_ptr() == s_in.data_ptr()
+
+
+@pytest.mark.parametrize("B,T,dil,with_go", [(3, 4133, 27, True), (1, 64, 1, True), (2, 9000, 512, False), (6, 25600, 4, True)])
+def test_weight_backward_kernel_matches_float64(B, T, dil, with_go, device):
+    """csrc/wavenet.hip weight path against a float64 contraction of the same operands (every tail: T not a
+    multiple of the 64-column chunk, taps reaching over both ends, the residual output unused)."""
+    torch.manual_seed(11)
+    desc = ops.make_wavenet_desc(B, T, dil)
+    dz = torch.randn(B, 128, T, device=device)
+    x = torch.randn(B, 64, T, device=device)
+    c = torch.randn(B, 80, T, device=device)
+    gs = torch.randn(B, 64, T, device=device)
+    go = torch.randn(B, 64, T, device=device) if with_go else None
+    g = torch.randn(B, 64, T, device=device)
+    flat = lambda outs: [t for o in outs for t in o]  # noqa: E731
+    with poison_lds(), poison_empty():
+        outs = ops.wavenet_weight_backward(desc, dz, x, c, gs, go, g)
+        again = ops.wavenet_weight_backward(desc, dz, x, c, gs, go, g)
+    (dwd, _, dbd), (dwa, _, dba), (dws, _, dbs), (dwo, _, dbo) = outs
+    assert dba is None
+    f = lambda t: t.double()  # noqa: E731
+    xp = torch.nn.functional.pad(f(x), (dil, dil))
+    want_d = torch.stack([torch.einsum("bmt,bct->mc", f(dz), xp[:, :, k * dil:k * dil + T]) for k in range(3)], dim=2)
+    want = dict(dwd=want_d, dwa=torch.einsum("bmt,bct->mc", f(dz), f(c))[:, :, None], dbd=f(dz).sum((0, 2)),
+                dws=torch.einsum("bmt,bct->mc", f(gs), f(g))[:, :, None], dbs=f(gs).sum((0, 2)))
+    got = dict(dwd=dwd, dwa=dwa, dbd=dbd, dws=dws, dbs=dbs)
+    if with_go:
+        want.update(dwo=torch.einsum("bmt,bct->mc", f(go), f(g))[:, :, None], dbo=f(go).sum((0, 2)))
+        got.update(dwo=dwo, dbo=dbo)
+    else:
+        assert dwo is None and dbo is None
+    for k in want:
+        assert got[k].shape == want[k].shape, k
+        assert torch.isfinite(got[k]).all(), k
+        assert _rel(got[k].double(), want[k]) <= 2e-5, (k, _rel(got[k].double(), want[k]))
+    for a, b in zip(flat(outs), flat(again)):  # fixed slices, ordered sums: bit-identical
+        assert (a is None and b is None) or torch.equal(a, b)
+    # weight-normalised form: (dv, dg) = torch's autograd through w = g v / |v| applied to the plain gradients
+    vs = [torch.randn(s, device=device) for s in ((128, 64, 3), (128, 80, 1), (64, 64, 1), (64, 64, 1))]
+    gm = [torch.rand(v.shape[0], device=device) + 0.5 for v in vs]
+    with poison_lds(), poison_empty():
+        outs_wn = ops.wavenet_weight_backward(desc, dz, x, c, gs, go, g,
+                                              convs=[(v, gg, i != 1) for i, (v, gg) in enumerate(zip(vs, gm))])
+    for i, (v, gg) in enumerate(zip(vs, gm)):
+        if outs[i][0] is None:
+            assert outs_wn[i] == (None, None, None)
+            continue
+        v64, g64 = f(v).requires_grad_(), f(gg).requires_grad_()
+        w = g64[:, None, None] * v64 / v64.flatten(1).norm(dim=1)[:, None, None]
+        w.backward(f(outs[i][0]))
+        assert _rel(outs_wn[i][0].double(), v64.grad) <= 2e-5, i
+        assert _rel(outs_wn[i][1].double(), g64.grad) <= 2e-5, i
+        assert (outs_wn[i][2] is None) == (outs[i][2] is None)
+        assert outs[i][2] is None or torch.equal(outs_wn[i][2], outs[i][2])
+
+
+def test_fused_layer_backward_without_residual_output(device):
+    """The last layer of the generator: only the skip output reaches the loss (dx_out is None)."""
+    torch.manual_seed(5)
+    blk = WaveNetResidualBlock(dilation=2).to(device)
+    for cv in (blk.conv, blk.conv1x1_aux, blk.conv1x1_skip, blk.conv1x1_out):
+        cv.apply_weight_norm()
+    x0, c0 = torch.randn(2, 64, 700, device=device), torch.randn(2, 80, 700, device=device)
+    ws = torch.randn(2, 64, 700, device=device)
+    res = {}
+    for fused in (True, False):
+        blk.fuse_layer = fused
+        blk.zero_grad()
+        x = x0.clone().requires_grad_()
+        with poison_lds(), poison_empty():
+            _, so = blk(x, c0, skips=None, skip_scale=1.0)
+            (so * ws).sum().backward()
+        res[fused] = dict(dx=x.grad, **{n: (None if p.grad is None else p.grad.clone()) for n, p in blk.named_parameters()})
+    for k in res[True]:
+        a, b = res[True][k], res[False][k]
+        assert (a is None) == (b is None) or (a is None and float(b.abs().max()) == 0.0) or (b is None and float(a.abs().max()) == 0.0), k
+        if a is not None and b is not None:
+            assert _rel(a, b) <= 5e-5, (k, _rel(a, b))

@@ -30,3 +30,14 @@ for B, T, save in ((16, 102400, False), (6, 25600, False), (6, 25600, True)):
         fl = 2.0 * B * T * (128 * 272 + 128 * 64)
         by = 4.0 * B * T * (64 * 4 + 80 + (192 if save else 0))
         print(f"B{B} T{T} d{dil:3d} save{int(save)}: {t*1e3:7.1f} us {fl/t/1e9:6.1f} TF {by/t/1e6:6.0f} GB/s", flush=True)
+
+# backward, weight path (two contraction launches + two reduce launches; PWG_PROFILE=1 prints each)
+B, T = 6, 25600
+dz = torch.randn(B, 128, T, device=dev)
+x, c, g = torch.randn(B, 64, T, device=dev), torch.randn(B, 80, T, device=dev), torch.randn(B, 64, T, device=dev)
+gs, go = torch.randn(B, 64, T, device=dev), torch.randn(B, 64, T, device=dev)
+for dil in (1, 16, 512):
+    desc = ops.make_wavenet_desc(B, T, dil, out_mul=math.sqrt(.5))
+    t = timeit(lambda: ops.wavenet_weight_backward(desc, dz, x, c, gs, go, g))
+    fl = 2.0 * B * T * 128 * (272 + 64)
+    print(f"weight backward B{B} T{T} d{dil:3d}: {t*1e3:7.1f} us {fl/t/1e9:6.1f} TF", flush=True)
