@@ -164,17 +164,21 @@ class ParallelWaveGANDiscriminator(torch.nn.Module, _WeightNormMixin):
 
     def forward(self, x):
         """(B, 1, T) -> (B, 1, T)."""
-        mods = list(self.conv_layers)
-        i = 0
-        while i < len(mods):
-            conv = mods[i]
-            if i + 1 < len(mods) and isinstance(mods[i + 1], FusedActivation):
-                act = mods[i + 1]
-                x = conv(x, post_act=act.kind, post_slope=act.slope)
-                i += 2
+        # each LeakyReLU rides on the NEXT convolution as its pre-activation (applied to the staged input tile), so
+        # that the backward needs no separate activation-gradient pass: the next convolution's data-gradient kernel
+        # multiplies by act'(x) in its epilogue and its weight-gradient kernel re-applies act on load.
+        pending = None
+        for mod in self.conv_layers:
+            if isinstance(mod, FusedActivation):
+                pending = mod
+                continue
+            if pending is None:
+                x = mod(x)
             else:
-                x = conv(x)
-                i += 1
+                x = mod(x, pre_act=pending.kind, pre_slope=pending.slope)
+            pending = None
+        if pending is not None:
+            raise RuntimeError("ParallelWaveGANDiscriminator: the layer list must end with a convolution")
         return x
 
 
