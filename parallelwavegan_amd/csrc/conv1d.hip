@@ -277,12 +277,33 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WM * WN >= 8 ? 1 : (WM * W
   const int l31 = lane & 31;
   const int lhi = lane >> 5;
 
-  const int n0 = blockIdx.x * BN;
+  // XCD-aware tile order.  The dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs, each with its
+  // own 4 MB L2.  In grid order the row blocks of one column tile -- which stage the SAME x window -- sit gridDim.x ids
+  // apart, on different XCDs, and each pulls that window from HBM.  The remap hands every XCD one contiguous run of
+  // logical tiles ordered row-block fastest, then column tile: the row blocks of a column tile (and the neighbouring
+  // column tiles, which share the halo) are resident on one XCD at the same time and meet in its L2.  A bijection for
+  // any grid size, so results do not depend on the dispatch assumption.  (PWG_DBG bit 16 = grid order, for the A/B.)
   const int mtiles = (a.m_g + BM - 1) / BM;
-  const int g = blockIdx.y / mtiles;
-  const int m0 = (blockIdx.y % mtiles) * BM;
-  const int b = blockIdx.z / a.ksplit;
-  const int ks = blockIdx.z - b * a.ksplit;  // reduction slice of this workgroup
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (!(a.dbg & 16)) {
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    const unsigned total = gx * gy * gridDim.z;
+    unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned per = total >> 3, rem = total & 7, xcd = lin & 7, seq = lin >> 3;
+    lin = xcd < rem ? xcd * (per + 1) + seq : rem * (per + 1) + (xcd - rem) * per + seq;
+    const unsigned mi = lin % mtiles;
+    lin /= mtiles;
+    bx = lin % gx;
+    lin /= gx;
+    const unsigned ngroups = gy / mtiles;
+    by = (lin % ngroups) * mtiles + mi;
+    bz = lin / ngroups;
+  }
+  const int n0 = bx * BN;
+  const int g = by / mtiles;
+  const int m0 = (by % mtiles) * BM;
+  const int b = bz / a.ksplit;
+  const int ks = bz - b * a.ksplit;  // reduction slice of this workgroup
 
   const int W = a.width;
   const int h0 = n0 / W;
