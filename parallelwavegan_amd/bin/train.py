@@ -85,7 +85,7 @@ class Trainer(object):
                 # the branches share the chip: a launch need not fill it alone (fewer, more efficient tiles and
                 # fewer weight-gradient slabs; measured +2.7 % on the HiFi-GAN V1 step).  Applied around every
                 # step (the hint is process-wide), see _train_step
-                self._concurrency_hint = float(config.get("conv_concurrency_hint", 0.5))
+                self._concurrency_hint = float(os.environ.get("PWG_CONCURRENCY_HINT", config.get("conv_concurrency_hint", 0.5)))
         self.reducers = None
         if config.get("distributed", False):
             self.reducers = {}

@@ -257,7 +257,8 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // (second launch bound: at least 2 waves per SIMD unless the wave owns 8 accumulator tiles -- hipcc's
 // allocation for the 2x2-tile waves otherwise flips between 174 and 256 VGPRs on unrelated edits)
 template <int WM, int WN, int WAVES_M, int WAVES_N, int CK, bool FAST, int ACT>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WM * WN >= 8 ? 1 : (WM * WN == 1 ? 4 : 2))) void conv1d_mfma_dma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WM * WN >= 8 ? 1 : (WM * WN == 1 ? 4 : (WAVES_M * WAVES_N == 4 && CK == 4 ? 3 : 2)))) void conv1d_mfma_dma_kernel(ConvArgs a) {
+  constexpr bool SLIM = WM * WN == 4 && WAVES_M * WAVES_N == 4 && CK == 4;  // 3 waves per SIMD (168 VGPRs)
   constexpr int BM = 32 * WM * WAVES_M;
   constexpr int BN = 32 * WN * WAVES_N;
   constexpr int NWAVES = WAVES_M * WAVES_N;
@@ -512,16 +513,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WM * WN >= 8 ? 1 : (WM * W
       const long tile_base = ybase + (long)(g * a.cout_g + m_w0) * a.y_cstride + n_w0;  // wave-uniform
       // the residual (add1) loads of ALL the wave's tiles are issued first (one exposure of the memory latency
       // instead of one per tile); add2 (last convolution of an MRF block) and the dgrad mask per tile
-      float4 a1v[WM][WN][4];
+      // (three-waves-per-SIMD instantiations, 168 VGPRs: per tile instead -- the third resident workgroup hides it)
+      constexpr bool PF_ALL = !SLIM;
+      float4 a1v[PF_ALL ? WM : 1][PF_ALL ? WN : 1][4];
+      if (PF_ALL) {
 #pragma unroll
-      for (int mi = 0; mi < WM; ++mi)
+        for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < WN; ++ni)
+          for (int ni = 0; ni < WN; ++ni)
 #pragma unroll
-          for (int ps = 0; ps < 4; ++ps) {
-            const unsigned o = (unsigned)(mi * 32 + ps * 8 + trow) * (unsigned)a.y_cstride + (unsigned)(ni * 32 + tcol);
-            if (add1_p) a1v[mi][ni][ps] = *reinterpret_cast<const float4*>(add1_p + tile_base + o);
-          }
+            for (int ps = 0; ps < 4; ++ps) {
+              const unsigned o = (unsigned)(mi * 32 + ps * 8 + trow) * (unsigned)a.y_cstride + (unsigned)(ni * 32 + tcol);
+              if (add1_p) a1v[PF_ALL ? mi : 0][PF_ALL ? ni : 0][ps] = *reinterpret_cast<const float4*>(add1_p + tile_base + o);
+            }
+      }
 #pragma unroll
       for (int mi = 0; mi < WM; ++mi) {
 #pragma unroll
@@ -537,6 +542,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WM * WN >= 8 ? 1 : (WM * W
             const int row = mi * 32 + ps * 8 + trow;
             off[ps] = (unsigned)row * (unsigned)a.y_cstride + (unsigned)(ni * 32 + tcol);
             bs[ps] = bias_p ? bias_p[g * a.cout_g + m_w0 + row] : 0.f;
+            if (!PF_ALL && add1_p) a1v[0][0][ps] = *reinterpret_cast<const float4*>(add1_p + tile_base + off[ps]);
             if (add2_p) a2v[ps] = *reinterpret_cast<const float4*>(add2_p + tile_base + off[ps]);
             if (mask_p) mkv[ps] = *reinterpret_cast<const float4*>(mask_p + tile_base + off[ps]);
           }
@@ -546,7 +552,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WM * WN >= 8 ? 1 : (WM * W
           for (int ps = 0; ps < 4; ++ps) {
             float o[4] = {v[ps].x, v[ps].y, v[ps].z, v[ps].w};
             const float m4[4] = {mkv[ps].x, mkv[ps].y, mkv[ps].z, mkv[ps].w};
-            const float p4[4] = {a1v[mi][ni][ps].x, a1v[mi][ni][ps].y, a1v[mi][ni][ps].z, a1v[mi][ni][ps].w};
+            const float4 a1t = a1v[PF_ALL ? mi : 0][PF_ALL ? ni : 0][ps];
+            const float p4[4] = {a1t.x, a1t.y, a1t.z, a1t.w};
             const float q4[4] = {a2v[ps].x, a2v[ps].y, a2v[ps].z, a2v[ps].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -574,7 +581,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WM * WN >= 8 ? 1 : (WM * W
 #pragma unroll
     for (int mi = 0; mi < WM; ++mi) {
       // (RB outputs at a time: 8 for the single-tile waves that run at 4 waves per SIMD / 128 VGPRs)
-      constexpr int RB = WM * WN == 1 ? 8 : 16;
+      constexpr int RB = SLIM ? 4 : (WM * WN == 1 ? 8 : 16);
 #pragma unroll
       for (int r0 = 0; r0 < 16; r0 += RB) {
         long off[RB];
