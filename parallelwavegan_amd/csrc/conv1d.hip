@@ -257,8 +257,8 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // (second launch bound: at least 2 waves per SIMD unless the wave owns 8 accumulator tiles -- hipcc's
 // allocation for the 2x2-tile waves otherwise flips between 174 and 256 VGPRs on unrelated edits)
 template <int WM, int WN, int WAVES_M, int WAVES_N, int CK, bool FAST, int ACT>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WM * WN >= 8 ? 1 : (WM * WN == 1 ? 4 : (WAVES_M * WAVES_N == 4 && CK == 4 ? 3 : 2)))) void conv1d_mfma_dma_kernel(ConvArgs a) {
-  constexpr bool SLIM = WM * WN == 4 && WAVES_M * WAVES_N == 4 && CK == 4;  // 3 waves per SIMD (168 VGPRs)
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WM * WN >= 8 ? 1 : (WM * WN == 1 ? 4 : (WAVES_M * WAVES_N == 4 ? 3 : 2)))) void conv1d_mfma_dma_kernel(ConvArgs a) {
+  constexpr bool SLIM = WM * WN >= 2 && WAVES_M * WAVES_N == 4;  // 3 waves per SIMD (168 VGPRs)
   constexpr int BM = 32 * WM * WAVES_M;
   constexpr int BN = 32 * WN * WAVES_N;
   constexpr int NWAVES = WAVES_M * WAVES_N;
