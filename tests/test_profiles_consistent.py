@@ -26,3 +26,21 @@ def test_traffic_summary_is_derived_from_the_committed_raw_counters(tmp_path):
     bench = json.load(open(os.path.join(ROOT, "profiles", "r02_i_bench.json")))
     assert bench["roofline"]["traffic"] == old["hbm_bytes_per_launch"]
     assert bench["roofline"]["launches_per_step"] == old["launches_per_forward"]
+
+
+def test_round3_traffic_summary_is_derived_from_the_committed_raw_counters(tmp_path):
+    """Same for round 3 (tools/pmc_round3.sh -> tools/pmc_round3_summary.py: FETCH_SIZE x 2 on gfx950, calibrated in
+    the same run), the file bench.py's `roofline.traffic` cites."""
+    out = tmp_path / "traffic.json"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_round3_summary.py"),
+                           os.path.join(ROOT, "profiles", "r03_pmc_hbm_raw.json"),
+                           os.path.join(ROOT, "profiles", "r03_pmc_infer_bench.json"), str(out)],
+                          stdout=subprocess.DEVNULL)
+    new = json.load(open(out))
+    old = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")))
+    for fam in ("conv1d_mfma_dma_kernel", "resunit_kernel"):
+        for key in ("hbm_bytes_per_launch", "algorithmic_bytes_per_launch"):
+            assert abs(new["kernels"][fam][key] - old["kernels"][fam][key]) <= 1e-9 * old["kernels"][fam][key]
+    assert abs(old["calibration"]["fetch_factor_used"] - 2.0) < 1e-3 and abs(old["calibration"]["write_factor_used"] - 1.0) < 1e-3
+    conv = old["kernels"]["conv1d_mfma_dma_kernel"]
+    assert conv["traffic_over_algorithmic"] < 1.3  # (XCD-aware tile order; 1.88 before it)
