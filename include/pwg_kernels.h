@@ -266,8 +266,10 @@ int pwg_wavenet_pack_weights_bwd(const pwg_wavenet_desc* d, const float* w_dil, 
                                  const float* scale_out, float* packed, void* stream);
 int pwg_wavenet_gate_backward(const pwg_wavenet_desc* d, const float* z, const float* dx_out, const float* ds_out,
                               const float* packed_bwd, float* dz, float* go, void* stream);
-int pwg_wavenet_data_backward(const pwg_wavenet_desc* d, const float* dz, const float* go, const float* packed_bwd, float* dx,
-                              float* dc, void* stream);
+/* dc_accum (may be NULL, may alias dc): the gradient the LATER layers already accumulated for the shared aux features
+ * c -- added in the epilogue, so the sum over the 30 layers needs no separate add launches.                          */
+int pwg_wavenet_data_backward(const pwg_wavenet_desc* d, const float* dz, const float* go, const float* packed_bwd,
+                              const float* dc_accum, float* dx, float* dc, void* stream);
 /* The layer's parameter gradients in three launches: two contractions over time -- dz (128 rows) against the three
  * tap windows of x and c (272 rows), and [gs = skip_mul * ds_out ; go] (128 rows) against the saved gate output g (64
  * rows) -- into per-slice slabs, and one finish kernel that sums the slices in a fixed order and writes, per

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libpwgkernels.so")
 
 PWG_ACT_NONE, PWG_ACT_LEAKY_RELU, PWG_ACT_TANH, PWG_ACT_RELU = 0, 1, 2, 3
 PWG_PAD_ZERO, PWG_PAD_REFLECT, PWG_PAD_REPLICATE = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class ConvDesc(ctypes.Structure):
@@ -147,7 +147,7 @@ SIGNATURES = {
     "pwg_wavenet_packed_weight_bwd_floats": (ctypes.c_size_t, [ctypes.POINTER(WaveNetDesc)]),
     "pwg_wavenet_pack_weights_bwd": (ctypes.c_int, [ctypes.POINTER(WaveNetDesc)] + [_vp] * 10),
     "pwg_wavenet_gate_backward": (ctypes.c_int, [ctypes.POINTER(WaveNetDesc)] + [_vp] * 7),
-    "pwg_wavenet_data_backward": (ctypes.c_int, [ctypes.POINTER(WaveNetDesc)] + [_vp] * 6),
+    "pwg_wavenet_data_backward": (ctypes.c_int, [ctypes.POINTER(WaveNetDesc)] + [_vp] * 7),
     "pwg_wavenet_weight_backward_workspace_floats": (ctypes.c_size_t, [ctypes.POINTER(WaveNetDesc)]),
     "pwg_wavenet_weight_backward": (ctypes.c_int, [ctypes.POINTER(WaveNetDesc)] + [_vp] * 6
                                     + [ctypes.POINTER(WaveNetParamGrad), _vp, ctypes.c_size_t, _vp]),

@@ -357,6 +357,7 @@ struct WnBwdArgs {
   float* go;            // gate kernel out (B, 64, T) or NULL
   float* dx;            // dgrad kernel out (B, 64, T) or NULL
   float* dc;            // dgrad kernel out (B, AUX, T) or NULL
+  const float* dc_in;   // dgrad kernel: gradient already accumulated for c by the later layers (added), or NULL
   int T, dil, aux;
   float out_mul;
   int vec_ok;
@@ -587,12 +588,19 @@ __global__ __launch_bounds__(256, 2) void wavenet_dgrad_kernel(WnBwdArgs a) {
     const float4* wc = w4 + (ROWS / 8) * 2 * 64;
     const float* blc = bl + WN_G * WD_COLS;
     const long ob = (long)b * a.aux * T + n;
+    // the gradient already accumulated by the later layers (dc_in) is fetched BEFORE the contraction (its latency
+    // hides under the MFMAs; it may alias dc: every element is read and written by the same lane)
     if (wave == 2) {
       f32x16 acc[2];
+      float pv[2][16];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int r = 0; r < 16; ++r) {
+          acc[i][r] = 0.f;
+          const int row = i * 32 + 8 * (r >> 2) + 4 * lhi + (r & 3);
+          pv[i][r] = (a.dc_in && n_ok && row < a.aux) ? a.dc_in[ob + (long)row * T] : 0.f;
+        }
       const float4* const wa[2] = {wc + lane, wc + 64 + lane};
       wn_contract<2>(acc, wa, 3 * 64, WN_G / 8, blc);
       if (n_ok) {
@@ -601,20 +609,25 @@ __global__ __launch_bounds__(256, 2) void wavenet_dgrad_kernel(WnBwdArgs a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = i * 32 + 8 * (r >> 2) + 4 * lhi + (r & 3);
-            if (row < a.aux) a.dc[ob + (long)row * T] = acc[i][r];
+            if (row < a.aux) a.dc[ob + (long)row * T] = acc[i][r] + pv[i][r];
           }
       }
     } else {
       f32x16 acc[1];
+      float pv[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+      for (int r = 0; r < 16; ++r) {
+        acc[0][r] = 0.f;
+        const int row = 64 + 8 * (r >> 2) + 4 * lhi + (r & 3);
+        pv[r] = (a.dc_in && n_ok && row < a.aux) ? a.dc_in[ob + (long)row * T] : 0.f;
+      }
       const float4* const wa[1] = {wc + 2 * 64 + lane};
       wn_contract<1>(acc, wa, 3 * 64, WN_G / 8, blc);
       if (n_ok) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = 64 + 8 * (r >> 2) + 4 * lhi + (r & 3);
-          if (row < a.aux) a.dc[ob + (long)row * T] = acc[0][r];
+          if (row < a.aux) a.dc[ob + (long)row * T] = acc[0][r] + pv[r];
         }
       }
     }
@@ -1036,8 +1049,8 @@ int pwg_wavenet_gate_backward(const pwg_wavenet_desc* d, const float* z, const f
   return PWG_OK;
 }
 
-int pwg_wavenet_data_backward(const pwg_wavenet_desc* d, const float* dz, const float* go, const float* packed_bwd, float* dx,
-                              float* dc, void* stream_) {
+int pwg_wavenet_data_backward(const pwg_wavenet_desc* d, const float* dz, const float* go, const float* packed_bwd,
+                              const float* dc_accum, float* dx, float* dc, void* stream_) {
   PWG_REQUIRE(wavenet_ok(d), PWG_ERR_UNSUPPORTED, "wavenet_data_backward: unsupported layer geometry");
   PWG_REQUIRE(dz && packed_bwd && (dx || dc), PWG_ERR_NULL, "wavenet_data_backward: NULL pointer");
   hipStream_t stream = (hipStream_t)stream_;
@@ -1047,6 +1060,7 @@ int pwg_wavenet_data_backward(const pwg_wavenet_desc* d, const float* dz, const 
   a.w = packed_bwd + 16 * 2 * 256;
   a.dx = dx;
   a.dc = dc;
+  a.dc_in = dc ? dc_accum : nullptr;
   a.T = d->t;
   a.dil = d->dilation;
   a.aux = d->aux_channels;
@@ -1056,7 +1070,7 @@ int pwg_wavenet_data_backward(const pwg_wavenet_desc* d, const float* dz, const 
   {
     ProfScope prof(stream, prof_shape_name("wavenet_dgrad_kernel", "B%d T%d d%d", d->batch, d->t, d->dilation),
                    2.0 * samples * WN_G * ((dx ? WN_K * WN_R : 0) + (dc ? d->aux_channels : 0)),
-                   4.0 * samples * (WN_G + (dx ? WN_R : 0) + (go ? WN_R : 0) + (dc ? d->aux_channels : 0)));
+                   4.0 * samples * (WN_G + (dx ? WN_R : 0) + (go ? WN_R : 0) + (dc ? d->aux_channels : 0) + (a.dc_in ? d->aux_channels : 0)));
     hipLaunchKernelGGL(wavenet_dgrad_kernel, dim3(ceil_div(d->t, WD_COLS), d->batch), dim3(256), lds, stream, a);
   }
   PWG_CHECK_LAUNCH("wavenet_data_backward");

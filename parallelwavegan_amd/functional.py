@@ -268,10 +268,16 @@ class WaveNetLayerFn(torch.autograd.Function):
         ctx.has_skips = skips is not None
         ctx.save_for_backward(x, c, z, gt)
         ctx.set_materialize_grads(False)
-        return x_out, s_out
+        # third output: c itself, for the NEXT layer -- the gradient of the shared aux features then arrives here
+        # already summed over the later layers and is an addend of this layer's data-gradient epilogue (one chain
+        # through the 30 layers instead of 29 accumulation launches of autograd)
+        c_next = c.view_as(c)
+        if not c.requires_grad:
+            ctx.mark_non_differentiable(c_next)
+        return x_out, s_out, c_next
 
     @staticmethod
-    def backward(ctx, dx_out, ds_out):
+    def backward(ctx, dx_out, ds_out, dc_next=None):
         x, c, z, gt = ctx.saved_tensors
         block, desc = ctx.block, ctx.desc
         conv_d, conv_a, conv_s, conv_o = block.fused_convs()
@@ -287,7 +293,8 @@ class WaveNetLayerFn(torch.autograd.Function):
         # data path: two launches (csrc/wavenet.hip): dz and go = out_mul * dx_out, then dx (+ go) and dc
         img = block.fused_image_bwd(desc.skip_mul)
         dz, go = ops.wavenet_gate_backward(desc, z, dx_out, ds_out, img)
-        dx, dc = ops.wavenet_data_backward(desc, dz, go, img, need_dx=need[0], need_dc=need[1])
+        dx, dc = ops.wavenet_data_backward(desc, dz, go, img, need_dx=need[0], need_dc=need[1],
+                                           dc_accum=None if dc_next is None else _c(dc_next))
         # gradient w.r.t. the pre-scale sum of the skip convolution (its weight-gradient operand / the incoming skips)
         gs = ds_out
         if desc.skip_mul != 1.0:

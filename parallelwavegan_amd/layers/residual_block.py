@@ -116,29 +116,32 @@ class WaveNetResidualBlock(torch.nn.Module):
             return False
         return ops.wavenet_layer_supported(self.fused_desc(x.shape[0], x.shape[2]))
 
-    def forward(self, x, c, skips=None, skip_scale=1.0):
+    def forward(self, x, c, skips=None, skip_scale=1.0, chain_aux=False):
         """Returns (x_out, skips + s) -- the running skip sum is an addend of the skip conv's epilogue
-        (``skip_scale`` is the final ``sqrt(1/layers)`` of the generator, applied by the last block)."""
+        (``skip_scale`` is the final ``sqrt(1/layers)`` of the generator, applied by the last block).
+        ``chain_aux``: also return the aux features for the NEXT layer (the same values; on the one-launch autograd
+        path an alias whose gradient is chained through the layers' data-gradient epilogues)."""
         if self._fusable(x, c):
             needs_grad = torch.is_grad_enabled() and (x.requires_grad or c.requires_grad
                                                       or (skips is not None and skips.requires_grad)
                                                       or any(p.requires_grad for p in self.fused_params()))
             if needs_grad:
-                return Fn.WaveNetLayerFn.apply(x, c, skips, self, skip_scale, *self.fused_params())
+                x_out, s_out, c_next = Fn.WaveNetLayerFn.apply(x, c, skips, self, skip_scale, *self.fused_params())
+                return (x_out, s_out, c_next) if chain_aux else (x_out, s_out)
             with torch.no_grad():
                 convs = self.fused_convs()
                 b_d, b_s, b_o = (None if cv.bias is None else cv.bias.detach() for cv in (convs[0], convs[2], convs[3]))
                 x_out, s_out, _, _ = ops.wavenet_layer_forward(self.fused_desc(x.shape[0], x.shape[2], skip_scale),
                                                                x.contiguous(), c.contiguous(), skips, self.fused_image(),
                                                                b_d, b_s, b_o, skips_out=skips)
-                return x_out, s_out
+                return (x_out, s_out, c) if chain_aux else (x_out, s_out)
         aux = self.conv1x1_aux(c) if (c is not None and self.conv1x1_aux is not None) else None
         # F.dropout on the dilated conv's input only; the residual path keeps x (residual_block.py:114-116)
         z = self.conv(self._drop(x), add1=aux)
         g = Fn.GateFn.apply(z)
         s = self.conv1x1_skip(g, add1=skips, out_mul=skip_scale)
         x = self.conv1x1_out(g, add1=x, out_mul=math.sqrt(0.5))
-        return x, s
+        return (x, s, c) if chain_aux else (x, s)
 
 
 class HiFiGANResidualBlock(torch.nn.Module):

@@ -205,16 +205,19 @@ def wavenet_gate_backward(desc, z, dx_out, ds_out, packed_bwd):
     return dz, go
 
 
-def wavenet_data_backward(desc, dz, go, packed_bwd, need_dx=True, need_dc=True):
-    """(dx, dc) = data gradients of the dilated convolution (+ go) and of the aux 1x1 convolution."""
-    _require_device(dz, go, packed_bwd)
+def wavenet_data_backward(desc, dz, go, packed_bwd, need_dx=True, need_dc=True, dc_accum=None):
+    """(dx, dc) = data gradients of the dilated convolution (+ go) and of the aux 1x1 convolution (+ ``dc_accum``:
+    what the later layers already accumulated for the shared aux features)."""
+    _require_device(dz, go, packed_bwd, dc_accum)
     b, t = dz.shape[0], dz.shape[2]
     dx = torch.empty((b, desc.residual_channels, t), device=dz.device, dtype=torch.float32) if need_dx else None
     dc = torch.empty((b, desc.aux_channels, t), device=dz.device, dtype=torch.float32) if need_dc else None
     if dx is None and dc is None:
         return None, None
-    _lib.check(_lib.lib().pwg_wavenet_data_backward(ctypes.byref(desc), _ptr(dz), _ptr(go), _ptr(packed_bwd), _ptr(dx),
-                                                    _ptr(dc), _stream()), "wavenet_data_backward")
+    if dc_accum is not None and (tuple(dc_accum.shape) != (b, desc.aux_channels, t) or not dc_accum.is_contiguous()):
+        raise ValueError("wavenet_data_backward: dc_accum must be a contiguous (B, aux, T) tensor")
+    _lib.check(_lib.lib().pwg_wavenet_data_backward(ctypes.byref(desc), _ptr(dz), _ptr(go), _ptr(packed_bwd), _ptr(dc_accum),
+                                                    _ptr(dx), _ptr(dc), _stream()), "wavenet_data_backward")
     return dx, dc
 
 

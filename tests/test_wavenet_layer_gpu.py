@@ -162,3 +162,45 @@ def test_fused_layer_backward_without_residual_output(device):
         assert (a is None) == (b is None) or (a is None and float(b.abs().max()) == 0.0) or (b is None and float(a.abs().max()) == 0.0), k
         if a is not None and b is not None:
             assert _rel(a, b) <= 5e-5, (k, _rel(a, b))
+
+
+@pytest.mark.parametrize("c_requires_grad", [True, False])
+def test_aux_gradient_chained_through_layers(c_requires_grad, device):
+    """Three layers share the aux features: with ``chain_aux`` the gradient w.r.t. c is summed along the chain in the
+    data-gradient epilogues (models/parallel_wavegan.py forward); same values as autograd's own accumulation."""
+    torch.manual_seed(9)
+    blks = [WaveNetResidualBlock(dilation=d).to(device) for d in (1, 4, 16)]
+    for blk in blks:
+        for cv in (blk.conv, blk.conv1x1_aux, blk.conv1x1_skip, blk.conv1x1_out):
+            cv.apply_weight_norm()
+    B, T = 2, 900
+    x0, c0 = torch.randn(B, 64, T, device=device), torch.randn(B, 80, T, device=device)
+    w = torch.randn(B, 64, T, device=device)
+    res = {}
+    for mode in ("chained", "plain", "unfused"):
+        for blk in blks:
+            blk.fuse_layer = mode != "unfused"
+            blk.zero_grad()
+        x = x0.clone().requires_grad_()
+        c = c0.clone().requires_grad_(c_requires_grad)
+        h, skips, cc = x, None, c
+        with poison_lds(), poison_empty():
+            for i, blk in enumerate(blks):
+                scale = 0.5 if i == len(blks) - 1 else 1.0
+                if mode == "chained":
+                    h, skips, cc = blk(h, cc, skips=skips, skip_scale=scale, chain_aux=True)
+                else:
+                    h, skips = blk(h, c, skips=skips, skip_scale=scale)
+            (skips * w).sum().backward()
+        res[mode] = dict(dx=x.grad, dc=c.grad, out=skips.detach(),
+                         **{f"{i}.{n}": p.grad.clone() for i, blk in enumerate(blks) for n, p in blk.named_parameters()
+                            if p.grad is not None})
+    for mode in ("chained", "plain"):
+        assert set(res[mode]) == set(res["unfused"])
+        for k, want in res["unfused"].items():
+            got = res[mode][k]
+            assert (got is None) == (want is None), (mode, k)
+            if want is not None:
+                assert torch.isfinite(got).all(), (mode, k)
+                assert _rel(got, want) <= 5e-5, (mode, k, _rel(got, want))
+    assert (res["chained"]["dc"] is not None) == c_requires_grad
