@@ -337,12 +337,16 @@ int pwg_resunit_supported(const pwg_resunit_desc* d) {
 }
 
 // measured on MI355X (tools/bench_resunit.py, B16 x 800 frames): the one-launch unit wins x1.10-1.41 at C = 32
-// and x1.17 at C = 64, k = 3, ties at C = 64, k = 7 (with 2.5x less HBM traffic) and loses 7 % at C = 64,
+// and x1.17 at C = 64, k = 3, tied at C = 64, k = 7 in round 2 (with 2.5x less HBM traffic) and loses 7 % at C = 64,
 // k = 11, where the recomputed halo (128 h-columns for 116 outputs, in both phases) outweighs the saved passes
 int pwg_resunit_profitable(const pwg_resunit_desc* d) {
   if (!pwg_resunit_supported(d)) return 0;
   if (!d->has_conv2) return 1;
-  return (d->channels == 32 || d->kernel <= 7) ? 1 : 0;
+  // round 3: with three resident workgroups per CU the two general launches are 3 % faster than the fused unit at
+  // C = 64, k = 7 in isolation (5052 vs 5227 us per block, tools/bench_resunit.py) and 0.4 % on the whole forward
+  // (PWG_RU_K64=3, same-box A/B) at 2.5x the HBM traffic of those units: within box-to-box variation, rule unchanged
+  static const int k64 = getenv("PWG_RU_K64") ? atoi(getenv("PWG_RU_K64")) : 7;  // largest fused kernel size at C = 64
+  return (d->channels == 32 || d->kernel <= k64) ? 1 : 0;
 }
 
 size_t pwg_resunit_packed_weight_floats(int32_t channels, int32_t kernel) {
