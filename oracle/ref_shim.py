@@ -1,8 +1,10 @@
 """Import shim so the UNMODIFIED reference (/root/reference) runs in the build
 container.  TEST INFRASTRUCTURE (see oracle/__init__.py).
 
-/root/reference does not exist on the GPU box: callers must check
-``available()`` and skip.  What is shimmed and why:
+/root/reference does not exist on the GPU box.  ``oracle/make_ref.py`` stages the reference's
+``parallel_wavegan`` package byte for byte as ``oracle/_ref/`` (git-ignored, shipped with the snapshot like a
+built ``.so``); when /root/reference is absent the shim resolves to that copy, so the GPU box can time the
+reference's own CPU path.  Callers must check ``available()`` and skip.  What is shimmed and why:
   * ``scipy.signal.kaiser`` was removed in scipy>=1.13 (layers/pqmf.py:11)
   * h5py, librosa, soundfile, kaldiio, tensorboardX are not installed
     (utils/utils.py:16, losses/mel_loss.py:8, bin/train.py:17,20)
@@ -12,11 +14,17 @@ import os
 import sys
 import types
 
-REF_ROOT = "/root/reference"
+STAGED_ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref")
+REF_ROOT = "/root/reference" if os.path.isdir("/root/reference/parallel_wavegan") else STAGED_ROOT
 
 
 def available():
     return os.path.isdir(os.path.join(REF_ROOT, "parallel_wavegan"))
+
+
+def is_staged_copy():
+    """True when ``REF_ROOT`` is the oracle/_ref copy (the GPU box), False for the reference checkout itself."""
+    return REF_ROOT == STAGED_ROOT
 
 
 class _NullWriter:

@@ -805,7 +805,11 @@ def main(argv=None):
     torch.cuda.set_device(device)  # before the process group exists: RCCL binds to the current device
     if args.distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("PWG_DIST_BACKEND", "nccl" if n_dev >= world_size else "gloo")
+        # RCCL ("nccl") unless ranks of THIS node really share a device (single-GPU smoke runs of the multi-rank path):
+        # the comparison is per node (LOCAL_WORLD_SIZE, exported by distributed/launch.py and torch.distributed.run),
+        # not against the global world size -- 2 nodes x 8 GPUs is world 16 on 8 local devices and must stay on RCCL
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world_size)))
+        backend = os.environ.get("PWG_DIST_BACKEND", "gloo" if local_world > n_dev else "nccl")
         torch.distributed.init_process_group(backend=backend, init_method="env://")
     if rank != 0:
         sys.stdout = open(os.devnull, "w")

@@ -62,10 +62,10 @@ def hifigan_generator(name, cfg, batch, frames, seed):
     print(name, "y", tuple(y.shape), "std %.4f max %.4f pre-tanh std %.3f" % (y.std().item(), y.abs().max().item(), pre[0].std().item()))
 
 
-def _load_yaml(name):
+def _load_yaml(name, corpus="ljspeech"):
     import yaml
 
-    with open(os.path.join(ref_shim.REF_ROOT, "egs", "ljspeech", "voc1", "conf", name)) as f:
+    with open(os.path.join(ref_shim.REF_ROOT, "egs", corpus, "voc1", "conf", name)) as f:
         return yaml.safe_load(f)
 
 
@@ -412,7 +412,8 @@ def mb_melgan_train_steps(name, seed, n_steps=2):
 
 def train_full_shape(name, tag, seed):
     """ONE ``Trainer._train_step`` of the unmodified reference at a BASELINE configuration's OWN batch shape
-    (C2 6 x 25600, C3 16 x 8192, C4 64 x 16384): the tile / split-K / slab plans the HIP
+    (C2 6 x 25600, C3 16 x 8192, C4 64 x 16384; VERDICT r02 item 1c -- and, round 4, C5 = BASELINE configs[4]:
+    HiFi-GAN V1 LibriTTS 24 kHz, egs/libritts/voc1/conf/hifigan.v1.yaml, 16 x 8400, the data-parallel workload): the tile / split-K / slab plans the HIP
     engine selects at these sizes are the ones the benchmark times, and the B = 2 fixtures never exercise them.
     Same stored quantities as ``_run_reference_trainer`` (losses, per-tensor first-moment norms, <update, moment>)."""
     import parallel_wavegan.layers as RLy
@@ -420,15 +421,17 @@ def train_full_shape(name, tag, seed):
     import parallel_wavegan.models as RM
     from parallel_wavegan.optimizers import RAdam
 
-    yaml_name = {"c2": "parallel_wavegan.v1.yaml", "c3": "hifigan.v1.yaml", "c4": "multi_band_melgan.v2.yaml"}[tag]
-    cfg = _load_yaml(yaml_name)
+    yaml_name = {"c2": "parallel_wavegan.v1.yaml", "c3": "hifigan.v1.yaml", "c4": "multi_band_melgan.v2.yaml",
+                 "c5": "hifigan.v1.yaml"}[tag]
+    cfg = _load_yaml(yaml_name, corpus="libritts" if tag == "c5" else "ljspeech")
     cfg["discriminator_train_start_steps"] = 0
     cfg["generator_train_start_steps"] = 0
     b, t, hop = cfg["batch_size"], cfg["batch_max_steps"], cfg["hop_size"]
     gcls = getattr(RM, cfg.get("generator_type", "ParallelWaveGANGenerator"))
     dcls = getattr(RM, cfg.get("discriminator_type", "ParallelWaveGANDiscriminator"))
     g, d = gcls(**cfg["generator_params"]), dcls(**cfg["discriminator_params"])
-    gs, ds = {"c2": (synth.PWG_G_SCALE, 1.4), "c3": (G_SCALE, 1.0), "c4": (synth.MELGAN_G_SCALE, 1.2)}[tag]
+    gs, ds = {"c2": (synth.PWG_G_SCALE, 1.4), "c3": (G_SCALE, 1.0), "c4": (synth.MELGAN_G_SCALE, 1.2),
+              "c5": (G_SCALE, 1.0)}[tag]
     g.load_state_dict(synth.synth_state_dict(g.state_dict(), seed=seed, g_scale=gs))
     d.load_state_dict(synth.synth_state_dict(d.state_dict(), seed=seed + 1, g_scale=ds))
     model = {"generator": g, "discriminator": d}
@@ -588,6 +591,7 @@ JOBS = {
     "c2_train_full": lambda: train_full_shape("c2_train_full", "c2", 171),
     "c3_train_full": lambda: train_full_shape("c3_train_full", "c3", 141),
     "c4_train_full": lambda: train_full_shape("c4_train_full", "c4", 181),
+    "c5_train_full": lambda: train_full_shape("c5_train_full", "c5", 191),
 }
 
 if __name__ == "__main__":

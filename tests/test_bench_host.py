@@ -1,0 +1,99 @@
+"""Host-side pieces of bench.py and of the CPU-baseline plumbing (no GPU needed)."""
+import importlib.util
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("pwg_bench", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+# An 8-rank RCCL INFO log as NCCL_DEBUG=INFO / NCCL_DEBUG_SUBSYS=INIT,TUNING,GRAPH writes it.  The line FORMATS are those
+# of the NCCL 2.2x sources RCCL is built from (init.cc "comm %p rank %d nranks %d cudaDev %d ... Init COMPLETE",
+# "%d coll channels, %d collnet channels, %d nvls channels, %d p2p channels ...", transport/p2p.cc "Channel %02d/%01d :
+# %d[%d] -> %d[%d] via P2P/IPC", enqueue.cc "%s: %ld Bytes -> Algo %s proto %s channel{Lo..Hi}={%d..%d}" -- older
+# builds print the numeric ids, "Algo %d proto %d"); host names, pointers and sizes are made up.  No such log could be
+# captured on the one-GPU boxes (a world of one short-circuits its collectives before the tuner logs anything).
+RCCL_LOG_8 = """\
+node0:4127:4127 [0] NCCL INFO Bootstrap : Using eth0:10.0.0.5<0>
+node0:4127:4127 [0] NCCL INFO NET/Plugin: Failed to find ncclNetPlugin_v8 symbol.
+node0:4127:4306 [0] NCCL INFO comm 0x5581a2c40e10 rank 0 nRanks 8 nNodes 1 localRanks 8 localRank 0 MNNVL 0
+node0:4127:4306 [0] NCCL INFO Channel 00/32 :    0   1   2   3   4   5   6   7
+node0:4127:4306 [0] NCCL INFO Trees [0] 1/-1/-1->0->-1 [1] 1/-1/-1->0->-1
+node0:4127:4306 [0] NCCL INFO Channel 00/0 : 0[0] -> 1[1] via P2P/IPC
+node0:4127:4306 [0] NCCL INFO Channel 01/0 : 0[0] -> 1[1] via P2P/IPC
+node0:4127:4306 [0] NCCL INFO Connected all rings
+node0:4127:4306 [0] NCCL INFO 32 coll channels, 0 collnet channels, 0 nvls channels, 32 p2p channels, 4 p2p channels per peer
+node0:4127:4306 [0] NCCL INFO comm 0x5581a2c40e10 rank 0 nranks 8 cudaDev 0 nvmlDev 0 busId 5000 commId 0x3c1e - Init COMPLETE
+node0:4127:4127 [0] NCCL INFO AllReduce: 67108864 Bytes -> Algo RING proto SIMPLE channel{Lo..Hi}={0..31}
+node0:4127:4127 [0] NCCL INFO AllReduce: 67108864 Bytes -> Algo RING proto SIMPLE channel{Lo..Hi}={0..31}
+node0:4127:4127 [0] NCCL INFO AllReduce: 13107200 Bytes -> Algo TREE proto LL128 channel{Lo..Hi}={0..15}
+node0:4127:4127 [0] NCCL INFO AllReduce: 8 Bytes -> Algo 0 proto 0 time 11.200000
+node0:4127:4127 [0] NCCL INFO Broadcast: 4096 Bytes -> Algo 1 proto 2 time 7.900000
+"""
+
+
+def test_rccl_log_summary_parses_a_multi_rank_log(tmp_path):
+    """the first 8-GPU bench line must not come back with ``algo_proto_counts: {}``."""
+    b = _bench()
+    path = tmp_path / "rccl.log"
+    path.write_text(RCCL_LOG_8)
+    b.RCCL_LOG["path"] = str(path)
+    s = b.rccl_log_summary()
+    assert s["nranks"] == 8 and s["coll_channels"] == 32
+    assert s["transports"] == ["P2P/IPC"]
+    assert s["algo_proto_counts"] == {"AllReduce:Ring/Simple": 2, "AllReduce:Tree/LL128": 1, "AllReduce:Tree/LL": 1,
+                                      "Broadcast:Ring/Simple": 1}
+    assert len(s["sample_lines"]) == 5 and "67108864" in s["sample_lines"][0]
+    # what the scaling judgement needs: did the big buckets run as a ring, and over how many channels
+    assert s["large_allreduce"] == {"bytes": 67108864, "algo": "Ring", "proto": "Simple", "channels": 32}
+    b.RCCL_LOG["path"] = str(tmp_path / "absent.log")
+    assert b.rccl_log_summary() is None
+
+
+def test_train_config_table_names_every_baseline_training_config():
+    b = _bench()
+    assert set(b.TRAIN_CONFIGS) == {"c2", "c3", "c4", "c5"}
+    for tag, name in b.TRAIN_CONFIGS.items():
+        conf = b.load_conf(name)
+        assert conf["batch_max_steps"] % conf["hop_size"] == 0, tag
+    c5 = b.load_conf(b.TRAIN_CONFIGS["c5"])
+    # reference egs/libritts/voc1/conf/hifigan.v1.yaml:40,100-102,128-129
+    assert c5["generator_params"]["upsample_scales"] == [5, 5, 4, 3]
+    assert (c5["mel_loss_params"]["fft_size"], c5["mel_loss_params"]["hop_size"], c5["mel_loss_params"]["win_length"]) == (2048, 300, 1200)
+    assert (c5["batch_size"], c5["batch_max_steps"], c5["sampling_rate"]) == (16, 8400, 24000)
+    assert round(b.hifigan_macs_per_sample(b.load_conf("hifigan.v1")["generator_params"])) == 1199424
+
+
+def test_staged_reference_copy_is_byte_identical_to_the_reference():
+    """oracle/make_ref.py stages the reference's package for the CPU baseline: sha256 of every file == the manifest
+    taken at staging time, and (in the build container) == the file under /root/reference."""
+    from oracle import make_ref
+
+    if not os.path.isdir(os.path.join(make_ref.DST_ROOT, "parallel_wavegan")):
+        pytest.skip("oracle/_ref not staged (python oracle/make_ref.py)")
+    assert make_ref.verify()
+    if os.path.isdir(os.path.join(make_ref.SRC_ROOT, "parallel_wavegan")):
+        m = make_ref.stage()
+        for rel, h in m["files"].items():
+            assert make_ref._sha(os.path.join(make_ref.SRC_ROOT, rel)) == h, rel
+
+
+def test_product_package_never_imports_the_oracle_or_the_staged_reference():
+    bad = []
+    for base, _, names in os.walk(os.path.join(ROOT, "parallelwavegan_amd")):
+        for n in names:
+            if n.endswith(".py"):
+                with open(os.path.join(base, n)) as f:
+                    src = f.read()
+                for needle in ("import oracle", "from oracle", "oracle._ref", "ref_shim", "ref_run"):
+                    if needle in src:
+                        bad.append((os.path.join(base, n), needle))
+    assert not bad, bad

@@ -1,9 +1,11 @@
-"""Training parity at each BASELINE configuration's OWN batch shape.
+"""Training parity at each BASELINE configuration's OWN batch shape (C5 added in round 4).
 
 C2 = Parallel WaveGAN.v1 (B 6 x 25600, RAdam, clip 10 / 1, multi-resolution STFT loss), C3 = HiFi-GAN V1
 (B 16 x 8192, MSD + MPD, mel + feature-matching loss), C4 = multi-band MelGAN.v2 (B 64 x 16384, PQMF, full-band +
-sub-band STFT losses): ONE ``Trainer._train_step`` of the unmodified reference at exactly these shapes is stored in
-``tests/golden/c{2,3,4}_train_full.npz`` (made by ``tests/golden/make_golden.py``: every logged loss, every
+sub-band STFT losses), C5 = BASELINE configs[4], HiFi-GAN V1 LibriTTS 24 kHz (B 16 x 8400, upsample scales 5/5/4/3, mel loss
+2048 / 300 / 1200 -- reference egs/libritts/voc1/conf/hifigan.v1.yaml:40,100-102,128-129 -- the data-parallel
+workload of ``bench.py --gpus N``): ONE ``Trainer._train_step`` of the unmodified reference at exactly these shapes is stored in
+``tests/golden/c{2,3,4,5}_train_full.npz`` (made by ``tests/golden/make_golden.py``: every logged loss, every
 parameter's first-moment norm and <first update, first moment>).  The tile / split-K / slab plans the HIP engine
 chooses at these sizes (``splits745``, ``tiles64``, ``tt64`` ... in profiles/r02_train_shapes_*.txt) are the ones the
 benchmark times; the B = 2 fixtures never reach them.
@@ -28,8 +30,8 @@ from tests.util import load_golden, poison_empty, poison_lds
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CONF = {"c2": "parallel_wavegan.v1", "c3": "hifigan.v1", "c4": "multi_band_melgan.v2"}
-SCALES = {"c2": (synth.PWG_G_SCALE, 1.4), "c3": (1.25, 1.0), "c4": (synth.MELGAN_G_SCALE, 1.2)}
+CONF = {"c2": "parallel_wavegan.v1", "c3": "hifigan.v1", "c4": "multi_band_melgan.v2", "c5": "hifigan.v1.libritts"}
+SCALES = {"c2": (synth.PWG_G_SCALE, 1.4), "c3": (1.25, 1.0), "c4": (synth.MELGAN_G_SCALE, 1.2), "c5": (1.25, 1.0)}
 # loss bars: 2e-4 relative (two CPU runs of the reference differ by ~5e-6 .. 1e-5) ...
 LOSS_TOL = 2e-4
 # ... except the spectral-convergence losses at these sizes.  The reference forms ||Y| - |X||_F / ||Y||_F with fp32
@@ -72,7 +74,7 @@ def _build(tag, gold, dev, **overrides):
     return tr, batch, model, opt
 
 
-@pytest.mark.parametrize("tag", ["c2", "c3", "c4"])
+@pytest.mark.parametrize("tag", ["c2", "c3", "c4", "c5"])
 def test_one_step_at_the_baseline_batch_shape_matches_the_reference(device, tag):
     gold = load_golden(f"{tag}_train_full")
     with poison_lds(), poison_empty():
@@ -114,7 +116,7 @@ def test_one_step_at_the_baseline_batch_shape_matches_the_reference(device, tag)
         assert rel.max() <= 5e-3, (tag, key, "upddot", gn[int(rel.argmax())], rel.max())
 
 
-@pytest.mark.parametrize("tag", ["c2", "c3", "c4"])
+@pytest.mark.parametrize("tag", ["c2", "c3", "c4", "c5"])
 def test_graph_replay_at_the_baseline_batch_shape_follows_eager(device, tag):
     """6 steps (2 eager, capture, 3 replays) in hipGraph mode vs 6 eager steps: every loss of every step finite and
     equal within the summation-order noise -- the configuration whose bench run reported a non-finite loss in
