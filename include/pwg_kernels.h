@@ -147,6 +147,28 @@ int pwg_conv1d_forward(const pwg_conv1d_desc* d, const float* x, const float* w_
 size_t pwg_conv1d_packed_weight_bwd_floats(const pwg_conv1d_desc* d);
 int pwg_conv1d_pack_weight_bwd(const pwg_conv1d_desc* d, const float* w, const float* scale,
                                float* w_packed_bwd, void* stream);
+/* ---- weight bank (round 4): the weight preparation of a whole model in two launches ----
+ * Replaces the per-layer sequence pwg_weight_norm_scale + pwg_conv1d_pack_weight + pwg_conv1d_pack_weight_bwd
+ * (i.e. the reference's per-layer weight-norm hook, torch/nn/utils/weight_norm.py `_weight_norm`, evaluated before
+ * every F.conv1d call of the layers/ and models/ modules) by ONE row-scale launch and ONE packing launch over a device table.
+ * pwg_weight_bank_build fills a HOST table (pwg_weight_bank_table_bytes(n) bytes) and `info[8]`; the caller copies
+ * the table to the device once and passes that copy to pwg_weight_bank_prepare, whose launches have constant
+ * arguments (hipGraph-capturable).  Results are bit-identical to the per-layer entry points.
+ * item: w = weight / weight_v (torch layout), g = weight_g or NULL, scale = n0 floats (iff g), fwd / bwd = images of
+ * pwg_conv1d_packed_weight_floats / _bwd_floats floats (NULL: not built), desc = any descriptor of the layer.   */
+typedef struct pwg_bank_item {
+  const float* w;
+  const float* g;
+  float* scale;
+  float* fwd;
+  float* bwd;
+  pwg_conv1d_desc desc;
+} pwg_bank_item;
+size_t pwg_weight_bank_table_bytes(int32_t n_items);
+int pwg_weight_bank_build(const pwg_bank_item* items, int32_t n_items, void* table_host, size_t table_bytes,
+                          int32_t* info);
+int pwg_weight_bank_prepare(const void* table_dev, const int32_t* info, int32_t with_bwd, void* stream);
+
 /* dx = d(pre_act)/dx(x) * conv_data_grad(dy) + accum.  `d` is the FORWARD descriptor
  * (its post_act/out_mul/out_div are NOT differentiated here: the caller passes the gradient
  * w.r.t. the pre-post_act, pre-scale result).  x: forward input (may be NULL when

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libpwgkernels.so")
 
 PWG_ACT_NONE, PWG_ACT_LEAKY_RELU, PWG_ACT_TANH, PWG_ACT_RELU = 0, 1, 2, 3
 PWG_PAD_ZERO, PWG_PAD_REFLECT, PWG_PAD_REPLICATE = 0, 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class ConvDesc(ctypes.Structure):
@@ -38,6 +38,13 @@ class ConvDesc(ctypes.Structure):
         ("out_mul", ctypes.c_float),
         ("out_div", ctypes.c_float),
     ]
+
+
+class BankItem(ctypes.Structure):
+    """Mirror of ``pwg_bank_item`` (include/pwg_kernels.h)."""
+
+    _fields_ = [("w", ctypes.c_void_p), ("g", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("fwd", ctypes.c_void_p),
+                ("bwd", ctypes.c_void_p), ("desc", ConvDesc)]
 
 
 class WaveNetDesc(ctypes.Structure):
@@ -125,6 +132,10 @@ SIGNATURES = {
                                           _vp]),
     "pwg_conv1d_packed_weight_bwd_floats": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
     "pwg_conv1d_pack_weight_bwd": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
+    "pwg_weight_bank_table_bytes": (ctypes.c_size_t, [_i32]),
+    "pwg_weight_bank_build": (ctypes.c_int, [ctypes.POINTER(BankItem), _i32, _vp, ctypes.c_size_t,
+                                             ctypes.POINTER(ctypes.c_int32)]),
+    "pwg_weight_bank_prepare": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), _i32, _vp]),
     "pwg_conv1d_backward_data_workspace_floats": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
     "pwg_conv1d_backward_data": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t,
                                                 _vp]),

@@ -86,6 +86,12 @@ class Trainer(object):
                 # fewer weight-gradient slabs; measured +2.7 % on the HiFi-GAN V1 step).  Applied around every
                 # step (the hint is process-wide), see _train_step
                 self._concurrency_hint = float(os.environ.get("PWG_CONCURRENCY_HINT", config.get("conv_concurrency_hint", 0.5)))
+        # weight preparation of a whole model in two launches per parameter epoch (weight_bank.WeightBank)
+        self._banks = {}
+        if config.get("use_weight_bank", os.environ.get("PWG_WEIGHT_BANK", "1") == "1"):
+            from ..weight_bank import WeightBank
+
+            self._banks = {k: WeightBank(self._module(k)) for k in ("generator", "discriminator")}
         self.reducers = None
         if config.get("distributed", False):
             self.reducers = {}
@@ -408,8 +414,15 @@ class Trainer(object):
         disc_on = self.steps > cfg["discriminator_train_start_steps"]
         p_real = None  # discriminator outputs on the real signal, shared by the two phases
 
+        def prep(key, with_bwd):
+            if key in self._banks and y.is_cuda:
+                self._banks[key].ensure(with_bwd)
+
         # ---------------- generator ----------------
         if self.steps > cfg.get("generator_train_start_steps", 0):
+            prep("generator", True)
+            if disc_on:
+                prep("discriminator", True)
             y_, y_mb_ = self._generator_forward(x)
             gen_loss = 0.0
             if cfg["use_stft_loss"]:
@@ -460,7 +473,9 @@ class Trainer(object):
 
         # ---------------- discriminator ----------------
         if disc_on:
+            prep("discriminator", True)  # (no launch when the generator phase prepared them: D has not changed since)
             if cfg.get("update_prediction_after_generator_update", True):
+                prep("generator", False)  # the generator was just updated; this pass needs forward images only
                 with torch.no_grad():
                     y_, _ = self._generator_forward(x)
             if p_real is not None:

@@ -314,6 +314,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WM * WN >= 8 ? 1 : (WM * W
   const int f0 = (h0 * a.stride - a.pad) * W;
   const int L = ((h1 - h0) * a.stride + (a.k - 1) * a.dil + 1) * W;
   const int tap_step = a.dil * W;
+  // Tap pruning: tap j of output row h reads input row h*stride - pad + j*dil; a tap whose rows lie in the zero padding
+  // for EVERY row of this tile contributes exact zeros and is skipped (weights and MFMAs).  Interior tiles keep all taps;
+  // the k = 41 layers of the scale discriminators at T = 9 / 17 columns per item (pad 20) run 17 / 33 of their 41 taps.
+  int tap_lo = 0, tap_end = a.k;
+  {
+    const int num_lo = a.pad - h1 * a.stride;
+    if (num_lo > 0) tap_lo = (num_lo + a.dil - 1) / a.dil;
+    const int num_hi = a.t_in - 1 + a.pad - h0 * a.stride;
+    const int hi = num_hi < 0 ? -1 : num_hi / a.dil;
+    if (hi + 1 < tap_end) tap_end = hi + 1;
+    if (tap_lo > tap_end) tap_lo = tap_end;
+    if (a.dbg & 32) {  // (PWG_DBG bit 32: no pruning, for the A/B)
+      tap_lo = 0;
+      tap_end = a.k;
+    }
+  }
 
   int coff[WN];
 #pragma unroll
@@ -381,6 +397,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WM * WN >= 8 ? 1 : (WM * W
       const int rr = p * ROWS_PER_PIECE + w_row_in_piece;
       const int tap = rr / CK;
       const int r = rr - tap * CK;
+      const int ptap = (p * ROWS_PER_PIECE) / CK;  // (a piece never straddles taps: CK % ROWS_PER_PIECE == 0)
+      if (ptap < tap_lo || ptap >= tap_end) continue;
       const float* src = wg + ((long)tap * a.cin_pad + ci0 + r) * a.m_pad + w_col;
       __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(ws + p * 256), 16, 0, 0);
     }
@@ -437,15 +455,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WM * WN >= 8 ? 1 : (WM * W
       }
     };
     float a0[KS][WM], b0[KS][WN], a1[KS][WM], b1[KS][WN];
-    load_ops(0, a0, b0);
-    int tap = 0;
-    for (; tap + 2 <= a.k; tap += 2) {
+    if (tap_lo < tap_end) load_ops(tap_lo, a0, b0);
+    int tap = tap_lo;
+    for (; tap + 2 <= tap_end; tap += 2) {
       load_ops(tap + 1, a1, b1);
       mma(a0, b0);
-      if (tap + 2 < a.k) load_ops(tap + 2, a0, b0);
+      if (tap + 2 < tap_end) load_ops(tap + 2, a0, b0);
       mma(a1, b1);
     }
-    if (tap < a.k) mma(a0, b0);
+    if (tap < tap_end) mma(a0, b0);
   }
 
   if (a.dbg & 4) {
@@ -730,6 +748,74 @@ __global__ __launch_bounds__(256) void conv1d_small_cout_kernel(const float* __r
 }
 
 // ---------------------------------------------------------------------------
+// Single-input-channel convolutions at the audio rate: the first layer of every discriminator (HiFi-GAN MSD 1 -> 128,
+// k = 15; MelGAN 1 -> 16, k = 15; PWG 1 -> 64, k = 3 -- reference models/hifigan.py:516-528, models/melgan.py:318-327,
+// models/parallel_wavegan.py:300-316).  On the MFMA tile Cin = 1 fills one of the contraction's channel slots: 3 - 9
+// TFLOP/s for what is a pure streaming write of the output (round 3: 0.65 ms of a C3 step, 0.92 ms of C4).  Here: one
+// workgroup per (item, 1024-sample tile); the input tile goes to LDS once, every thread keeps the k taps of its 4
+// output columns in registers and walks the output channels (weights: LDS broadcast reads), plain fp32 FMAs in tap order.
+// HBM-bound: one read of x, one write of y.
+// ---------------------------------------------------------------------------
+constexpr int SI_TILE = 1024;
+constexpr int SI_MAXK = 16;
+__global__ __launch_bounds__(256) void conv1d_small_cin_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                               const float* __restrict__ bias, float* __restrict__ y,
+                                                               int cin_pad, int m_pad, int cout, int t_in, int t_out,
+                                                               int k, int dil, int pad, int pre_act, float pre_slope,
+                                                               int post_act, float post_slope, float out_mul) {
+  extern __shared__ float sm[];
+  float* ws = sm;              // [cout][k]
+  float* bs = sm + cout * k;   // [cout]
+  float* xs = bs + cout;       // [SI_TILE + halo]
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * SI_TILE;
+  const int L = SI_TILE + (k - 1) * dil;
+  for (int i = threadIdx.x; i < cout * k; i += 256) {  // from the packed image [tap][ci][m], ci = 0
+    const int tap = i % k, c = i / k;
+    ws[i] = wp[(long)tap * cin_pad * m_pad + c];
+  }
+  for (int i = threadIdx.x; i < cout; i += 256) bs[i] = bias ? bias[i] : 0.f;
+  const float* xb = x + (long)b * t_in;
+  for (int i = threadIdx.x; i < L; i += 256) {
+    const int f = t0 - pad + i;
+    float v = (f >= 0 && f < t_in) ? xb[f] : 0.f;
+    if (pre_act == PWG_ACT_LEAKY_RELU)
+      v = v > 0.f ? v : v * pre_slope;
+    else if (pre_act == PWG_ACT_RELU)
+      v = v > 0.f ? v : 0.f;
+    xs[i] = v;
+  }
+  __syncthreads();
+  float xv[4][SI_MAXK];
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int tap = 0; tap < SI_MAXK; ++tap) xv[o][tap] = tap < k ? xs[threadIdx.x + 256 * o + tap * dil] : 0.f;
+  float* yb = y + (long)b * cout * t_out;
+  for (int c = 0; c < cout; ++c) {
+    const float bv = bs[c];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < SI_MAXK; ++tap) {
+      if (tap < k) {
+        const float wv = ws[c * k + tap];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[o] = __builtin_fmaf(wv, xv[o][tap], acc[o]);
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const int t = t0 + threadIdx.x + 256 * o;
+      if (t < t_out) {
+        float v = acc[o] + bv;
+        if (out_mul != 1.0f) v *= out_mul;
+        yb[(long)c * t_out + t] = apply_act(v, post_act, post_slope);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // weight packing:  torch layout -> [group][tap][ci (pad 16)][m (pad 32)]
 // ---------------------------------------------------------------------------
 struct PackArgs {
@@ -798,6 +884,94 @@ __global__ void scale_rows_kernel(const float* v, const float* scale, float* w, 
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
        i += (long)gridDim.x * blockDim.x)
     w[i] = v[i] * scale[i / inner];
+}
+
+// ---------------------------------------------------------------------------
+// Weight bank (round 4): the weight preparation of a WHOLE model -- weight-norm row scales, packed forward images,
+// packed data-gradient images of every convolution -- as two launches over a device table instead of one
+// weight_norm_scale + pack + pack launch sequence per layer (HiFi-GAN V1 training step: 551 of them, 4.8 ms of
+// kernel time, all of it 3-10 us kernels).  Same arithmetic as the per-layer kernels above, element for element.
+// ---------------------------------------------------------------------------
+struct BankRows {   // one per weight-normalised layer
+  const float* v;
+  const float* g;
+  float* scale;
+  int inner, row0;  // floats per dim-0 slice; first global row of this layer
+};
+struct BankImage {  // one per packed image
+  PackArgs a;
+  int block0;       // first workgroup of this image in the pack launch
+  int pad_;
+};
+constexpr int BANK_ELEMS_PER_BLOCK = 2048;
+
+// last table entry whose `first` field (row0 / block0) is <= id  (entries are sorted by it, the first is 0)
+template <typename T, typename F>
+__device__ __forceinline__ int bank_find(const T* tab, int n, int id, F first) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (first(tab[mid]) <= id) lo = mid;
+    else hi = mid - 1;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void bank_scale_kernel(const BankRows* __restrict__ tab, int n) {
+  __shared__ float red[4];
+  const int li = bank_find(tab, n, (int)blockIdx.x, [](const BankRows& r) { return r.row0; });
+  const BankRows r = tab[li];
+  const int row = (int)blockIdx.x - r.row0;
+  const float* p = r.v + (long)row * r.inner;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < r.inner; i += blockDim.x) {
+    const float t = p[i];
+    s += t * t;
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < 4; ++i) t += red[i];
+    r.scale[row] = r.g[row] / sqrtf(t);
+  }
+}
+
+__global__ __launch_bounds__(256) void bank_pack_kernel(const BankImage* __restrict__ tab, int n) {
+  const int ii = bank_find(tab, n, (int)blockIdx.x, [](const BankImage& e) { return e.block0; });
+  const PackArgs a = tab[ii].a;
+  const long total = (long)a.groups * a.k_phase * a.cin_pad * a.m_pad;
+  const long base = (long)((int)blockIdx.x - tab[ii].block0) * BANK_ELEMS_PER_BLOCK;
+#pragma unroll 2
+  for (int j = 0; j < BANK_ELEMS_PER_BLOCK / 256; ++j) {
+    const long i = base + j * 256 + threadIdx.x;
+    if (i >= total) break;
+    const int m = i % a.m_pad;
+    long r = i / a.m_pad;
+    const int ci = r % a.cin_pad;
+    r /= a.cin_pad;
+    const int tap = r % a.k_phase;
+    const int g = r / a.k_phase;
+    float v = 0.f;
+    if (m < a.m_g && ci < a.cin_g) {
+      if (!a.transposed) {
+        const int co = g * a.cout_g + m;
+        v = a.w[((long)co * a.cin_g + ci) * a.kernel + tap];
+        if (a.scale) v *= a.scale[co];
+      } else {
+        const int phase = m / a.cout_g;
+        const int co = m - phase * a.cout_g;
+        const int kk = phase + (a.k_phase - 1 - tap) * a.stride;
+        if (kk < a.kernel) {
+          const int cig = g * a.cin_g + ci;
+          v = a.w[((long)cig * a.cout_g + co) * a.kernel + kk];
+          if (a.scale) v *= a.scale[cig];
+        }
+      }
+    }
+    a.wp[i] = v;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1105,17 +1279,29 @@ static int choose_cfg(const Geometry& g, int W, int batch, int groups, bool dma,
                                   {11, 1.06f}};
   // 17 = 64x64x4: the only 64-row tile whose double-buffered weight chunk fits the LDS at k = 41 (grouped
   // scale-discriminator layers, 64 channels per group, T = 9..128 columns per item)
-  static const Cand mid_few[] = {{10, 1.0f}, {11, 0.8f}, {13, 0.8f}, {17, 0.7f}};
+  // (16 / 6 = 32x128x16 / 32x256x16: eligible only for k <= 3, see the CK = 16 rule below; 64 -> 64 k = 3 at
+  // T = 25600: 61.7 us against 67.4 us, 48 -> 48 k = 1 at T = 4096: 59.4 against 64.4, profiles/r04_k1_sweep.txt)
+  static const Cand mid_few[] = {{10, 1.0f}, {11, 0.8f}, {13, 0.8f}, {17, 0.7f}, {16, 1.08f}, {6, 1.05f}};
   static const Cand mid_many[] = {{11, 1.0f}, {10, 0.9f}, {13, 0.8f}, {17, 0.85f}};
   static const Cand small_any[] = {{10, 1.0f}};
+  // Round 4: 96 rows (multi-band MelGAN's middle stage and its residual stacks, models/melgan.py:130-178) are three
+  // 32-row blocks: every 64 / 128-row tile computes a quarter of its rows for nothing AND the planner had no 32-row
+  // tile with a long chunk on its list.  Forced sweep at B64 x T2048 (tools/bench_dsplit.py k1,
+  // profiles/r04_k1_sweep.txt): k = 1: 32x256x16 53.7 us against 101.2 us for the 64x256x4 the old list chose;
+  // k = 3 (dilation 3): 32x128x16 103 us against 166 us.  (PWG_ROWS32=0 restores the round-3 lists.)
+  static const Cand rows32[] = {{6, 1.0f}, {16, 0.98f}, {5, 0.94f}, {10, 0.86f}, {12, 0.66f}, {9, 0.66f}, {11, 0.6f}};
+  static const bool rows32_on = !(getenv("PWG_ROWS32") && atoi(getenv("PWG_ROWS32")) == 0);
   const Cand* cand;
   int ncand;
-  if (m > 64) {
+  if (rows32_on && m > 64 && m <= 128 && m % 64 != 0 && m % 32 == 0 && k <= 4) {
+    cand = rows32;
+    ncand = 7;
+  } else if (m > 64) {
     cand = k <= 4 ? big_few : big_many;
     ncand = (k <= 4 ? 9 : 8) - ((m > 128 && k <= 4) ? 1 : 0);  // (few taps: 64x256x4 only for m <= 128)
   } else if (m > 32) {
     cand = k <= 4 ? mid_few : mid_many;  // (k = 7 at C = 64: 64x256x4 103 vs 32x128x8 95 TFLOP/s, profiles/r02_conv_sweep.txt)
-    ncand = 4;
+    ncand = (k <= 4 && rows32_on) ? 6 : 4;
   } else {
     cand = small_any;
     ncand = 1;
@@ -1133,6 +1319,18 @@ static int choose_cfg(const Geometry& g, int W, int batch, int groups, bool dma,
     // C=64 k=3 T=4096 at 1024 workgroups 58 -> 36)
     while (split < 8 && nchunks >= 8 * split && blocks * split < 512 && mfma_chunk * per_cu * (2 * split) <= 6200.0)
       split *= 2;
+    // Round 4: LONG reductions over few columns -- the period discriminators' 512 / 1024-channel layers, 9..110
+    // columns per item, K = Cin * k = 2560..5120 -- leave the big tiles (the only ones whose chunk hides its own DMA
+    // round trip) with 128 workgroups on 256 CUs.  Slicing the reduction there is not about latency but about filling
+    // the chip with efficient tiles: forced sweep (tools/bench_dsplit.py, profiles/r04_dsplit_sweep.txt) 128x128x4 split
+    // 4 = 226 us against 274 us for the 32x128x16 tile the fill score used to pick (1024 -> 1024, k = 5), 133 against
+    // 165 us for 512 -> 1024 stride 3.  Each slice keeps >= 32 chunks, so the slab traffic (one y-sized write + read
+    // per slice) stays below 2 % of the launch's operand traffic.  (PWG_SPLIT_FILL=0 restores the round-3 rule.)
+    static const bool split_fill = !(getenv("PWG_SPLIT_FILL") && atoi(getenv("PWG_SPLIT_FILL")) == 0);
+    if (split_fill && c.wm * c.wn >= 2) {
+      const long full = (long)(512.f * concurrency_hint());
+      while (split < 4 && nchunks >= 32 * (2 * split) && blocks * split < full) split *= 2;
+    }
     return split;
   };
   int best = -1, best_split = 1;
@@ -1144,7 +1342,9 @@ static int choose_cfg(const Geometry& g, int W, int batch, int groups, bool dma,
       const size_t cap = (pass == 0 && c.waves < 8) ? 80 * 1024 : 160 * 1024;
       if (cfg_lds(cand[i].id, g, W, dma) > cap) continue;
       if (c.waves == 8 && (!dma || g.stride != 1 || W != 1 || (k - 1) * g.dil > 64)) continue;  // FAST geometry only
-      if (c.ck == 16 && (!dma || g.cin_g < 256)) continue;  // 16-channel chunks: long reductions only
+      // 16-channel chunks: long reductions -- or few taps (k <= 3: a 4 / 8-channel chunk carries 2 - 12 MFMAs per
+      // wave against a 2.7 us DMA round trip; measured at 96 channels, see rows32 above)
+      if (c.ck == 16 && (!dma || (g.cin_g < 256 && !(rows32_on && k <= 3 && g.cin_g >= 32)))) continue;
       const long ntiles = ceil_div(g.n_cols, c.bn);
       const long blocks = ntiles * ceil_div(m, c.bm) * groups * batch;
       const int split = max_split(c, blocks);
@@ -1270,6 +1470,15 @@ static ConvPlan plan_conv(const pwg_conv1d_desc* d, const Geometry& g) {
   p.dma = d->pad_mode == PWG_PAD_ZERO;  // reflect/replicate need index remapping: register path
   p.ksplit = 1;
   p.id = choose_cfg(g, d->width, d->batch, d->groups, p.dma, &p.ksplit);
+  // tuning override (tools/bench_dshapes.py): PWG_FORCE_CFG=<id>[,<ksplit>], read per call
+  if (const char* f = getenv("PWG_FORCE_CFG")) {
+    int id = -1, ks = 1;
+    if (sscanf(f, "%d,%d", &id, &ks) >= 1 && id >= 0 && id < kNumCfgs && p.dma && cfg_lds(id, g, d->width, true) <= 160 * 1024) {
+      p.id = id;
+      p.ksplit = ks < 1 ? 1 : (ks > 16 ? 16 : ks);
+      if (ceil_div(g.cin_g, cfg_info(id).ck) < p.ksplit) p.ksplit = 1;
+    }
+  }
   if (p.dma && cfg_lds(p.id, g, d->width, true) > 160 * 1024) {  // very long filters (PQMF k=63): single buffer
     p.dma = false;
     p.ksplit = 1;
@@ -1318,6 +1527,25 @@ extern "C" int pwg_conv1d_forward(const pwg_conv1d_desc* d_in, const float* x, c
   int rc = make_geometry(d, &g);
   if (rc != PWG_OK) return rc;
   if (gconv_forward_applicable(d, add1, add2)) return gconv_forward(d, x, w_packed, bias, y, (hipStream_t)stream);
+  static const bool small_cin_on = !(getenv("PWG_SMALL_CIN") && atoi(getenv("PWG_SMALL_CIN")) == 0);
+  if (small_cin_on && !d->transposed && d->groups == 1 && d->c_in == 1 && d->width == 1 && d->stride == 1 &&
+      d->pad_mode == PWG_PAD_ZERO && d->kernel <= SI_MAXK && d->c_out >= 8 && d->c_out <= 256 && !add1 && !add2 &&
+      d->out_div == 1.0f && d->t_out >= 2048 &&
+      (d->pre_act == PWG_ACT_NONE || d->pre_act == PWG_ACT_LEAKY_RELU || d->pre_act == PWG_ACT_RELU)) {
+    ConvArgs chk;
+    rc = fill_args(d, g, x, w_packed, bias, add1, add2, y, &chk);
+    if (rc != PWG_OK) return rc;
+    const size_t lds = ((size_t)d->c_out * (d->kernel + 1) + SI_TILE + (d->kernel - 1) * d->dilation) * sizeof(float);
+    PWG_REQUIRE(lds <= 64 * 1024, PWG_ERR_UNSUPPORTED, "conv1d (single input channel): %zu B of LDS", lds);
+    const double out_elems = (double)d->batch * d->c_out * d->t_out;
+    ProfScope prof((hipStream_t)stream, "conv1d_small_cin_kernel", 2.0 * out_elems * d->kernel,
+                   4.0 * ((double)d->batch * d->t_in + out_elems));
+    hipLaunchKernelGGL(conv1d_small_cin_kernel, dim3(ceil_div(d->t_out, SI_TILE), d->batch), dim3(256), lds,
+                       (hipStream_t)stream, x, w_packed, bias, y, g.cin_pad, g.m_pad, d->c_out, d->t_in, d->t_out, d->kernel,
+                       d->dilation, d->pad_left, d->pre_act, d->pre_slope, d->post_act, d->post_slope, d->out_mul);
+    PWG_CHECK_LAUNCH("conv1d_small_cin");
+    return PWG_OK;
+  }
   if (!d->transposed && d->groups == 1 && d->width == 1 && d->stride == 1 && d->pad_mode == PWG_PAD_ZERO &&
       d->c_out <= 4 && d->c_out * d->c_in * d->kernel <= SC_MAXW && !add1 && !add2 && d->out_div == 1.0f &&
       d->t_out >= 4096 && (d->kernel - 1) * d->dilation <= 1024 &&
@@ -1452,5 +1680,112 @@ extern "C" int pwg_scale_rows(const float* v, const float* scale, float* w, int3
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(scale_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, v, scale, w, total, inner);
   PWG_CHECK_LAUNCH("scale_rows");
+  return PWG_OK;
+}
+
+
+// ---------------------------------------------------------------------------
+// Weight bank: host side.  The table is built ONCE per set of parameter / image addresses (host memory, uploaded by
+// the caller outside any stream capture) and then only referenced: a prepare call is two launches whose arguments
+// never change, so it can be captured into a hipGraph and replayed.
+// Table layout (bytes): [BankRows x n_rows_tab][BankImage x n_images], images ordered forward images first.
+// info[0] = n_rows_tab, info[1] = total scale rows, info[2] = n forward images, info[3] = pack workgroups of the
+// forward images, info[4] = n images, info[5] = pack workgroups of all images, info[6] = byte offset of the images.
+// ---------------------------------------------------------------------------
+static void fill_pack_args(const pwg_conv1d_desc* d, const Geometry& g, const float* w, const float* scale, float* wp,
+                           PackArgs* a) {
+  a->w = w;
+  a->scale = scale;
+  a->wp = wp;
+  a->groups = d->groups;
+  a->k_phase = g.k_phase;
+  a->cin_g = g.cin_g;
+  a->cin_pad = g.cin_pad;
+  a->cout_g = g.cout_g;
+  a->m_g = g.m_g;
+  a->m_pad = g.m_pad;
+  a->kernel = d->kernel;
+  a->stride = d->stride;
+  a->transposed = d->transposed;
+}
+
+extern "C" size_t pwg_weight_bank_table_bytes(int32_t n_items) {
+  if (n_items <= 0) return 0;
+  return (size_t)n_items * (sizeof(BankRows) + 2 * sizeof(BankImage));
+}
+
+extern "C" int pwg_weight_bank_build(const pwg_bank_item* items, int32_t n_items, void* table_host, size_t table_bytes,
+                                     int32_t* info) {
+  PWG_REQUIRE(items && table_host && info && n_items > 0, PWG_ERR_NULL, "weight_bank_build: NULL pointer / no items");
+  PWG_REQUIRE(table_bytes >= pwg_weight_bank_table_bytes(n_items), PWG_ERR_WORKSPACE, "weight_bank_build: table too small");
+  BankRows* rows = reinterpret_cast<BankRows*>(table_host);
+  int n_rows_tab = 0, row0 = 0;
+  for (int i = 0; i < n_items; ++i) {
+    const pwg_bank_item& it = items[i];
+    PWG_REQUIRE(it.w != nullptr, PWG_ERR_NULL, "weight_bank_build: item %d has no weight", i);
+    if (it.g == nullptr) continue;
+    PWG_REQUIRE(it.scale != nullptr, PWG_ERR_NULL, "weight_bank_build: item %d: weight-norm layer without a scale buffer", i);
+    const pwg_conv1d_desc& d = it.desc;
+    PWG_REQUIRE(d.groups > 0 && d.c_in % d.groups == 0 && d.c_out % d.groups == 0 && d.kernel > 0, PWG_ERR_BAD_SHAPE,
+                "weight_bank_build: item %d: bad descriptor", i);
+    // torch layouts: Conv (c_out, c_in/g, k): dim 0 = c_out; ConvTranspose (c_in, c_out/g, k): dim 0 = c_in
+    const int n0 = d.transposed ? d.c_in : d.c_out;
+    const int inner = (d.transposed ? d.c_out / d.groups : d.c_in / d.groups) * d.kernel;
+    rows[n_rows_tab] = BankRows{it.w, it.g, it.scale, inner, row0};
+    row0 += n0;
+    ++n_rows_tab;
+  }
+  BankImage* imgs = reinterpret_cast<BankImage*>(rows + n_rows_tab);
+  int n_img = 0, block0 = 0, n_fwd = 0, blocks_fwd = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int i = 0; i < n_items; ++i) {
+      const pwg_bank_item& it = items[i];
+      float* out = pass == 0 ? it.fwd : it.bwd;
+      if (!out) continue;
+      pwg_conv1d_desc d = it.desc;
+      if (pass == 1) dual_desc(&it.desc, &d);
+      Geometry g;
+      const int rc = make_geometry(&d, &g);
+      if (rc != PWG_OK) return rc;
+      BankImage& e = imgs[n_img];
+      fill_pack_args(&d, g, it.w, it.g ? it.scale : nullptr, out, &e.a);
+      e.block0 = block0;
+      e.pad_ = 0;
+      const long total = (long)e.a.groups * e.a.k_phase * e.a.cin_pad * e.a.m_pad;
+      block0 += (int)((total + BANK_ELEMS_PER_BLOCK - 1) / BANK_ELEMS_PER_BLOCK);
+      ++n_img;
+    }
+    if (pass == 0) {
+      n_fwd = n_img;
+      blocks_fwd = block0;
+    }
+  }
+  info[0] = n_rows_tab;
+  info[1] = row0;
+  info[2] = n_fwd;
+  info[3] = blocks_fwd;
+  info[4] = n_img;
+  info[5] = block0;
+  info[6] = (int32_t)((const char*)imgs - (const char*)table_host);
+  return PWG_OK;
+}
+
+extern "C" int pwg_weight_bank_prepare(const void* table_dev, const int32_t* info, int32_t with_bwd, void* stream_) {
+  PWG_REQUIRE(table_dev && info, PWG_ERR_NULL, "weight_bank_prepare: NULL pointer");
+  hipStream_t stream = (hipStream_t)stream_;
+  const BankRows* rows = reinterpret_cast<const BankRows*>(table_dev);
+  const BankImage* imgs = reinterpret_cast<const BankImage*>((const char*)table_dev + info[6]);
+  if (info[0] > 0 && info[1] > 0) {
+    ProfScope prof(stream, "bank_scale_kernel", 0, 0);
+    hipLaunchKernelGGL(bank_scale_kernel, dim3(info[1]), dim3(256), 0, stream, rows, info[0]);
+    PWG_CHECK_LAUNCH("bank_scale");
+  }
+  const int n_img = with_bwd ? info[4] : info[2];
+  const int blocks = with_bwd ? info[5] : info[3];
+  if (n_img > 0 && blocks > 0) {
+    ProfScope prof(stream, "bank_pack_kernel", 0, 8.0 * (double)blocks * BANK_ELEMS_PER_BLOCK);
+    hipLaunchKernelGGL(bank_pack_kernel, dim3(blocks), dim3(256), 0, stream, imgs, n_img);
+    PWG_CHECK_LAUNCH("bank_pack");
+  }
   return PWG_OK;
 }

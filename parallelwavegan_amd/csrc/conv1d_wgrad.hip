@@ -517,6 +517,60 @@ __global__ __launch_bounds__(256) void reduce_slabs_wn_kernel(const float* __res
   for (int i = threadIdx.x; i < inner; i += 256) dv[base + i] = c1 * (row[i] - v[base + i] * c2);
 }
 
+// ---------------------------------------------------------------------------
+// Weight gradient of single-input-channel convolutions (the discriminators' first layers, see conv1d_small_cin_kernel
+// in conv1d.hip): dW[co][0][j] = sum_{b,t} dy[b][co][t] * act(x[b][t + j*d - pad]), db[co] = sum dy.  On the MFMA tile one
+// of 32 operand columns carries data (round 3: 1.5 - 3 TFLOP/s, 1.15 ms of a C4 step, 0.65 ms of C3).  Here: one
+// workgroup per (item, 1024-column chunk); the x window goes to LDS, each wave walks a quarter of the output channels,
+// its lanes stride over the chunk's columns with k + 1 running sums in registers (dy read once, coalesced; x taps are
+// shifted LDS reads), a wave reduction finishes each channel.  Every (item, chunk) writes a private tap-major slab
+// [tap][co] + bias row -- the layout the slab finishers above expect -- summed afterwards in a fixed order.
+// ---------------------------------------------------------------------------
+constexpr int SIW_TILE = 1024;
+constexpr int SIW_MAXK = 16;
+__global__ __launch_bounds__(256) void conv1d_small_cin_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                     float* __restrict__ slabs, long slab_stride, int cout,
+                                                                     int t_in, int t_out, int k, int dil, int pad,
+                                                                     int chunks_per_item, float slope_x, int write_bias) {
+  extern __shared__ float xs[];  // [SIW_TILE + halo]
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int t0 = chunk * SIW_TILE;
+  const int L = SIW_TILE + (k - 1) * dil;
+  const float* xb = x + (long)b * t_in;
+  for (int i = threadIdx.x; i < L; i += 256) {
+    const int f = t0 - pad + i;
+    float v = (f >= 0 && f < t_in) ? xb[f] : 0.f;
+    xs[i] = __builtin_fmaxf(v, v * slope_x);  // LeakyReLU for 0 <= slope <= 1 (1 = none, 0 = ReLU), as the MFMA kernel
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = min(SIW_TILE, t_out - t0);
+  float* slab = slabs + ((long)b * chunks_per_item + chunk) * slab_stride;
+  for (int co = wave; co < cout; co += 4) {
+    const float* g = dy + ((long)b * cout + co) * t_out + t0;
+    float acc[SIW_MAXK], accb = 0.f;
+#pragma unroll
+    for (int j = 0; j < SIW_MAXK; ++j) acc[j] = 0.f;
+    for (int t = lane; t < n; t += 64) {
+      const float v = g[t];
+      accb += v;
+#pragma unroll
+      for (int j = 0; j < SIW_MAXK; ++j)
+        if (j < k) acc[j] = __builtin_fmaf(v, xs[t + j * dil], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < SIW_MAXK; ++j)
+      for (int o = 32; o > 0; o >>= 1) acc[j] += __shfl_down(acc[j], o, 64);
+    for (int o = 32; o > 0; o >>= 1) accb += __shfl_down(accb, o, 64);
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < SIW_MAXK; ++j)
+        if (j < k) slab[(long)j * cout + co] = acc[j];
+      if (write_bias) slab[(long)k * cout + co] = accb;
+    }
+  }
+}
+
 struct WgPlan {
   bool small;      // 32x32 tile, waves split the taps
   bool win;        // per-tap windows
@@ -631,6 +685,58 @@ static WgPlan wgrad_plan(int co_g, int ci_g, int groups, int k, int stride, int 
   return p;
 }
 
+// Sum `splits` tap-major slabs (+ fused bias row) of a layer with `n0` rows, `ci_g` input channels per group and `k`
+// taps into the torch-layout gradients; with `wn`, through the weight-norm backward.  (Shared by the MFMA kernel's
+// launcher and the single-input-channel path.)
+static int finish_wgrad_slabs(float* workspace, int splits, long slab_elems, long slab_stride, int n0, int ci_g, int k,
+                              float* dw_out, float* db_out, const WnFinish* wn, hipStream_t stream) {
+  // fused finisher: one workgroup per weight row, so it needs many rows or few slabs to fill the chip; layers
+  // with few rows cut into many slabs (C <= 128 generator stages) keep the wide slab reduction (one workgroup
+  // per 32 elements) followed by the row-wise weight-norm backward, into a spare slab of the workspace
+  const long plane = (long)n0 * ci_g;  // elements per tap of a tap-major slab
+  const int inner = ci_g * k;
+  const bool wn_fused = wn != nullptr && (splits < 16 || n0 >= 512);
+  if (wn != nullptr && !wn_fused) {
+    float* dw_tmp = workspace + (size_t)splits * slab_stride;
+    {
+      ProfScope prof(stream, "reduce_slabs_kernel", 0, 4.0 * slab_stride * (splits + 1));
+      hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)((slab_stride + 31) / 32)), dim3(256), 0, stream,
+                         workspace, dw_tmp, db_out, slab_elems, slab_stride, splits, plane, k);
+      PWG_CHECK_LAUNCH("reduce_slabs");
+    }
+    return pwg_weight_norm_backward(dw_tmp, wn->v, wn->g, wn->dv, wn->dg, n0, inner, stream);
+  }
+  if (wn != nullptr) {
+    const int nbias = db_out ? n0 : 0;
+    ProfScope prof(stream, "reduce_slabs_wn_kernel", 0, 4.0 * (slab_stride * (double)splits + 3.0 * slab_elems));
+    const bool wide = splits >= 16 && (size_t)9 * inner * sizeof(float) <= 64 * 1024;  // (>= 512 rows of <= 1820 floats)
+    if (wide)
+      hipLaunchKernelGGL(reduce_slabs_wn_kernel<true>, dim3(n0 + ceil_div(nbias, 256)), dim3(256),
+                         (size_t)9 * inner * sizeof(float), stream, (const float*)workspace, slab_stride, splits,
+                         slab_elems, wn->v, wn->g, wn->dv, wn->dg, db_out, n0, inner, nbias, ci_g, k);
+    else
+      hipLaunchKernelGGL(reduce_slabs_wn_kernel<false>, dim3(n0 + ceil_div(nbias, 256)), dim3(256),
+                         (size_t)inner * sizeof(float), stream, (const float*)workspace, slab_stride, splits,
+                         slab_elems, wn->v, wn->g, wn->dv, wn->dg, db_out, n0, inner, nbias, ci_g, k);
+    PWG_CHECK_LAUNCH("reduce_slabs_wn");
+    return PWG_OK;
+  }
+  if (splits > 1) {
+    ProfScope prof(stream, "reduce_slabs_kernel", 0, 4.0 * slab_stride * (splits + 1));
+    if (splits >= 16) {
+      hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)((slab_stride + 31) / 32)), dim3(256), 0, stream,
+                         workspace, dw_out, db_out, slab_elems, slab_stride, splits, plane, k);
+    } else {
+      long blocks = (slab_stride + 255) / 256;
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(reduce_slabs_kernel, dim3((int)blocks), dim3(256), 0, stream, workspace, dw_out, db_out,
+                         slab_elems, slab_stride, splits, plane, k);
+    }
+    PWG_CHECK_LAUNCH("reduce_slabs");
+  }
+  return PWG_OK;
+}
+
 template <int TG, bool SMALL, int TT, bool WIN, int MODE>
 static int launch_wgrad_mode(WgArgs a, const WgPlan& p, float* dw_out, float* workspace, size_t ws_floats,
                         hipStream_t stream, double flops, double bytes, const WnFinish* wn) {
@@ -672,51 +778,8 @@ static int launch_wgrad_mode(WgArgs a, const WgPlan& p, float* dw_out, float* wo
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
   }
   PWG_CHECK_LAUNCH("conv1d_backward_weight");
-  // fused finisher: one workgroup per weight row, so it needs many rows or few slabs to fill the chip; layers
-  // with few rows cut into many slabs (C <= 128 generator stages) keep the wide slab reduction (one workgroup
-  // per 32 elements) followed by the row-wise weight-norm backward, into a spare slab of the workspace
-  const long plane = (long)a.co_g * a.groups * a.ci_g;  // elements per tap of a tap-major slab
-  const bool wn_fused = wn != nullptr && (p.splits < 16 || a.co_g * a.groups >= 512);
-  if (wn != nullptr && !wn_fused) {
-    float* dw_tmp = workspace + (size_t)p.splits * a.slab_stride;
-    {
-      ProfScope prof(stream, "reduce_slabs_kernel", 0, 4.0 * a.slab_stride * (p.splits + 1));
-      hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)((a.slab_stride + 31) / 32)), dim3(256), 0, stream,
-                         workspace, dw_tmp, db_out, a.slab_elems, a.slab_stride, p.splits, plane, a.k);
-      PWG_CHECK_LAUNCH("reduce_slabs");
-    }
-    return pwg_weight_norm_backward(dw_tmp, wn->v, wn->g, wn->dv, wn->dg, a.co_g * a.groups, a.ci_g * a.k, stream);
-  }
-  if (wn != nullptr) {
-    const int n0 = a.co_g * a.groups, inner = a.ci_g * a.k;
-    const int nbias = db_out ? n0 : 0;
-    ProfScope prof(stream, "reduce_slabs_wn_kernel", 0, 4.0 * (a.slab_stride * (double)p.splits + 3.0 * a.slab_elems));
-    const bool wide = p.splits >= 16 && (size_t)9 * inner * sizeof(float) <= 64 * 1024;  // (>= 512 rows of <= 1820 floats)
-    if (wide)
-      hipLaunchKernelGGL(reduce_slabs_wn_kernel<true>, dim3(n0 + ceil_div(nbias, 256)), dim3(256),
-                         (size_t)9 * inner * sizeof(float), stream, (const float*)workspace, a.slab_stride, p.splits,
-                         a.slab_elems, wn->v, wn->g, wn->dv, wn->dg, db_out, n0, inner, nbias, a.ci_g, a.k);
-    else
-      hipLaunchKernelGGL(reduce_slabs_wn_kernel<false>, dim3(n0 + ceil_div(nbias, 256)), dim3(256),
-                         (size_t)inner * sizeof(float), stream, (const float*)workspace, a.slab_stride, p.splits,
-                         a.slab_elems, wn->v, wn->g, wn->dv, wn->dg, db_out, n0, inner, nbias, a.ci_g, a.k);
-    PWG_CHECK_LAUNCH("reduce_slabs_wn");
-    return PWG_OK;
-  }
-  if (p.splits > 1) {
-    ProfScope prof(stream, "reduce_slabs_kernel", 0, 4.0 * a.slab_stride * (p.splits + 1));
-    if (p.splits >= 16) {
-      hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)((a.slab_stride + 31) / 32)), dim3(256), 0, stream,
-                         workspace, dw_out, db_out, a.slab_elems, a.slab_stride, p.splits, plane, a.k);
-    } else {
-      long blocks = (a.slab_stride + 255) / 256;
-      if (blocks > 2048) blocks = 2048;
-      hipLaunchKernelGGL(reduce_slabs_kernel, dim3((int)blocks), dim3(256), 0, stream, workspace, dw_out, db_out,
-                         a.slab_elems, a.slab_stride, p.splits, plane, a.k);
-    }
-    PWG_CHECK_LAUNCH("reduce_slabs");
-  }
-  return PWG_OK;
+  return finish_wgrad_slabs(workspace, p.splits, a.slab_elems, a.slab_stride, a.co_g * a.groups, a.ci_g, a.k, dw_out,
+                            db_out, wn, stream);
 }
 
 template <int TG, bool SMALL, int TT>
@@ -740,6 +803,15 @@ static int launch_wgrad(WgArgs a, const WgPlan& p, float* dw_out, float* workspa
 
 using namespace pwg;
 
+// single-input-channel path (conv1d_small_cin_wgrad_kernel): `d` flattened; PWG_SMALL_CIN=0 disables it
+static bool small_cin_wgrad_applicable(const pwg_conv1d_desc* d) {
+  static const bool on = !(getenv("PWG_SMALL_CIN") && atoi(getenv("PWG_SMALL_CIN")) == 0);
+  return on && !d->transposed && d->groups == 1 && d->c_in == 1 && d->width == 1 && d->stride == 1 &&
+         d->pad_mode == PWG_PAD_ZERO && d->kernel <= SIW_MAXK && d->c_out >= 8 && d->c_out <= 1024 && d->t_out >= 2048 &&
+         (size_t)(SIW_TILE + (d->kernel - 1) * d->dilation) * sizeof(float) <= 64 * 1024;
+}
+static long small_cin_wgrad_slabs(const pwg_conv1d_desc* d) { return (long)d->batch * ceil_div(d->t_out, SIW_TILE); }
+
 static void wgrad_roles(const pwg_conv1d_desc* d, int* co_g, int* ci_g, int* n_cols) {
   if (!d->transposed) {
     *co_g = d->c_out / d->groups;
@@ -760,6 +832,7 @@ extern "C" size_t pwg_conv1d_backward_weight_workspace_floats(const pwg_conv1d_d
   wgrad_roles(d, &co_g, &ci_g, &n_cols);
   const WgPlan p = wgrad_plan(co_g, ci_g, d->groups, d->kernel, d->stride, d->dilation, d->width, n_cols, d->batch);
   if (gconv_wgrad_applicable(d)) return gconv_wgrad_workspace_floats(d);
+  if (small_cin_wgrad_applicable(d)) return (size_t)small_cin_wgrad_slabs(d) * ((size_t)d->c_out * (d->kernel + 1));
   // one slab per reduction slice: dW plus the fused bias row
   return p.splits > 1 ? (size_t)p.splits * ((size_t)co_g * d->groups * ci_g * d->kernel + (size_t)co_g * d->groups) : 0;
 }
@@ -810,6 +883,23 @@ static int backward_weight_impl(const pwg_conv1d_desc* d_in, const float* x, con
   PWG_REQUIRE(slope >= 0.f && slope <= 1.f, PWG_ERR_UNSUPPORTED,
               "conv1d_backward_weight: LeakyReLU slope %g outside [0, 1] (the operand activation is max(v, slope*v))",
               (double)slope);
+  if (small_cin_wgrad_applicable(d)) {
+    const long nslabs = small_cin_wgrad_slabs(d);
+    const long slab_elems = (long)d->c_out * d->kernel, slab_stride = slab_elems + (db ? d->c_out : 0);
+    const size_t need = (size_t)(nslabs + (wn ? 1 : 0)) * slab_stride;
+    PWG_REQUIRE(workspace && workspace_floats >= need, PWG_ERR_WORKSPACE,
+                "conv1d_backward_weight: workspace of %zu floats needed, %zu given", need, workspace_floats);
+    PWG_REQUIRE(nslabs < (1L << 30), PWG_ERR_UNSUPPORTED, "conv1d_backward_weight: too many slabs");
+    {
+      ProfScope prof(stream, "conv1d_small_cin_wgrad_kernel", 2.0 * y_elems * d->kernel, 4.0 * ((double)x_elems + (double)y_elems));
+      hipLaunchKernelGGL(conv1d_small_cin_wgrad_kernel, dim3(ceil_div(d->t_out, SIW_TILE), d->batch), dim3(256),
+                         (size_t)(SIW_TILE + (d->kernel - 1) * d->dilation) * sizeof(float), stream, x, dy, workspace,
+                         slab_stride, d->c_out, d->t_in, d->t_out, d->kernel, d->dilation, d->pad_left,
+                         ceil_div(d->t_out, SIW_TILE), slope, db ? 1 : 0);
+      PWG_CHECK_LAUNCH("conv1d_small_cin_wgrad");
+    }
+    return finish_wgrad_slabs(workspace, (int)nslabs, slab_elems, slab_stride, d->c_out, 1, d->kernel, dw, db, wn, stream);
+  }
   if (!d->transposed) {
     a.g = dy;
     a.x = x;
@@ -894,6 +984,7 @@ extern "C" size_t pwg_conv1d_backward_weight_wn_workspace_floats(const pwg_conv1
   wgrad_roles(d, &co_g, &ci_g, &n_cols);
   const WgPlan p = wgrad_plan(co_g, ci_g, d->groups, d->kernel, d->stride, d->dilation, d->width, n_cols, d->batch);
   if (gconv_wgrad_applicable(d)) return gconv_wgrad_workspace_floats(d);
+  if (small_cin_wgrad_applicable(d)) return (size_t)(small_cin_wgrad_slabs(d) + 1) * ((size_t)d->c_out * (d->kernel + 1));
   // (+1: room for the summed gradient when the two-kernel finish is used)
   return (size_t)(p.splits + 1) * ((size_t)co_g * d->groups * ci_g * d->kernel + (size_t)co_g * d->groups);
 }

@@ -87,15 +87,23 @@ class PreparedWeights:
     keeps one instance per parameter epoch, so every forward / backward of that epoch -- e.g. D(y) and
     D(G(c)) of a discriminator phase -- shares a single scale + pack + pack launch sequence."""
 
-    __slots__ = ("key", "w", "scale", "_fwd", "_fwd_desc", "_bwd", "_res")
+    __slots__ = ("key", "w", "scale", "_fwd", "_fwd_desc", "_bwd", "_res", "_stale")
 
     def __init__(self, key, w, scale, fwd=None, fwd_desc=None):
         """``fwd``: the packed forward image, or None with ``fwd_desc`` (any descriptor of the layer) to build it
         on first use -- layers that only run inside a fused multi-layer kernel never need it."""
         self.key, self.w, self.scale, self._fwd, self._fwd_desc, self._bwd, self._res = key, w, scale, fwd, fwd_desc, None, None
+        self._stale = False  # set by weight_bank.WeightBank when it overwrites the (shared, persistent) images
+
+    def _check(self):
+        if self._stale:
+            raise RuntimeError("these prepared weights were overwritten by a later WeightBank.ensure(): a backward pass "
+                               "through a graph built before the last parameter update is not supported with a "
+                               "weight bank (call backward before the optimizer step, or disable the bank)")
 
     @property
     def fwd(self):
+        self._check()
         if self._fwd is None:
             with torch.no_grad():
                 self._fwd = ops.pack_weight(self._fwd_desc, self.w, self.scale)
@@ -109,6 +117,7 @@ class PreparedWeights:
         return self._res
 
     def bwd(self, desc):
+        self._check()
         if self._bwd is None:
             with torch.no_grad():
                 self._bwd = ops.pack_weight_bwd(desc, self.w, self.scale)

@@ -56,6 +56,9 @@ class WaveNetResidualBlock(torch.nn.Module):
         gate_out_channels = gate_channels // 2
         self.conv1x1_out = Conv1d1x1(gate_out_channels, residual_channels, bias=bias)
         self.conv1x1_skip = Conv1d1x1(gate_out_channels, skip_channels, bias=bias)
+        for cv in self.fused_convs():
+            if cv is not None:
+                cv.bank_images = False  # weight_bank.WeightBank: row scales only; the layer's own fused image is used
 
     fuse_layer = True  # one launch per layer where csrc/wavenet.hip covers the geometry (PWG.v1: 64 / 128 / 64 / 80)
 

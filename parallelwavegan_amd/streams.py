@@ -4,17 +4,27 @@ hipGraph, they become parallel branches of the DAG and small kernels of differen
 the 256 CUs.  Autograd replays each backward node on the stream of its forward, so the backward
 pass is forked the same way.
 """
+import os
+
 import torch
 
 _POOL = {}
 
 
+# At most this many side streams: more branches than that share streams round-robin (branches on one stream run in
+# program order).  The device exposes 4 hardware queues to a process by default; measured on the HiFi-GAN V1 step
+# (tools/exp_queues.sh, profiles/r04_queues_and_streams.txt): 8 or 16 queues make the captured step 35 % SLOWER (the
+# concurrent MFMA kernels evict each other's tiles), one stream is 22 % slower than the default.
+MAX_SIDE_STREAMS = int(os.environ.get("PWG_MAX_SIDE_STREAMS", "8"))
+
+
 def _streams(device, n):
     key = (device.index if device.index is not None else torch.cuda.current_device())
     pool = _POOL.setdefault(key, [])
-    while len(pool) < n:
+    m = max(1, min(n, MAX_SIDE_STREAMS))
+    while len(pool) < m:
         pool.append(torch.cuda.Stream(device=device))
-    return pool[:n]
+    return [pool[i % m] for i in range(n)]
 
 
 def _record(obj, stream):
@@ -39,8 +49,9 @@ def run_branches(branches, device, enabled=True):
         s.wait_event(fork)
         with torch.cuda.stream(s):
             outs.append(fn())
-    for o, s in zip(outs, side):
+    for s in dict.fromkeys(side):
         cur.wait_stream(s)
+    for o in outs:
         _record(o, cur)  # produced on a side stream, consumed on the caller's stream
     return outs
 
@@ -70,7 +81,7 @@ def run_branches_chained(branches, device):
             done = torch.cuda.Event()
             done.record(s)
             prev = (done, out)
-    for s in side:
+    for s in dict.fromkeys(side):
         cur.wait_stream(s)
     _record(prev[1], cur)
     return prev[1]

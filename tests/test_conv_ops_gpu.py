@@ -256,3 +256,56 @@ def test_small_cout_streaming_kernel(cin, cout, t, k, dil, pre, post, device):
         y = ops.conv1d_forward(desc, x.to(device), ops.pack_weight(desc, wd), b.to(device))
     assert "conv1d_small_cout_kernel" in prof.results
     assert (y.cpu() - ref).abs().max().item() <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("B,cout,t,k,dil,pad,pre,post,wn", [
+    (2, 16, 3000, 15, 1, 7, None, "leaky_relu", True),     # MelGAN discriminator's first layer (zero padding)
+    (3, 16, 2600, 15, 1, 0, None, "leaky_relu", False),    # ... as trained: reflect pad applied beforehand, pad 0
+    (1, 128, 4100, 15, 1, 7, None, "leaky_relu", True),    # HiFi-GAN scale discriminator's first layer, ragged tiles
+    (2, 64, 2500, 3, 2, 2, "leaky_relu", None, False),     # dilated, pre-activated (the operand activation of the wgrad)
+    (2, 8, 2048, 16, 1, 8, None, None, True),              # maximal tap count, exactly two tiles
+])
+def test_single_input_channel_kernels(B, cout, t, k, dil, pad, pre, post, wn, device):
+    """Cin = 1 over a long sequence (every discriminator's first layer) takes the streaming VALU kernels
+    conv1d_small_cin_kernel / conv1d_small_cin_wgrad_kernel instead of an MFMA tile with one live channel: forward,
+    weight and bias gradient (plain and through the weight-norm finish) vs ATen CPU; the data gradient keeps its path."""
+    from tests.util import poison_empty, poison_lds
+
+    g = torch.Generator().manual_seed(cout + k + t)
+    x = torch.randn(B, 1, t, generator=g, requires_grad=True)
+    v = (torch.randn(cout, 1, k, generator=g) / k ** 0.5).requires_grad_()
+    gg = (1.0 + 0.1 * torch.randn(cout, 1, 1, generator=g)).requires_grad_()
+    b = (0.1 * torch.randn(cout, generator=g)).requires_grad_()
+    w = gg * v / v.flatten(1).norm(dim=1).view(-1, 1, 1) if wn else v
+    xa = x if pre is None else F.leaky_relu(x, 0.2)
+    ref = F.conv1d(xa, w, b, dilation=dil, padding=pad)
+    t_out = ref.shape[-1]
+    out_ref = F.leaky_relu(ref, 0.1) if post else ref
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)  # (gradient w.r.t. the pre-post_act sum, which is what the backward entry points take)
+    desc = ops.make_conv_desc(B, 1, cout, t, t_out, k, dilation=dil, pad_left=pad, pre_act=pre, pre_slope=0.2,
+                              post_act=post, post_slope=0.1)
+    xd, dyd, bd = x.detach().to(device), dy.to(device), b.detach().to(device)
+    wd = w.detach().to(device).contiguous()
+    with poison_lds(), poison_empty(), ops.profile() as prof:
+        y = ops.conv1d_forward(desc, xd, ops.pack_weight(desc, wd), bd)
+        if wn:
+            dv, dg, db = ops.conv1d_backward_weight_wn(desc, xd, dyd, v.detach().to(device), gg.detach().reshape(-1).to(device))
+            dv2, dg2, db2 = ops.conv1d_backward_weight_wn(desc, xd, dyd, v.detach().to(device), gg.detach().reshape(-1).to(device))
+        else:
+            dv, db = ops.conv1d_backward_weight(desc, xd, dyd, tuple(v.shape))
+            dv2, db2 = ops.conv1d_backward_weight(desc, xd, dyd, tuple(v.shape))
+            dw_only, none = ops.conv1d_backward_weight(desc, xd, dyd, tuple(v.shape), need_db=False)
+        dx = ops.conv1d_backward_data(desc, dyd, ops.pack_weight_bwd(desc, wd), xd)
+    assert "conv1d_small_cin_kernel" in prof.results and "conv1d_small_cin_wgrad_kernel" in prof.results, list(prof.results)
+    _close(y, out_ref, "forward")
+    _close(dv, v.grad, "weight gradient")
+    _close(db, b.grad, "bias gradient")
+    _close(dx, x.grad, "data gradient")
+    assert torch.equal(dv, dv2) and torch.equal(db, db2)  # fixed slabs, fixed summation order
+    if wn:
+        _close(dg.reshape(-1), gg.grad.reshape(-1), "dg")
+        assert torch.equal(dg, dg2)
+    else:
+        assert none is None
+        _close(dw_only, v.grad, "weight gradient (no bias)")

@@ -1,0 +1,37 @@
+"""N training steps of one BASELINE config exactly as bench.py times them (hipGraph replay, branch streams), nothing
+else -- the command tools/graph_timeline.py's kernel trace is taken from.  usage: train_replay.py [c3|c5|c2|c4] [steps]"""
+import os
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from parallelwavegan_amd.bin.train import Trainer  # noqa: E402
+from parallelwavegan_amd.utils import build_from_config  # noqa: E402
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "c3"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+dev = torch.device("cuda:0")
+conf = bench.load_conf(bench.TRAIN_CONFIGS[tag])
+torch.manual_seed(4321)
+model, criterion, opt, sched = build_from_config(conf, dev)
+conf.update(generator_train_start_steps=0, discriminator_train_start_steps=0, train_max_steps=10 ** 9,
+            save_interval_steps=10 ** 9, eval_interval_steps=10 ** 9, log_interval_steps=10 ** 9, distributed=False,
+            rank=0, outdir=tempfile.mkdtemp(), progress=False, use_hip_graph=os.environ.get("PWG_NO_GRAPH") != "1",
+            graph_warmup_steps=2, branch_streams=os.environ.get("PWG_NO_BRANCH") != "1")
+batch = bench.synthetic_batch(conf, conf["batch_size"], dev, 0)
+tr = Trainer(steps=1, epochs=0, data_loader={"train": [batch], "dev": [batch]}, sampler={"train": None, "dev": None},
+             model=model, criterion=criterion, optimizer=opt, scheduler=sched, config=conf, device=dev)
+tr.tqdm = None
+import time  # noqa: E402
+
+for i in range(n):
+    if i == n - 6:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+    tr._train_step(batch)
+torch.cuda.synchronize()
+print(f"{tag}: last 6 steps {(time.perf_counter() - t0) / 6 * 1e3:.2f} ms per step (graph: {bool(tr._graphs)})")
