@@ -488,6 +488,21 @@ int pwg_stft_loss_backward(const float* fx, const float* fy, const float* basis,
                            int32_t n_cols, int32_t taps, int32_t bins, int32_t frames, float eps,
                            const float* sums, const float* g2, float* dspec, void* stream);
 
+/* ---- STFT loss through a radix-2 FFT in LDS (round 4; power-of-two n_fft in 256 .. 2048) ----
+ * Same contract as pwg_stft_loss_forward / _backward (reference losses/stft_loss.py:16-40, :61, :82: torch.stft with
+ * center=True / reflect padding / window zero-padded to n_fft, clamp 1e-7, sqrt, the two losses), computed from the raw
+ * signals x (predicted), y (target), both (B, T): one complex FFT per frame carries both signals.  window: `win` floats;
+ * twiddle: n_fft / 2 pairs (cos, -sin)(2 pi t / n_fft) (host float64 -> float32); sums: 5 floats [S_d, S_y, S_l, sc, mag].
+ * Backward: g2 = upstream gradients of (sc, mag) on the device; dframes: scratch of B * (1 + T / hop) * win floats; dx (B, T). */
+int pwg_stft_fft_supported(int32_t n_fft, int32_t win, int32_t hop);
+size_t pwg_stft_fft_workspace_floats(int32_t batch, int32_t frames, int32_t n_fft);
+int pwg_stft_fft_loss_forward(const float* x, const float* y, const float* window, const float* twiddle, int32_t batch,
+                              int32_t t, int32_t n_fft, int32_t hop, int32_t win, float eps, float* workspace,
+                              float* sums, void* stream);
+int pwg_stft_fft_loss_backward(const float* x, const float* y, const float* window, const float* twiddle, int32_t batch,
+                               int32_t t, int32_t n_fft, int32_t hop, int32_t win, float eps, const float* sums,
+                               const float* g2, float* dframes, float* dx, void* stream);
+
 /* Fused mel-spectrogram loss of a (predicted, target) pair (losses/mel_loss.py:95-110,150-165):
  *   sum[0] = sum_{b,j,f} | log(max(mel_x, eps)) - log(max(mel_y, eps)) | / log_div,
  *   mel = filterbank (n_mels x bins) applied to |STFT| = sqrt(max(re^2 + im^2, eps)); F.l1_loss is sum[0] / (B * n_mels * frames).

@@ -16,7 +16,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # in-loop LeakyReLU is v_mul + v_max instead of three instructions (see csrc/conv1d.hip, ACT == 1)
 EXTRA = {"conv1d.hip": ["-fno-honor-nans", "-mno-amdgpu-ieee"],
          "conv1d_wgrad.hip": ["-fno-honor-nans", "-mno-amdgpu-ieee"],
-         "resunit.hip": ["-fno-honor-nans", "-mno-amdgpu-ieee"]}
+         "resunit.hip": ["-fno-honor-nans", "-mno-amdgpu-ieee"],
+         # no FMA contraction: the spectra of the two signals of a frame are formed by the same source expressions and
+         # must round identically (loss and gradient of (x, x) are exactly 0, as with torch.stft); hipcc otherwise
+         # contracts re*re + im*im differently in the two inlined copies
+         "stft_fft.hip": ["-ffp-contract=off"]}
 
 
 def sources():

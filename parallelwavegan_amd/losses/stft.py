@@ -11,6 +11,7 @@ FFT does not apply.  Replaces ``torch.stft`` at
 /root/reference/parallel_wavegan/losses/stft_loss.py:30-36 and losses/mel_loss.py:99.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -49,6 +50,7 @@ class STFTMagnitude(torch.nn.Module):
             assert win.shape == (win_length,), (win.shape, win_length)
         else:
             win = _window(window, win_length) if window is not None else np.ones(win_length)
+        self._win64 = np.asarray(win, dtype=np.float64)  # (the FFT path multiplies by the window itself)
         n = np.arange(self.taps * hop_size)
         valid = n < win_length
         w = np.where(valid, win[np.minimum(n, win_length - 1)], 0.0)
@@ -88,10 +90,32 @@ class STFTMagnitude(torch.nn.Module):
     def forward(self, x):
         return Fn.StftMagFn.apply(self.spectrum(x), self.eps)
 
+    use_fft = os.environ.get("PWG_STFT_FFT", "1") == "1"  # power-of-two sizes: radix-2 FFT in LDS (csrc/stft_fft.hip)
+
     def pair_losses(self, x, y):
         """Fused single-launch losses of the pair: 2-element tensor [spectral convergence ||Y| - |X||_F / ||Y||_F,
-        mean |log|Y| - log|X||] over (B, bins, frames); differentiable w.r.t. ``x`` (``y`` is a constant)."""
+        mean |log|Y| - log|X||] over (B, bins, frames); differentiable w.r.t. ``x`` (``y`` is a constant).
+        Power-of-two FFT sizes (256 .. 2048) go through the FFT kernel, every other size (the sub-band losses' 171 /
+        384 / 683) through the dense windowed DFT on MFMA."""
+        if self.use_fft and x.shape[-1] > self.fft_size // 2 and self._fft_tables(x.device) is not None:
+            return StftFftPairFn.apply(x, y.detach(), self)
         return StftPairSumsFn.apply(x, y.detach(), self)
+
+    def _fft_tables(self, device):
+        """(window, twiddle) device tensors for the FFT path, or None when the geometry is not covered."""
+        from .. import _lib
+
+        tabs = getattr(self, "_fft_tabs", None)
+        if tabs is None or tabs[0] != str(device):
+            if not _lib.lib().pwg_stft_fft_supported(self.fft_size, self.win_length, self.hop_size):
+                tabs = (str(device), None)
+            else:
+                t = np.arange(self.fft_size // 2, dtype=np.float64) * (2.0 * np.pi / self.fft_size)
+                tw = np.stack([np.cos(t), -np.sin(t)], axis=1).astype(np.float32)
+                tabs = (str(device), (torch.from_numpy(self._win64.astype(np.float32)).to(device),
+                                      torch.from_numpy(np.ascontiguousarray(tw)).to(device)))
+            self._fft_tabs = tabs
+        return tabs[1]
 
 
 class StftPairSumsFn(torch.autograd.Function):
@@ -150,4 +174,48 @@ class StftPairSumsFn(torch.autograd.Function):
         dx = torch.empty(b, t, device=fx.device, dtype=torch.float32)
         _lib.check(L.pwg_frame_fold_backward(_ptr(dfold), _ptr(dx), b, t, pad, mod.hop_size, n_cols, _stream()),
                    "frame_fold_backward")
+        return dx, None, None
+
+
+class StftFftPairFn(torch.autograd.Function):
+    """``pwg_stft_fft_loss_forward`` / ``_backward`` (csrc/stft_fft.hip): the pair losses of a power-of-two resolution
+    from the raw signals -- one complex radix-2 FFT in LDS per frame carries both signals; the backward pass re-runs
+    it, transforms the per-bin gradients back with the same FFT and overlap-adds the windowed frame gradients with a
+    deterministic gather.  Same values as :class:`StftPairSumsFn` to fp32 rounding (the FFT's error is the smaller)."""
+
+    @staticmethod
+    def forward(ctx, x, y, mod):
+        from .. import _lib
+        from ..ops import _ptr, _require_device, _stream
+
+        x = x if x.is_contiguous() else x.contiguous()
+        y = y if y.is_contiguous() else y.contiguous()
+        _require_device(x, y)
+        b, t = x.shape
+        frames = mod.frames(t)
+        window, twiddle = mod._fft_tables(x.device)
+        L = _lib.lib()
+        ws = torch.empty(L.pwg_stft_fft_workspace_floats(b, frames, mod.fft_size), device=x.device, dtype=torch.float32)
+        sums = torch.empty(5, device=x.device, dtype=torch.float32)  # [S_d, S_y, S_l, sc, mag]
+        _lib.check(L.pwg_stft_fft_loss_forward(_ptr(x), _ptr(y), _ptr(window), _ptr(twiddle), b, t, mod.fft_size,
+                                               mod.hop_size, mod.win_length, float(mod.eps), _ptr(ws), _ptr(sums),
+                                               _stream()), "stft_fft_loss_forward")
+        ctx.save_for_backward(x, y, sums, window, twiddle)
+        ctx.mod, ctx.dims = mod, (b, t, frames)
+        return sums[3:]
+
+    @staticmethod
+    def backward(ctx, g2):
+        from .. import _lib
+        from ..ops import _ptr, _stream
+
+        x, y, sums, window, twiddle = ctx.saved_tensors
+        mod = ctx.mod
+        b, t, frames = ctx.dims
+        g2 = g2.contiguous()
+        dframes = torch.empty(b, frames, mod.win_length, device=x.device, dtype=torch.float32)
+        dx = torch.empty(b, t, device=x.device, dtype=torch.float32)
+        _lib.check(_lib.lib().pwg_stft_fft_loss_backward(_ptr(x), _ptr(y), _ptr(window), _ptr(twiddle), b, t, mod.fft_size,
+                                                         mod.hop_size, mod.win_length, float(mod.eps), _ptr(sums), _ptr(g2),
+                                                         _ptr(dframes), _ptr(dx), _stream()), "stft_fft_loss_backward")
         return dx, None, None

@@ -164,3 +164,62 @@ def test_fused_mel_loss_log_bases_and_ragged_shapes(device):
         l0.backward()
         assert abs(l1.item() - l0.item()) <= 2e-5 * l0.item(), (log_base, l1.item(), l0.item())
         assert _rel(g1.cpu().numpy(), yh.grad.cpu().numpy()) <= 5e-4
+
+
+@pytest.mark.parametrize("n_fft,hop,win,b,t", [
+    (1024, 120, 600, 3, 5000),    # MultiResolutionSTFTLoss defaults (stft_loss.py:124-127)
+    (2048, 240, 1200, 2, 4111),   # T not a multiple of the hop, window shorter than the FFT
+    (512, 50, 240, 5, 1300),
+    (256, 64, 256, 2, 129),       # shortest signal the reflect padding allows (T = n_fft / 2 + 1), window == n_fft
+    (2048, 300, 2048, 1, 9000),
+])
+def test_fft_stft_loss_matches_torch_stft_in_float64(n_fft, hop, win, b, t, device):
+    """csrc/stft_fft.hip (radix-2 FFT in LDS, both signals per frame, FFT-based backward + deterministic overlap-add
+    gather) against the reference's formulas (losses/stft_loss.py:16-40, :61, :82) evaluated with torch.stft in float64
+    on the CPU: the two losses to 2e-5, the gradient to 2e-4 of its largest entry (the dense-DFT kernel's bar is 2e-3);
+    the dense kernel agrees; two runs are bit-identical."""
+    from parallelwavegan_amd.losses.stft_loss import STFTLoss
+    from tests.util import poison_empty, poison_lds
+
+    x = (0.5 * synth.synth_input("fftx", (b, t), seed=n_fft + t)).to(device).requires_grad_()
+    y = (0.5 * synth.synth_input("ffty", (b, t), seed=n_fft + t + 1)).to(device)
+    crit = STFTLoss(n_fft, hop, win).to(device)
+    assert crit.stft_magnitude._fft_tables(device) is not None
+    with poison_lds(), poison_empty(), ops_profile() as prof:
+        sc, mag = crit(x, y)
+        (sc + 2.0 * mag).backward()
+    assert "stft_fft_fwd_kernel" in prof.results and "stft_fft_bwd_kernel" in prof.results, list(prof.results)
+    g_fft = x.grad.clone()
+    x.grad = None
+    sc2, mag2 = crit(x, y)
+    (sc2 + 2.0 * mag2).backward()
+    assert torch.equal(sc, sc2) and torch.equal(mag, mag2) and torch.equal(g_fft, x.grad)
+
+    xd = x.detach().cpu().double().requires_grad_()
+    wdw = torch.hann_window(win, dtype=torch.float64)
+
+    def mag64(s):
+        sp = torch.stft(s, n_fft, hop, win, wdw, return_complex=True)
+        return torch.sqrt(torch.clamp(sp.real ** 2 + sp.imag ** 2, min=1e-7)).transpose(2, 1)
+
+    xm, ym = mag64(xd), mag64(y.cpu().double())
+    sc_ref = torch.norm(ym - xm, p="fro") / torch.norm(ym, p="fro")
+    mag_ref = torch.nn.functional.l1_loss(torch.log(ym), torch.log(xm))
+    (sc_ref + 2.0 * mag_ref).backward()
+    assert abs(sc.item() - sc_ref.item()) <= 2e-5 * sc_ref.item(), (sc.item(), sc_ref.item())
+    assert abs(mag.item() - mag_ref.item()) <= 2e-5 * mag_ref.item(), (mag.item(), mag_ref.item())
+    assert _rel(g_fft.cpu().numpy(), xd.grad.numpy()) <= 2e-4
+
+    # the dense windowed-DFT kernel (the path of the non-power-of-two sizes) on the same input
+    crit.stft_magnitude.use_fft = False
+    x.grad = None
+    sc3, mag3 = crit(x, y)
+    (sc3 + 2.0 * mag3).backward()
+    assert abs(sc3.item() - sc.item()) <= 2e-5 * sc.item() and abs(mag3.item() - mag.item()) <= 2e-5 * mag.item()
+    assert _rel(x.grad.cpu().numpy(), g_fft.cpu().numpy()) <= 2e-3
+
+
+def ops_profile():
+    from parallelwavegan_amd import ops
+
+    return ops.profile()
