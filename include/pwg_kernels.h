@@ -503,6 +503,19 @@ int pwg_stft_fft_loss_backward(const float* x, const float* y, const float* wind
                                int32_t t, int32_t n_fft, int32_t hop, int32_t win, float eps, const float* sums,
                                const float* g2, float* dframes, float* dx, void* stream);
 
+/* Mel-spectrogram loss through the same FFT (reference losses/mel_loss.py:95-110, :150-165; eps = the module's 1e-10):
+ * total[0] = sum_{b,j,f} | log(max(mel_x, eps)) - log(max(mel_y, eps)) | / log_div.  fb: filterbank [n_mels][bins_pad]
+ * (bin fastest, bins_pad >= n_fft / 2 + 1); mel_range: per mel (first, last) bin of its non-zero support; bin_range: per
+ * bin (first, last) mel covering it (int32 pairs).  workspace: pwg_stft_fft_workspace_floats() floats; dframes / dx as above. */
+int pwg_mel_fft_loss_forward(const float* x, const float* y, const float* window, const float* twiddle, const float* fb,
+                             const int32_t* mel_range, const int32_t* bin_range, int32_t batch, int32_t t, int32_t n_fft,
+                             int32_t hop, int32_t win, int32_t n_mels, int32_t bins_pad, float eps, float log_div,
+                             float* workspace, float* total, void* stream);
+int pwg_mel_fft_loss_backward(const float* x, const float* y, const float* window, const float* twiddle, const float* fb,
+                              const int32_t* mel_range, const int32_t* bin_range, int32_t batch, int32_t t, int32_t n_fft,
+                              int32_t hop, int32_t win, int32_t n_mels, int32_t bins_pad, float eps, float log_div,
+                              const float* gout, float* dframes, float* dx, void* stream);
+
 /* Fused mel-spectrogram loss of a (predicted, target) pair (losses/mel_loss.py:95-110,150-165):
  *   sum[0] = sum_{b,j,f} | log(max(mel_x, eps)) - log(max(mel_y, eps)) | / log_div,
  *   mel = filterbank (n_mels x bins) applied to |STFT| = sqrt(max(re^2 + im^2, eps)); F.l1_loss is sum[0] / (B * n_mels * frames).

@@ -202,6 +202,8 @@ SIGNATURES = {
     "pwg_stft_fft_loss_forward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
     "pwg_stft_fft_loss_backward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp,
                                                   _vp, _vp]),
+    "pwg_mel_fft_loss_forward": (ctypes.c_int, [_vp] * 7 + [_i32] * 7 + [_f32, _f32, _vp, _vp, _vp]),
+    "pwg_mel_fft_loss_backward": (ctypes.c_int, [_vp] * 7 + [_i32] * 7 + [_f32, _f32, _vp, _vp, _vp, _vp]),
     "pwg_mel_loss_workspace_floats": (ctypes.c_size_t, [_i32, _i32, _i32, _i32]),
     "pwg_mel_loss_forward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp,
                                             _vp, _vp, _vp, _vp]),

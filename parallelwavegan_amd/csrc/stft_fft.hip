@@ -65,6 +65,31 @@ __device__ __forceinline__ float2* fft_lds(float2* src, float2* dst, const float
   return src;
 }
 
+// buf[0 .. N/2) = even / odd packing of the windowed frame f of x, buf[N/2 .. N) = the same of y
+template <int LOGN>
+__device__ __forceinline__ void load_frame_pair(float2* buf, const float* __restrict__ xb, const float* __restrict__ yb,
+                                                const float* __restrict__ window, int f, int hop, int win, int off,
+                                                int t_len, int tid) {
+  constexpr int N = 1 << LOGN, H = N / 2;
+  for (int m = tid; m < N; m += 256) {
+    const float* sb = m < H ? xb : yb;
+    const int mm = m & (H - 1);
+    float v[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int n = 2 * mm + e, j = n - off;
+      v[e] = 0.f;
+      if (j >= 0 && j < win) {
+        int t = f * hop + n - H;  // center = True: the signal is reflect-padded by n_fft / 2
+        if (t < 0) t = -t;
+        if (t >= t_len) t = 2 * (t_len - 1) - t;
+        v[e] = window[j] * sb[t];
+      }
+    }
+    buf[m] = make_float2(v[0], v[1]);
+  }
+}
+
 // X[k] of a real frame from the M-point transform Z of its even / odd packing, k = 0 .. M (W = W_N^k, (-1, 0) at k = M)
 __device__ __forceinline__ float2 rfft_bin(const float2* __restrict__ z, int k, int M, float2 w) {
   const float2 zk = z[k & (M - 1)], zn = z[(M - k) & (M - 1)];
@@ -97,23 +122,7 @@ __global__ __launch_bounds__(256) void stft_fft_kernel(StftFftArgs a) {
     const float* xb = a.x + (long)b * a.t;
     const float* yb = a.y + (long)b * a.t;
     __syncthreads();  // the previous frame's readers are done (first time: the twiddles are staged)
-    for (int m = tid; m < N; m += 256) {  // buf0[0 .. H) = packed x frame, buf0[H .. N) = packed y frame
-      const float* sb = m < H ? xb : yb;
-      const int mm = m & (H - 1);
-      float v[2];
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int n = 2 * mm + e, j = n - a.off;
-        v[e] = 0.f;
-        if (j >= 0 && j < a.win) {
-          int t = f * a.hop + n - H;  // center = True: the signal is reflect-padded by n_fft / 2
-          if (t < 0) t = -t;
-          if (t >= a.t) t = 2 * (a.t - 1) - t;
-          v[e] = a.window[j] * sb[t];
-        }
-      }
-      buf0[m] = make_float2(v[0], v[1]);
-    }
+    load_frame_pair<LOGN>(buf0, xb, yb, a.window, f, a.hop, a.win, a.off, a.t, tid);
     __syncthreads();
     float2* r = fft_lds<LOGN - 1, 2, 2>(buf0, buf1, tw, tid);
     float2* o = (r == buf0) ? buf1 : buf0;
@@ -169,6 +178,116 @@ __global__ __launch_bounds__(256) void stft_fft_kernel(StftFftArgs a) {
       p[3] = 0.f;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Mel-spectrogram loss (reference losses/mel_loss.py:95-110, :150-165) on the same transform: |X|, |Y| of a frame go to
+// LDS, threads 0 .. 2 n_mels - 1 contract them with their filter -- only over the filter's support (Slaney triangles:
+// 3 .. 60 of the 513 / 1025 bins; the bins outside hold exact zeros in the dense matrix) -- clamp, log and accumulate
+// |log mel x - log mel y| / log_div.  Backward: the same quantities are recomputed, d mel_x goes to LDS, each bin gathers
+// d|X|[k] = sum_j fb[j][k] d mel_x[j] over the few filters that cover it, and G = d|X| / |X| * X returns through the same
+// inverse-direction FFT, windowing and gather as the STFT loss.  No spectrum, magnitude or mel tensor in HBM.
+// ---------------------------------------------------------------------------------------------------------------
+struct MelFftArgs {
+  StftFftArgs s;
+  const float* fb;       // filterbank [mel][bins_pad] (bin fastest)
+  const int* mel_range;  // per mel: first / last bin of its support (last < first: empty)
+  const int* bin_range;  // per bin: first / last mel whose support contains it
+  int n_mels, bins_pad;
+  float log_div;
+  const float* gout;     // backward: d loss / d (sum |log mel x - log mel y|), device scalar
+};
+constexpr int MEL_FFT_MAX_MELS = 128;
+
+template <int LOGN, bool BWD>
+__global__ __launch_bounds__(256) void mel_fft_kernel(MelFftArgs m) {
+  const StftFftArgs& a = m.s;
+  constexpr int N = 1 << LOGN, H = N / 2;
+  extern __shared__ float2 sm2[];
+  float2* buf0 = sm2;
+  float2* buf1 = sm2 + N;
+  float2* tw = sm2 + 2 * N;
+  __shared__ float red[4];
+  __shared__ float dmel[MEL_FFT_MAX_MELS];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < H; i += 256) tw[i] = a.twiddle[i];
+  float acc = 0.f;
+  const float gscale = BWD ? m.gout[0] / m.log_div : 0.f;
+  const int units = a.batch * a.frames;
+  for (int u = blockIdx.x; u < units; u += gridDim.x) {
+    const int b = u / a.frames, f = u - b * a.frames;
+    __syncthreads();  // the previous frame's readers are done (first time: the twiddles are staged)
+    load_frame_pair<LOGN>(buf0, a.x + (long)b * a.t, a.y + (long)b * a.t, a.window, f, a.hop, a.win, a.off, a.t, tid);
+    __syncthreads();
+    float2* r = fft_lds<LOGN - 1, 2, 2>(buf0, buf1, tw, tid);
+    float2* o = (r == buf0) ? buf1 : buf0;
+    float* mag = reinterpret_cast<float*>(o);  // [0 .. H] = |X|, [H + 1 .. 2 H + 1] = |Y|  (2 N floats available)
+    for (int k = tid; k <= H; k += 256) {
+      const float2 w = k < H ? tw[k] : make_float2(-1.f, 0.f);
+      const float2 xk = rfft_bin(r, k, H, w), yk = rfft_bin(r + H, k, H, w);
+      mag[k] = sqrtf(fmaxf(xk.x * xk.x + xk.y * xk.y, a.eps));
+      mag[H + 1 + k] = sqrtf(fmaxf(yk.x * yk.x + yk.y * yk.y, a.eps));
+    }
+    __syncthreads();
+    float mel_v = 0.f;
+    if (tid < 2 * m.n_mels) {
+      const int sig = tid >= m.n_mels, j = tid - sig * m.n_mels;
+      const int lo = m.mel_range[2 * j], hi = m.mel_range[2 * j + 1];
+      const float* fr = m.fb + (long)j * m.bins_pad;
+      const float* mg = mag + sig * (H + 1);
+      for (int k = lo; k <= hi; ++k) mel_v += fr[k] * mg[k];
+    }
+    // pair the two signals' mels of filter j: thread j (x) needs thread n_mels + j's value (y) -> through LDS
+    __syncthreads();  // (all reads of mag are done: the scratch is reused below)
+    if (tid < 2 * m.n_mels) mag[tid] = mel_v;
+    __syncthreads();
+    if (tid < m.n_mels) {
+      const float vx = mag[tid], vy = mag[m.n_mels + tid];
+      const float lx = logf(fmaxf(vx, a.eps)), ly = logf(fmaxf(vy, a.eps));
+      if (!BWD) {
+        acc += fabsf(lx - ly) / m.log_div;
+      } else {
+        // d/d mel_x of |log(clamp(mel_x)) - log(clamp(mel_y))| / log_div; the clamp passes where mel_x >= eps
+        dmel[tid] = vx >= a.eps ? (lx > ly ? 1.f : (lx < ly ? -1.f : 0.f)) * gscale / vx : 0.f;
+      }
+    }
+    if (BWD) {
+      __syncthreads();
+      for (int k = tid; k <= H; k += 256) {
+        const int jlo = m.bin_range[2 * k], jhi = m.bin_range[2 * k + 1];
+        float dm = 0.f;
+        for (int j = jlo; j <= jhi; ++j) dm += m.fb[(long)j * m.bins_pad + k] * dmel[j];
+        const float2 w = k < H ? tw[k] : make_float2(-1.f, 0.f);
+        const float2 xk = rfft_bin(r, k, H, w);
+        const float p = xk.x * xk.x + xk.y * xk.y;
+        const float sc = p >= a.eps ? dm / sqrtf(fmaxf(p, a.eps)) : 0.f;
+        o[k] = make_float2(sc * xk.x, -sc * xk.y);  // conj(G[k])
+      }
+      for (int k = H + 1 + tid; k < N; k += 256) o[k] = make_float2(0.f, 0.f);
+      __syncthreads();
+      float2* g = fft_lds<LOGN, 1, 1>(o, r, tw, tid);
+      float* df = a.dframes + (long)u * a.win;
+      for (int j = tid; j < a.win; j += 256) df[j] = a.window[j] * g[j + a.off].x;
+    }
+  }
+  if (!BWD) {
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) a.partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+
+// total = sum over workgroups (fixed order) of partial[.]
+__global__ __launch_bounds__(256) void mel_fft_finish_kernel(const float* partial, int units, float* total) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int u = threadIdx.x; u < units; u += 256) s += partial[u];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) total[0] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // sums[j] = sum over workgroups (fixed order) of partial[.][j]; sums[3] = sqrt(S_d) / sqrt(S_y), sums[4] = S_l / n
@@ -333,6 +452,91 @@ extern "C" int pwg_stft_fft_loss_backward(const float* x, const float* y, const 
   ProfScope prof(stream, "stft_fft_gather_kernel", 0, 4.0 * ((double)batch * a.frames * win + (double)total));
   hipLaunchKernelGGL(stft_fft_gather_kernel, dim3((int)blocks), dim3(256), 0, stream, (const float*)dframes, dx, batch, t,
                      n_fft, hop, win, a.off, a.frames);
+  PWG_CHECK_LAUNCH("stft_fft_gather");
+  return PWG_OK;
+}
+
+
+// ---- mel loss through the FFT
+static int fill_mel_fft(MelFftArgs* m, const float* x, const float* y, const float* window, const float* twiddle,
+                        const float* fb, const int32_t* mel_range, const int32_t* bin_range, int batch, int t, int n_fft,
+                        int hop, int win, int n_mels, int bins_pad, float eps, float log_div) {
+  const int rc = fill_fft_args(&m->s, x, y, window, twiddle, batch, t, n_fft, hop, win, eps);
+  if (rc != PWG_OK) return rc;
+  PWG_REQUIRE(fb && mel_range && bin_range, PWG_ERR_NULL, "mel_fft: NULL filterbank / range table");
+  PWG_REQUIRE(n_mels > 0 && n_mels <= MEL_FFT_MAX_MELS && bins_pad >= n_fft / 2 + 1 && log_div > 0.f, PWG_ERR_UNSUPPORTED,
+              "mel_fft: n_mels %d (<= %d), bins_pad %d, log_div %g", n_mels, MEL_FFT_MAX_MELS, bins_pad, (double)log_div);
+  m->fb = fb;
+  m->mel_range = mel_range;
+  m->bin_range = bin_range;
+  m->n_mels = n_mels;
+  m->bins_pad = bins_pad;
+  m->log_div = log_div;
+  m->gout = nullptr;
+  return PWG_OK;
+}
+
+template <bool BWD>
+static int launch_mel_fft(const MelFftArgs& m, int n_fft, hipStream_t stream) {
+  const StftFftArgs& a = m.s;
+  const int grid = fft_grid(a.batch * a.frames, n_fft);
+  const size_t lds = (size_t)(2 * n_fft + n_fft / 2) * sizeof(float2);
+  void (*kern)(MelFftArgs) = nullptr;
+  switch (log2_exact(n_fft)) {
+    case 8: kern = mel_fft_kernel<8, BWD>; break;
+    case 9: kern = mel_fft_kernel<9, BWD>; break;
+    case 10: kern = mel_fft_kernel<10, BWD>; break;
+    default: kern = mel_fft_kernel<11, BWD>; break;
+  }
+  const double units = (double)a.batch * a.frames;
+  ProfScope prof(stream, BWD ? "mel_fft_bwd_kernel" : "mel_fft_fwd_kernel",
+                 units * 5.0 * n_fft * log2_exact(n_fft) * (BWD ? 2.0 : 1.0),
+                 4.0 * (2.0 * a.batch * a.t + (BWD ? units * a.win : 0.0)));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, m);
+  PWG_CHECK_LAUNCH(BWD ? "mel_fft_backward" : "mel_fft_forward");
+  return PWG_OK;
+}
+
+extern "C" int pwg_mel_fft_loss_forward(const float* x, const float* y, const float* window, const float* twiddle,
+                                        const float* fb, const int32_t* mel_range, const int32_t* bin_range, int32_t batch,
+                                        int32_t t, int32_t n_fft, int32_t hop, int32_t win, int32_t n_mels, int32_t bins_pad,
+                                        float eps, float log_div, float* workspace, float* total, void* stream_) {
+  MelFftArgs m;
+  int rc = fill_mel_fft(&m, x, y, window, twiddle, fb, mel_range, bin_range, batch, t, n_fft, hop, win, n_mels, bins_pad,
+                        eps, log_div);
+  if (rc != PWG_OK) return rc;
+  PWG_REQUIRE(workspace && total, PWG_ERR_NULL, "mel_fft_loss_forward: NULL workspace / total");
+  hipStream_t stream = (hipStream_t)stream_;
+  m.s.partial = workspace;
+  rc = launch_mel_fft<false>(m, n_fft, stream);
+  if (rc != PWG_OK) return rc;
+  hipLaunchKernelGGL(mel_fft_finish_kernel, dim3(1), dim3(256), 0, stream, (const float*)workspace,
+                     fft_grid(m.s.batch * m.s.frames, n_fft), total);
+  PWG_CHECK_LAUNCH("mel_fft_finish");
+  return PWG_OK;
+}
+
+extern "C" int pwg_mel_fft_loss_backward(const float* x, const float* y, const float* window, const float* twiddle,
+                                         const float* fb, const int32_t* mel_range, const int32_t* bin_range, int32_t batch,
+                                         int32_t t, int32_t n_fft, int32_t hop, int32_t win, int32_t n_mels, int32_t bins_pad,
+                                         float eps, float log_div, const float* gout, float* dframes, float* dx,
+                                         void* stream_) {
+  MelFftArgs m;
+  int rc = fill_mel_fft(&m, x, y, window, twiddle, fb, mel_range, bin_range, batch, t, n_fft, hop, win, n_mels, bins_pad,
+                        eps, log_div);
+  if (rc != PWG_OK) return rc;
+  PWG_REQUIRE(gout && dframes && dx, PWG_ERR_NULL, "mel_fft_loss_backward: NULL pointer");
+  hipStream_t stream = (hipStream_t)stream_;
+  m.gout = gout;
+  m.s.dframes = dframes;
+  rc = launch_mel_fft<true>(m, n_fft, stream);
+  if (rc != PWG_OK) return rc;
+  const long total = (long)batch * t;
+  long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  ProfScope prof(stream, "stft_fft_gather_kernel", 0, 4.0 * ((double)batch * m.s.frames * win + (double)total));
+  hipLaunchKernelGGL(stft_fft_gather_kernel, dim3((int)blocks), dim3(256), 0, stream, (const float*)dframes, dx, batch, t,
+                     n_fft, hop, win, m.s.off, m.s.frames);
   PWG_CHECK_LAUNCH("stft_fft_gather");
   return PWG_OK;
 }

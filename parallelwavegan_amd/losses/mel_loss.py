@@ -1,4 +1,5 @@
 """Mel-spectrogram loss (drop-in for parallel_wavegan.losses.mel_loss)."""
+import ctypes
 import math
 
 import numpy as np
@@ -79,7 +80,12 @@ class MelSpectrogramLoss(torch.nn.Module):
             if y_hat.dim() == 3:
                 y_hat = y_hat.reshape(-1, y_hat.size(2))
                 y = y.reshape(-1, y.size(2))
-            total = MelPairLossFn.apply(y_hat, y.detach(), ms)
+            mod = ms.stft_magnitude
+            if (mod.use_fft and y_hat.shape[-1] > mod.fft_size // 2 and ms.num_mels <= 128
+                    and mod._fft_tables(y_hat.device) is not None):
+                total = MelFftPairLossFn.apply(y_hat, y.detach(), ms)  # power-of-two sizes: FFT in LDS (csrc/stft_fft.hip)
+            else:
+                total = MelPairLossFn.apply(y_hat, y.detach(), ms)
             n = y_hat.shape[0] * ms.num_mels * ms.stft_magnitude.frames(y_hat.shape[1])
             return total / n
         return Fn.l1_mean(self.mel_spectrogram(y_hat), self.mel_spectrogram(y))
@@ -146,4 +152,74 @@ class MelPairLossFn(torch.autograd.Function):
         dx = torch.empty(b, t, device=fx.device, dtype=torch.float32)
         _lib.check(L.pwg_frame_fold_backward(_ptr(dfold), _ptr(dx), b, t, pad, mod.hop_size, n_cols, _stream()),
                    "frame_fold_backward")
+        return dx, None, None
+
+
+class MelFftPairLossFn(torch.autograd.Function):
+    """sum | log mel(x) - log mel(y) | with ``pwg_mel_fft_loss_forward`` / ``_backward`` (csrc/stft_fft.hip): frame ->
+    radix-2 FFT in LDS -> magnitude -> mel filters over their supports -> clamp -> log -> L1, both signals per frame; the
+    backward pass recomputes them, gathers d|X| from the few filters covering each bin and returns through the same FFT."""
+
+    @staticmethod
+    def _tables(ms, device):
+        tabs = getattr(ms, "_fft_mel_tabs", None)
+        if tabs is None or tabs[0] != str(device):
+            fb = ms.mel_b[: ms.num_mels].contiguous().to(device)  # [mel][bins_pad]
+            nz = fb.cpu().numpy() != 0.0
+            bins = ms.stft_magnitude.bins
+            mel_range = np.zeros((ms.num_mels, 2), dtype=np.int32)
+            for j in range(ms.num_mels):
+                idx = np.nonzero(nz[j, :bins])[0]
+                mel_range[j] = (idx[0], idx[-1]) if idx.size else (0, -1)
+            bin_range = np.zeros((bins, 2), dtype=np.int32)
+            for k in range(bins):
+                cover = [j for j in range(ms.num_mels) if mel_range[j, 0] <= k <= mel_range[j, 1]]
+                bin_range[k] = (cover[0], cover[-1]) if cover else (0, -1)
+            tabs = (str(device), fb, torch.from_numpy(mel_range).to(device), torch.from_numpy(bin_range).to(device))
+            ms._fft_mel_tabs = tabs
+        return tabs[1:]
+
+    @staticmethod
+    def forward(ctx, x, y, ms):
+        from .. import _lib
+        from ..ops import _ptr, _require_device, _stream
+
+        mod = ms.stft_magnitude
+        x = x if x.is_contiguous() else x.contiguous()
+        y = y if y.is_contiguous() else y.contiguous()
+        _require_device(x, y)
+        b, t = x.shape
+        frames = mod.frames(t)
+        window, twiddle = mod._fft_tables(x.device)
+        fb, mel_range, bin_range = MelFftPairLossFn._tables(ms, x.device)
+        L = _lib.lib()
+        ws = torch.empty(L.pwg_stft_fft_workspace_floats(b, frames, mod.fft_size), device=x.device, dtype=torch.float32)
+        total = torch.empty(1, device=x.device, dtype=torch.float32)
+        ip = lambda z: ctypes.c_void_p(z.data_ptr())  # noqa: E731  (int32 tables)
+        _lib.check(L.pwg_mel_fft_loss_forward(_ptr(x), _ptr(y), _ptr(window), _ptr(twiddle), _ptr(fb), ip(mel_range),
+                                              ip(bin_range), b, t, mod.fft_size, mod.hop_size, mod.win_length, ms.num_mels,
+                                              fb.shape[1], float(ms.eps), float(ms.log_div), _ptr(ws), _ptr(total),
+                                              _stream()), "mel_fft_loss_forward")
+        ctx.save_for_backward(x, y, window, twiddle, fb, mel_range, bin_range)
+        ctx.ms, ctx.dims = ms, (b, t, frames)
+        return total.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        from .. import _lib
+        from ..ops import _ptr, _stream
+
+        x, y, window, twiddle, fb, mel_range, bin_range = ctx.saved_tensors
+        ms = ctx.ms
+        mod = ms.stft_magnitude
+        b, t, frames = ctx.dims
+        gout = gout.contiguous().reshape(1)
+        dframes = torch.empty(b, frames, mod.win_length, device=x.device, dtype=torch.float32)
+        dx = torch.empty(b, t, device=x.device, dtype=torch.float32)
+        ip = lambda z: ctypes.c_void_p(z.data_ptr())  # noqa: E731
+        _lib.check(_lib.lib().pwg_mel_fft_loss_backward(_ptr(x), _ptr(y), _ptr(window), _ptr(twiddle), _ptr(fb),
+                                                        ip(mel_range), ip(bin_range), b, t, mod.fft_size, mod.hop_size,
+                                                        mod.win_length, ms.num_mels, fb.shape[1], float(ms.eps),
+                                                        float(ms.log_div), _ptr(gout), _ptr(dframes), _ptr(dx), _stream()),
+                   "mel_fft_loss_backward")
         return dx, None, None

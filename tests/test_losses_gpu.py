@@ -223,3 +223,52 @@ def ops_profile():
     from parallelwavegan_amd import ops
 
     return ops.profile()
+
+
+@pytest.mark.parametrize("n_fft,hop,win,mels,log_base,b,t", [
+    (1024, 256, None, 80, None, 3, 8192),     # HiFi-GAN V1 LJSpeech mel loss (egs/ljspeech/voc1/conf/hifigan.v1.yaml)
+    (2048, 300, 1200, 80, None, 2, 8400),     # LibriTTS 24 kHz (egs/libritts/voc1/conf/hifigan.v1.yaml:100-102)
+    (512, 128, 400, 100, 10.0, 2, 2601),      # mel count off the 32-grid, log10, ragged length
+])
+def test_fft_mel_loss_matches_torch_stft_in_float64(n_fft, hop, win, mels, log_base, b, t, device):
+    """The FFT path of MelSpectrogramLoss (mel_fft_*_kernel) against losses/mel_loss.py:95-110 evaluated with torch.stft
+    and the module's own filterbank in float64: value 2e-5, gradient 2e-4 of its largest entry; bit-identical repeats."""
+    from tests.util import poison_empty, poison_lds
+
+    fs = 24000 if n_fft == 2048 else 22050
+    crit = losses.MelSpectrogramLoss(fs=fs, fft_size=n_fft, hop_size=hop, win_length=win, window="hann", num_mels=mels,
+                                     fmin=0, fmax=fs / 2, log_base=log_base).to(device)
+    # (seed: the plain n_fft + mels pair of the 2048-point case holds one (mel, frame) element whose two log-mels differ
+    # by 1.3e-7 -- there the sign of the L1 subgradient is decided by fp32 rounding, torch's own float32 gradient is 3 %
+    # of the maximum away from its float64 one; the test asserts below that the data is free of such near-ties)
+    seed = n_fft + mels + (10 if n_fft == 2048 else 0)
+    x = (0.4 * synth.synth_input("melx", (b, 1, t), seed=seed)).to(device).requires_grad_()
+    y = (0.4 * synth.synth_input("mely", (b, 1, t), seed=seed + 1)).to(device)
+    with poison_lds(), poison_empty(), ops_profile() as prof:
+        loss = crit(x, y)
+        loss.backward()
+    assert "mel_fft_fwd_kernel" in prof.results and "mel_fft_bwd_kernel" in prof.results, list(prof.results)
+    g = x.grad.clone()
+    x.grad = None
+    loss2 = crit(x, y)
+    loss2.backward()
+    assert torch.equal(loss, loss2) and torch.equal(g, x.grad)
+
+    ms = crit.mel_spectrogram
+    wl = ms.win_length
+    xd = x.detach().cpu().double().requires_grad_()
+    wdw = torch.hann_window(wl, dtype=torch.float64)
+    melmat = ms.melmat.cpu().double()  # (bins, mels)
+
+    def logmel(s):
+        sp = torch.stft(s.reshape(-1, s.size(-1)), n_fft, hop, wl, wdw, return_complex=True)
+        amp = torch.sqrt(torch.clamp(sp.real ** 2 + sp.imag ** 2, min=ms.eps)).transpose(2, 1)
+        mel = torch.clamp(torch.matmul(amp, melmat), min=ms.eps)
+        return torch.log(mel) / ms.log_div
+
+    lx, ly = logmel(xd), logmel(y.cpu().double())
+    assert float((lx - ly).abs().min()) > 2e-6  # no near-tie of the L1 term in this data (see the seed note)
+    ref = torch.nn.functional.l1_loss(lx, ly)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 2e-5 * ref.item(), (loss.item(), ref.item())
+    assert _rel(g.cpu().numpy(), xd.grad.numpy()) <= 2e-4
