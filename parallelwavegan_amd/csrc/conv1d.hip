@@ -681,6 +681,10 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(FinishArgs a) {
 // ---------------------------------------------------------------------------
 constexpr int SC_TILE = 1024;
 constexpr int SC_MAXW = 2048;  // cout * cin * k floats of weights in LDS
+// OPT = outputs per thread (tile = 256 * OPT samples).  Round 4: the launch is a serial walk over the input channels with two
+// barriers each, so few large tiles leave the chip idle -- PWG's last 64 -> 1 layer at B6 x 25600 was 150 workgroups and
+// 116 us for a 39 MB read; the host picks the largest OPT that still gives >= 1024 workgroups.
+template <int OPT>
 __global__ __launch_bounds__(256) void conv1d_small_cout_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                                 const float* __restrict__ bias, float* __restrict__ y,
                                                                 int cin, int cin_pad, int m_pad, int cout, int t_in,
@@ -691,16 +695,17 @@ __global__ __launch_bounds__(256) void conv1d_small_cout_kernel(const float* __r
   float* ws = sm;                      // [cout][cin][k]
   float* xs = sm + cout * cin * k;     // [SC_TILE + halo]
   const int b = blockIdx.y;
-  const int t0 = blockIdx.x * SC_TILE;
+  constexpr int TILE = 256 * OPT;
+  const int t0 = blockIdx.x * TILE;
   const int halo = (k - 1) * dil;
-  const int L = SC_TILE + halo;
+  const int L = TILE + halo;
   for (int i = threadIdx.x; i < cout * cin * k; i += 256) {  // from the packed image [tap][ci][m]
     const int tap = i % k, ci = (i / k) % cin, c = i / (k * cin);
     ws[i] = wp[((long)tap * cin_pad + ci) * m_pad + c];
   }
-  float acc[4][4];
+  float acc[OPT][4];
 #pragma unroll
-  for (int o = 0; o < 4; ++o)
+  for (int o = 0; o < OPT; ++o)
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[o][c] = 0.f;
   const float* xb = x + (long)b * cin * t_in;
@@ -717,15 +722,15 @@ __global__ __launch_bounds__(256) void conv1d_small_cout_kernel(const float* __r
     }
     __syncthreads();
     for (int tap = 0; tap < k; ++tap) {
-      float xv[4];
+      float xv[OPT];
 #pragma unroll
-      for (int o = 0; o < 4; ++o) xv[o] = xs[threadIdx.x + 256 * o + tap * dil];
+      for (int o = 0; o < OPT; ++o) xv[o] = xs[threadIdx.x + 256 * o + tap * dil];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         if (c < cout) {
           const float wv = ws[(c * cin + ci) * k + tap];
 #pragma unroll
-          for (int o = 0; o < 4; ++o) acc[o][c] = __builtin_fmaf(wv, xv[o], acc[o][c]);
+          for (int o = 0; o < OPT; ++o) acc[o][c] = __builtin_fmaf(wv, xv[o], acc[o][c]);
         }
       }
     }
@@ -735,7 +740,7 @@ __global__ __launch_bounds__(256) void conv1d_small_cout_kernel(const float* __r
     if (c < cout) {
       const float bv = bias ? bias[c] : 0.f;
 #pragma unroll
-      for (int o = 0; o < 4; ++o) {
+      for (int o = 0; o < OPT; ++o) {
         const int t = t0 + threadIdx.x + 256 * o;
         if (t < t_out) {
           float v = acc[o][c] + bv;
@@ -1555,11 +1560,16 @@ extern "C" int pwg_conv1d_forward(const pwg_conv1d_desc* d_in, const float* x, c
     rc = fill_args(d, g, x, w_packed, bias, add1, add2, y, &chk);
     if (rc != PWG_OK) return rc;
     // few output channels over a long sequence: streaming VALU kernel (see conv1d_small_cout_kernel)
-    const size_t lds = ((size_t)d->c_out * d->c_in * d->kernel + SC_TILE + (d->kernel - 1) * d->dilation) * sizeof(float);
+    int opt = 4;
+    while (opt > 1 && (long)ceil_div(d->t_out, 256 * opt) * d->batch < 1024) opt >>= 1;
+    const int tile = 256 * opt;
+    const size_t lds = ((size_t)d->c_out * d->c_in * d->kernel + tile + (d->kernel - 1) * d->dilation) * sizeof(float);
     const double out_elems = (double)d->batch * d->c_out * d->t_out;
     ProfScope prof((hipStream_t)stream, "conv1d_small_cout_kernel", 2.0 * out_elems * d->c_in * d->kernel,
                    4.0 * ((double)d->batch * d->c_in * d->t_in + out_elems));
-    hipLaunchKernelGGL(conv1d_small_cout_kernel, dim3(ceil_div(d->t_out, SC_TILE), d->batch), dim3(256), lds,
+    void (*sck)(const float*, const float*, const float*, float*, int, int, int, int, int, int, int, int, int, int, float, int,
+                float, float) = opt == 4 ? conv1d_small_cout_kernel<4> : (opt == 2 ? conv1d_small_cout_kernel<2> : conv1d_small_cout_kernel<1>);
+    hipLaunchKernelGGL(sck, dim3(ceil_div(d->t_out, tile), d->batch), dim3(256), lds,
                        (hipStream_t)stream, x, w_packed, bias, y, d->c_in, g.cin_pad, g.m_pad, d->c_out, d->t_in, d->t_out,
                        d->kernel, d->dilation, d->pad_left, d->pre_act, d->pre_slope, d->post_act, d->post_slope,
                        d->out_mul);

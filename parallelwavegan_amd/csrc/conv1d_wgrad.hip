@@ -528,6 +528,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_wn_kernel(const float* __res
 // ---------------------------------------------------------------------------
 constexpr int SIW_TILE = 1024;
 constexpr int SIW_MAXK = 16;
+constexpr int SIW_CO_PER_WG = 16;  // output channels per workgroup (grid.z walks the channel groups): 4 per wave
 __global__ __launch_bounds__(256) void conv1d_small_cin_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                      float* __restrict__ slabs, long slab_stride, int cout,
                                                                      int t_in, int t_out, int k, int dil, int pad,
@@ -546,17 +547,25 @@ __global__ __launch_bounds__(256) void conv1d_small_cin_wgrad_kernel(const float
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = min(SIW_TILE, t_out - t0);
   float* slab = slabs + ((long)b * chunks_per_item + chunk) * slab_stride;
-  for (int co = wave; co < cout; co += 4) {
+  const int co_end = min(cout, ((int)blockIdx.z + 1) * SIW_CO_PER_WG);
+  for (int co = blockIdx.z * SIW_CO_PER_WG + wave; co < co_end; co += 4) {
     const float* g = dy + ((long)b * cout + co) * t_out + t0;
     float acc[SIW_MAXK], accb = 0.f;
 #pragma unroll
     for (int j = 0; j < SIW_MAXK; ++j) acc[j] = 0.f;
-    for (int t = lane; t < n; t += 64) {
-      const float v = g[t];
-      accb += v;
+    // four independent 256-B loads per wave in flight (the chunk is 1024 columns: 4 rounds at most)
+    for (int t = lane; t < n; t += 256) {
+      float v[4];
 #pragma unroll
-      for (int j = 0; j < SIW_MAXK; ++j)
-        if (j < k) acc[j] = __builtin_fmaf(v, xs[t + j * dil], acc[j]);
+      for (int u = 0; u < 4; ++u) v[u] = (t + 64 * u < n) ? g[t + 64 * u] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        accb += v[u];
+        const int tt = min(t + 64 * u, SIW_TILE - 1);  // (v = 0 past the end: any staged column will do)
+#pragma unroll
+        for (int j = 0; j < SIW_MAXK; ++j)
+          if (j < k) acc[j] = __builtin_fmaf(v[u], xs[tt + j * dil], acc[j]);
+      }
     }
 #pragma unroll
     for (int j = 0; j < SIW_MAXK; ++j)
@@ -892,7 +901,8 @@ static int backward_weight_impl(const pwg_conv1d_desc* d_in, const float* x, con
     PWG_REQUIRE(nslabs < (1L << 30), PWG_ERR_UNSUPPORTED, "conv1d_backward_weight: too many slabs");
     {
       ProfScope prof(stream, "conv1d_small_cin_wgrad_kernel", 2.0 * y_elems * d->kernel, 4.0 * ((double)x_elems + (double)y_elems));
-      hipLaunchKernelGGL(conv1d_small_cin_wgrad_kernel, dim3(ceil_div(d->t_out, SIW_TILE), d->batch), dim3(256),
+      hipLaunchKernelGGL(conv1d_small_cin_wgrad_kernel,
+                         dim3(ceil_div(d->t_out, SIW_TILE), d->batch, ceil_div(d->c_out, SIW_CO_PER_WG)), dim3(256),
                          (size_t)(SIW_TILE + (d->kernel - 1) * d->dilation) * sizeof(float), stream, x, dy, workspace,
                          slab_stride, d->c_out, d->t_in, d->t_out, d->kernel, d->dilation, d->pad_left,
                          ceil_div(d->t_out, SIW_TILE), slope, db ? 1 : 0);

@@ -23,6 +23,7 @@ from .. import ops
 class _ConvNd(torch.nn.Module):
     transposed = False
     width_mode = False  # True for the (k, 1) Conv2d: input is (B, C, H, W)
+    explicit_pad_min_elems = 1 << 20  # no-grad forward with reflect / replicate padding: see forward()
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
                  bias=True, output_padding=0, pad_mode="zero"):
@@ -253,6 +254,18 @@ class _ConvNd(torch.nn.Module):
                                        None if add1 is None else add1.reshape(b, self.out_channels, -1),
                                        None if add2 is None else add2.reshape(b, self.out_channels, -1))
                 return y.reshape(b, self.out_channels, desc.t_out, width)
+            if (self.pad_mode != "zero" and (self.padding > 0 or self.padding_right > 0) and not self.transposed
+                    and x.numel() >= self.explicit_pad_min_elems):
+                # Large inputs: pad explicitly (one streaming launch) and run the zero-padding LDS-DMA kernel -- what the
+                # training path does anyway.  The register-staged kernel that maps reflected indices itself runs at
+                # 33 - 41 TFLOP/s on MelGAN's residual stacks (96 channels, k = 3, B64 x T2048: 176 us) against 103 us
+                # for the DMA kernel + 25 us for the pad (profiles/r04_k1_sweep.txt, r04_b_train_shapes_c4.txt).
+                xp = Fn.pad1d(x, self.padding, self.padding_right, self.pad_mode)
+                t_out = self.out_length(x.shape[-1])
+                desc = ops.make_conv_desc(b, self.in_channels, self.out_channels, xp.shape[-1], t_out, self.kernel_size,
+                                          self.stride, self.dilation, 0, self.groups, transposed=False, **fused)
+                return ops.conv1d_forward(desc, xp, self.packed_weight(),
+                                          None if self.bias is None else self.bias.detach(), add1, add2)
             desc = self.make_desc(b, x.shape[-1], **fused)
             return ops.conv1d_forward(desc, x.contiguous(), self.packed_weight(),
                                       None if self.bias is None else self.bias.detach(), add1, add2)
