@@ -314,23 +314,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WM * WN >= 8 ? 1 : (WM * W
   const int f0 = (h0 * a.stride - a.pad) * W;
   const int L = ((h1 - h0) * a.stride + (a.k - 1) * a.dil + 1) * W;
   const int tap_step = a.dil * W;
-  // Tap pruning: tap j of output row h reads input row h*stride - pad + j*dil; a tap whose rows lie in the zero padding
-  // for EVERY row of this tile contributes exact zeros and is skipped (weights and MFMAs).  Interior tiles keep all taps;
-  // the k = 41 layers of the scale discriminators at T = 9 / 17 columns per item (pad 20) run 17 / 33 of their 41 taps.
-  int tap_lo = 0, tap_end = a.k;
-  {
-    const int num_lo = a.pad - h1 * a.stride;
-    if (num_lo > 0) tap_lo = (num_lo + a.dil - 1) / a.dil;
-    const int num_hi = a.t_in - 1 + a.pad - h0 * a.stride;
-    const int hi = num_hi < 0 ? -1 : num_hi / a.dil;
-    if (hi + 1 < tap_end) tap_end = hi + 1;
-    if (tap_lo > tap_end) tap_lo = tap_end;
-    if (a.dbg & 32) {  // (PWG_DBG bit 32: no pruning, for the A/B)
-      tap_lo = 0;
-      tap_end = a.k;
-    }
-  }
-
   int coff[WN];
 #pragma unroll
   for (int ni = 0; ni < WN; ++ni) {
@@ -397,8 +380,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WM * WN >= 8 ? 1 : (WM * W
       const int rr = p * ROWS_PER_PIECE + w_row_in_piece;
       const int tap = rr / CK;
       const int r = rr - tap * CK;
-      const int ptap = (p * ROWS_PER_PIECE) / CK;  // (a piece never straddles taps: CK % ROWS_PER_PIECE == 0)
-      if (ptap < tap_lo || ptap >= tap_end) continue;
       const float* src = wg + ((long)tap * a.cin_pad + ci0 + r) * a.m_pad + w_col;
       __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(ws + p * 256), 16, 0, 0);
     }
@@ -455,15 +436,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WM * WN >= 8 ? 1 : (WM * W
       }
     };
     float a0[KS][WM], b0[KS][WN], a1[KS][WM], b1[KS][WN];
-    if (tap_lo < tap_end) load_ops(tap_lo, a0, b0);
-    int tap = tap_lo;
-    for (; tap + 2 <= tap_end; tap += 2) {
+    load_ops(0, a0, b0);
+    int tap = 0;
+    for (; tap + 2 <= a.k; tap += 2) {
       load_ops(tap + 1, a1, b1);
       mma(a0, b0);
-      if (tap + 2 < tap_end) load_ops(tap + 2, a0, b0);
+      if (tap + 2 < a.k) load_ops(tap + 2, a0, b0);
       mma(a1, b1);
     }
-    if (tap < tap_end) mma(a0, b0);
+    if (tap < a.k) mma(a0, b0);
   }
 
   if (a.dbg & 4) {
@@ -906,9 +887,11 @@ struct BankRows {   // one per weight-normalised layer
 struct BankImage {  // one per packed image
   PackArgs a;
   int block0;       // first workgroup of this image in the pack launch
-  int pad_;
+  int col_tiles;    // > 0: plain convolution, 64 x 64 LDS transposition tiles, this many per row block;
+                    // < 0: polyphase image, -col_tiles chunks per input-channel row; 0: element-wise packing
 };
 constexpr int BANK_ELEMS_PER_BLOCK = 2048;
+constexpr int BANK_TT = 64;  // transposition tile
 
 // last table entry whose `first` field (row0 / block0) is <= id  (entries are sorted by it, the first is 0)
 template <typename T, typename F>
@@ -943,9 +926,74 @@ __global__ __launch_bounds__(256) void bank_scale_kernel(const BankRows* __restr
   }
 }
 
+// Plain convolutions: the torch layout (co, ci, tap) has the contraction index fastest, the packed image the output
+// channel.  Element-wise packing reads one 4-byte word per 64-byte sector (PMC, round 4: 1.7 GB fetched per launch for
+// 0.26 GB written on the HiFi-GAN discriminator, profiles/r04_train_pmc_summary.json).  A 64 x 64 tile through LDS reads
+// rows of 256 B and writes runs of 64 output channels; the zero padding of the image (ci >= cin_g, m >= m_g) is never
+// touched -- the bank zero-fills its persistent buffers once.
+__device__ __forceinline__ void bank_pack_tile(const PackArgs& a, int tile, int col_tiles) {
+  __shared__ float t[BANK_TT][BANK_TT + 1];
+  const int inner = a.cin_g * a.kernel;           // floats per output channel
+  const int n0 = a.groups * a.cout_g;             // output channels
+  const int r0 = (tile / col_tiles) * BANK_TT, c0 = (tile % col_tiles) * BANK_TT;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < BANK_TT; r += 4) {
+    const int co = r0 + r, c = c0 + tx;
+    float v = 0.f;
+    if (co < n0 && c < inner) {
+      v = a.w[(long)co * inner + c];
+      if (a.scale) v *= a.scale[co];
+    }
+    t[r][tx] = v;
+  }
+  __syncthreads();
+  const int co = r0 + tx;
+  if (co < n0) {
+    const int g = co / a.cout_g, m = co - g * a.cout_g;
+    for (int cc = ty; cc < BANK_TT; cc += 4) {
+      const int c = c0 + cc;
+      if (c < inner) {
+        const int ci = c / a.kernel, tap = c - ci * a.kernel;
+        a.wp[(((long)g * a.k_phase + tap) * a.cin_pad + ci) * a.m_pad + m] = t[tx][cc];
+      }
+    }
+  }
+}
+
+// Polyphase (transposed-convolution) images -- the data-gradient image of every plain convolution: the torch layout is
+// (cig, co, kk) with the tap fastest, the image wants runs of co for a fixed (cig, kk).  One workgroup stages
+// floor(1024 / kernel) channels x kernel taps of one input-channel row (a contiguous read) and writes one run per tap.
+constexpr int BANK_CHUNK = 1024;
+__device__ __forceinline__ void bank_pack_row_chunk(const PackArgs& a, int blk, int chunks) {
+  __shared__ float t[BANK_CHUNK];
+  const int cig = blk / chunks, chunk = blk - cig * chunks;
+  const int co_per = BANK_CHUNK / a.kernel;
+  const int co0 = chunk * co_per;
+  const int nco = min(co_per, a.cout_g - co0);
+  const int nel = nco * a.kernel;
+  const float sc = a.scale ? a.scale[cig] : 1.f;
+  const float* src = a.w + ((long)cig * a.cout_g + co0) * a.kernel;
+  for (int e = threadIdx.x; e < nel; e += 256) t[e] = src[e] * sc;
+  __syncthreads();
+  const int g = cig / a.cin_g, ci = cig - g * a.cin_g;
+  for (int e = threadIdx.x; e < nel; e += 256) {
+    const int kk = e / nco, j = e - kk * nco;  // tap-major over the chunk: consecutive threads, consecutive channels
+    const int phase = kk % a.stride, tap = a.k_phase - 1 - kk / a.stride;
+    a.wp[(((long)g * a.k_phase + tap) * a.cin_pad + ci) * a.m_pad + phase * a.cout_g + co0 + j] = t[j * a.kernel + kk];
+  }
+}
+
 __global__ __launch_bounds__(256) void bank_pack_kernel(const BankImage* __restrict__ tab, int n) {
   const int ii = bank_find(tab, n, (int)blockIdx.x, [](const BankImage& e) { return e.block0; });
   const PackArgs a = tab[ii].a;
+  if (tab[ii].col_tiles > 0) {  // (uniform per workgroup)
+    bank_pack_tile(a, (int)blockIdx.x - tab[ii].block0, tab[ii].col_tiles);
+    return;
+  }
+  if (tab[ii].col_tiles < 0) {
+    bank_pack_row_chunk(a, (int)blockIdx.x - tab[ii].block0, -tab[ii].col_tiles);
+    return;
+  }
   const long total = (long)a.groups * a.k_phase * a.cin_pad * a.m_pad;
   const long base = (long)((int)blockIdx.x - tab[ii].block0) * BANK_ELEMS_PER_BLOCK;
 #pragma unroll 2
@@ -1760,9 +1808,21 @@ extern "C" int pwg_weight_bank_build(const pwg_bank_item* items, int32_t n_items
       BankImage& e = imgs[n_img];
       fill_pack_args(&d, g, it.w, it.g ? it.scale : nullptr, out, &e.a);
       e.block0 = block0;
-      e.pad_ = 0;
-      const long total = (long)e.a.groups * e.a.k_phase * e.a.cin_pad * e.a.m_pad;
-      block0 += (int)((total + BANK_ELEMS_PER_BLOCK - 1) / BANK_ELEMS_PER_BLOCK);
+      e.col_tiles = 0;
+      // (the caller zero-fills the image buffers once: the tiled forms write the real elements only)
+      static const bool tiled = !(getenv("PWG_BANK_TILED") && atoi(getenv("PWG_BANK_TILED")) == 0);
+      if (d.transposed && tiled && e.a.kernel <= BANK_CHUNK / 4) {
+        // polyphase image: one workgroup per (input-channel row, chunk of floor(1024 / k) output channels)
+        const int chunks = ceil_div(e.a.cout_g, BANK_CHUNK / e.a.kernel);
+        e.col_tiles = -chunks;
+        block0 += e.a.groups * e.a.cin_g * chunks;
+      } else if (!d.transposed && tiled) {
+        e.col_tiles = ceil_div(e.a.cin_g * e.a.kernel, BANK_TT);
+        block0 += ceil_div(e.a.groups * e.a.cout_g, BANK_TT) * e.col_tiles;
+      } else {
+        const long total = (long)e.a.groups * e.a.k_phase * e.a.cin_pad * e.a.m_pad;
+        block0 += (int)((total + BANK_ELEMS_PER_BLOCK - 1) / BANK_ELEMS_PER_BLOCK);
+      }
       ++n_img;
     }
     if (pass == 0) {

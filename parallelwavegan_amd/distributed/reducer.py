@@ -95,6 +95,17 @@ class GradReducer:
         self.flat_grads = {p: b.views[p] for b in self.buckets for p in b.params}
         self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in params]
         self.enabled = True
+        # Weight-gradient kernels write into the bucket slots directly (ops.claim_grad_slot) -- apex flattens in place
+        # too (reference bin/train.py:1494-1503): the hook then has nothing to copy.  One claim per parameter and
+        # backward pass (``epoch``).  PWG_DDP_DIRECT=0: every gradient goes through a hook copy as in round 3.
+        self.direct_slots = os.environ.get("PWG_DDP_DIRECT", "1") == "1"
+        self.epoch = 0
+        self.copies = 0  # hook copies since construction (bench / tests: how many gradients did NOT arrive in place)
+        from .. import ops
+
+        for p in params:
+            if p.is_cuda:
+                ops.GRAD_SLOTS[p.data_ptr()] = [self.flat_grads[p], self, -1]
         self.defer = False  # True: hooks only fill the buckets (hipGraph capture / replay); the caller exchanges
         self.skip_comm = False  # measurement aid: run the step without its collectives (bench: exposed time)
         # test aid: issue the collectives even in a world of one (exercises RCCL init, its stream semantics and
@@ -118,6 +129,7 @@ class GradReducer:
             b.events = []
             b.flat.zero_()  # parameters that receive no gradient this step contribute exactly 0
         self._next = 0
+        self.epoch += 1  # every slot may be claimed once in the coming backward pass
 
     def begin_replay(self):
         """Host bookkeeping of :meth:`prepare` for a step whose kernels (incl. the bucket zero-fill and
@@ -132,7 +144,9 @@ class GradReducer:
         if not self.enabled:
             return
         b = self.bucket_of[p]
-        b.views[p].copy_(p.grad)
+        if p.grad.data_ptr() != b.views[p].data_ptr():  # (else: the kernel wrote the slot itself, see direct_slots)
+            b.views[p].copy_(p.grad)
+            self.copies += 1
         p.grad = None  # the bucket slot now owns this gradient
         if not self.defer and b.flat.is_cuda:
             # autograd runs this hook on the stream of the node that produced the gradient; with the
@@ -197,5 +211,11 @@ class GradReducer:
         return 1.0 / self.world
 
     def remove(self):
+        from .. import ops
+
         for h in self._handles:
             h.remove()
+        for p in self.params:
+            e = ops.GRAD_SLOTS.get(p.data_ptr()) if p.is_cuda else None
+            if e is not None and e[1] is self:
+                del ops.GRAD_SLOTS[p.data_ptr()]

@@ -175,6 +175,9 @@ class FusedConvFn(torch.autograd.Function):
         ctx.x_shape = tuple(x.shape)
         ctx.holder = holder
         ctx.has_g = g is not None
+        # addresses of the parameters whose gradients this node produces (data-parallel gradient slots, ops.GRAD_SLOTS)
+        ctx.slot_keys = (w.data_ptr(), None if bias is None else bias.data_ptr(), None if g is None else g.data_ptr()) \
+            if ops.GRAD_SLOTS else None
         need_y = fused.get("post_act") not in (None, "none")
         ctx.save_for_backward(x3, y if need_y else None, wc if g is not None else None,
                               _c(g) if g is not None else None)
@@ -204,19 +207,32 @@ class FusedConvFn(torch.autograd.Function):
         if need_x:
             dx = ops.conv1d_backward_data(desc, gsum, ctx.holder.bwd(desc), x3).reshape(ctx.x_shape)
         wn_row_bytes = 4 * (ctx.w_shape[1] * ctx.w_shape[2])
+        # data parallel: results go straight into the parameters' bucket slots where those are free (ops.claim_grad_slot)
+        out_w = out_b = out_g = None
+        if ctx.slot_keys is not None and ops.GRAD_SLOTS:
+            kw, kb, kg = ctx.slot_keys
+            if need_b and has_bias:
+                out_b = ops.claim_grad_slot(kb, (desc.c_out,))
+            if ctx.has_g and need_w and need_g:
+                out_w = ops.claim_grad_slot(kw, ctx.w_shape)
+                out_g = ops.claim_grad_slot(kg, tuple(g.reshape(-1).shape))
+            elif not ctx.has_g and need_w:
+                out_w = ops.claim_grad_slot(kw, ctx.w_shape)
         if ctx.has_g and (need_w or need_g) and wn_row_bytes + 256 <= 64 * 1024:
             # weight-normalised layer: slabs -> (dv, dg) in one fused finishing kernel
             dv, dg, db = ops.conv1d_backward_weight_wn(desc, x3, gsum, v, g.reshape(-1),
-                                                       need_db=need_b and has_bias)
+                                                       need_db=need_b and has_bias, out_dv=out_w, out_dg=out_g,
+                                                       out_db=out_b)
             dw = dv.reshape(ctx.w_orig_shape)
             dg = dg.reshape(g.shape)
         elif need_w or need_g or (need_b and has_bias):
             dw, db = ops.conv1d_backward_weight(desc, x3, gsum, ctx.w_shape, need_dw=need_w or need_g,
-                                                need_db=need_b and has_bias)
+                                                need_db=need_b and has_bias,
+                                                out_dw=None if ctx.has_g else out_w, out_db=out_b)
             if dw is not None and ctx.has_g:
                 # weight norm backward: (dv, dg) from the gradient w.r.t. the effective weight
-                dv = torch.empty_like(v)
-                dg = torch.empty_like(g)
+                dv = out_w if out_w is not None else torch.empty_like(v)
+                dg = out_g.view(g.shape) if out_g is not None else torch.empty_like(g)
                 n0 = v.shape[0]
                 _lib.check(_L().pwg_weight_norm_backward(_ptr(dw), _ptr(v), _ptr(g), _ptr(dv), _ptr(dg), n0,
                                                          v.numel() // n0, _stream()), "weight_norm_backward")

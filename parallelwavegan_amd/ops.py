@@ -35,6 +35,35 @@ def bump_params(params):
         p._pwg_epoch = getattr(p, "_pwg_epoch", 0) + 1
 
 
+# Data-parallel gradient slots (distributed.GradReducer): parameter storage address -> [bucket view, owner, claim
+# epoch].  A weight-gradient launch whose layer's parameter has a free slot writes its result straight into the
+# bucket: autograd's AccumulateGrad adopts the returned alias as ``p.grad`` without a copy and the reducer's hook finds
+# nothing left to copy.  A slot is claimed once per backward pass (the owner's epoch); later contributions of the same
+# pass -- the discriminator phase differentiates D(y) and D(G(c)) in one pass -- go to ordinary tensors and autograd
+# adds them up as before.
+GRAD_SLOTS = {}
+
+
+def claim_grad_slot(key, shape):
+    """A fresh alias (shape ``shape``) of the gradient slot registered for the parameter at address ``key`` -- once
+    per backward pass -- or None."""
+    e = GRAD_SLOTS.get(key)
+    if e is None:
+        return None
+    view, owner, claimed = e
+    if not owner.enabled or not owner.direct_slots or claimed == owner.epoch or view.numel() != _numel(shape):
+        return None
+    e[2] = owner.epoch
+    return view.view(shape)
+
+
+def _numel(shape):
+    n = 1
+    for d in shape:
+        n *= int(d)
+    return n
+
+
 def _require_device(*tensors):
     for t in tensors:
         if t is None:
@@ -280,11 +309,12 @@ def conv1d_backward_data(desc, dy, w_packed_bwd, x=None, accum=None, out=None):
     return out
 
 
-def conv1d_backward_weight(desc, x, dy, weight_shape, need_dw=True, need_db=True):
-    """(dw in torch layout, db); deterministic two-stage reduction over (batch, time) slices."""
-    _require_device(x, dy)
-    dw = torch.empty(weight_shape, device=x.device, dtype=torch.float32) if need_dw else None
-    db = torch.empty(desc.c_out, device=x.device, dtype=torch.float32) if need_db else None
+def conv1d_backward_weight(desc, x, dy, weight_shape, need_dw=True, need_db=True, out_dw=None, out_db=None):
+    """(dw in torch layout, db); deterministic two-stage reduction over (batch, time) slices.  ``out_dw`` / ``out_db``:
+    optional destinations (contiguous, the right number of elements), e.g. data-parallel bucket slots."""
+    _require_device(x, dy, out_dw, out_db)
+    dw = (out_dw if out_dw is not None else torch.empty(weight_shape, device=x.device, dtype=torch.float32)) if need_dw else None
+    db = (out_db if out_db is not None else torch.empty(desc.c_out, device=x.device, dtype=torch.float32)) if need_db else None
     ws, ws_n = None, 0
     if need_dw:
         ws_n = _lib.lib().pwg_conv1d_backward_weight_workspace_floats(ctypes.byref(desc))
@@ -295,13 +325,13 @@ def conv1d_backward_weight(desc, x, dy, weight_shape, need_dw=True, need_db=True
     return dw, db
 
 
-def conv1d_backward_weight_wn(desc, x, dy, v, g, need_db=True):
+def conv1d_backward_weight_wn(desc, x, dy, v, g, need_db=True, out_dv=None, out_dg=None, out_db=None):
     """(dv, dg, db) of a weight-normalised layer: weight-gradient kernel + ONE fused finishing kernel (slab sum
-    + weight-norm backward); ``v`` is weight_v in torch layout, ``g`` weight_g."""
-    _require_device(x, dy, v, g)
-    dv = torch.empty_like(v)
-    dg = torch.empty_like(g)
-    db = torch.empty(desc.c_out, device=x.device, dtype=torch.float32) if need_db else None
+    + weight-norm backward); ``v`` is weight_v in torch layout, ``g`` weight_g.  ``out_*``: optional destinations."""
+    _require_device(x, dy, v, g, out_dv, out_dg, out_db)
+    dv = out_dv if out_dv is not None else torch.empty_like(v)
+    dg = out_dg if out_dg is not None else torch.empty_like(g)
+    db = (out_db if out_db is not None else torch.empty(desc.c_out, device=x.device, dtype=torch.float32)) if need_db else None
     ws_n = _lib.lib().pwg_conv1d_backward_weight_wn_workspace_floats(ctypes.byref(desc))
     ws = torch.empty(max(ws_n, 1), device=x.device, dtype=torch.float32)
     _lib.check(_lib.lib().pwg_conv1d_backward_weight_wn(ctypes.byref(desc), _ptr(x), _ptr(dy), _ptr(v), _ptr(g), _ptr(dv),

@@ -59,9 +59,11 @@ class WeightBank:
             fwd = bwd = None
             if getattr(m, "bank_images", True):  # (False: layers that normally run inside a fused multi-layer kernel
                 # -- the WaveNet block's four convolutions -- get their row scale here and pack lazily if ever needed)
-                fwd = torch.empty(ops.packed_weight_floats(desc), device=dev, dtype=torch.float32)
+                # zero-filled ONCE: the packing launch writes the real elements only, the padding of an image
+                # (channels up to a multiple of 16, rows up to a multiple of 128, unused polyphase taps) stays zero
+                fwd = torch.zeros(ops.packed_weight_floats(desc), device=dev, dtype=torch.float32)
                 n_bwd = _lib.lib().pwg_conv1d_packed_weight_bwd_floats(ctypes.byref(desc))
-                bwd = torch.empty(n_bwd, device=dev, dtype=torch.float32) if n_bwd else None
+                bwd = torch.zeros(n_bwd, device=dev, dtype=torch.float32) if n_bwd else None
             it.w, it.desc = w3.data_ptr(), desc
             it.fwd = None if fwd is None else fwd.data_ptr()
             it.bwd = None if bwd is None else bwd.data_ptr()

@@ -43,9 +43,13 @@ def _worker(rank, world, port, use_graph, out_dir):
         assert n_groups == 3
         assert [k for _, k in entry["segments"]] == (
             [("generator", None)] + [("discriminator", gi) for gi in range(n_groups)] + [None])
+    # weight-gradient kernels write straight into the bucket slots (ops.claim_grad_slot): hook copies per step
+    copies = {k: r.copies / N_STEPS for k, r in tr.reducers.items()} if not use_graph else None
+    n_params = {k: len(r.params) for k, r in tr.reducers.items()}
     sums = {k: float(sum(p.double().sum().item() for p in model[k].parameters())) for k in model}
     absd = {k: float(sum(p.double().abs().sum().item() for p in model[k].parameters())) for k in model}
-    torch.save(dict(log=log, sums=sums, absd=absd), os.path.join(out_dir, f"r{rank}_g{int(use_graph)}.pt"))
+    torch.save(dict(log=log, sums=sums, absd=absd, copies=copies, n_params=n_params),
+               os.path.join(out_dir, f"r{rank}_g{int(use_graph)}.pt"))
     dist.destroy_process_group()
 
 
@@ -54,6 +58,11 @@ def test_segmented_graph_ddp_matches_eager_ddp():
     for i, use_graph in enumerate((False, True)):
         mp.spawn(_worker, args=(2, 29620 + i, use_graph, out), nprocs=2, join=True)
     res = {(r, g): torch.load(os.path.join(out, f"r{r}_g{g}.pt")) for r in (0, 1) for g in (0, 1)}
+    # every generator gradient arrives in its bucket slot without a copy; the discriminator phase differentiates D(y) and
+    # D(G(c)) in one pass, so autograd still sums the two contributions of a parameter and the hook copies that sum
+    cp, npar = res[(0, 0)]["copies"], res[(0, 0)]["n_params"]
+    print(f"[ddp] hook copies per step: {cp} of {npar} parameters")
+    assert cp["generator"] == 0 and cp["discriminator"] <= npar["discriminator"]
     for g in (0, 1):  # replicas stay in lock-step: identical parameters on both ranks
         for k in ("generator", "discriminator"):
             assert res[(0, g)]["sums"][k] == res[(1, g)]["sums"][k], (g, k)
