@@ -86,6 +86,22 @@ class Trainer(object):
                 # fewer weight-gradient slabs; measured +2.7 % on the HiFi-GAN V1 step).  Applied around every
                 # step (the hint is process-wide), see _train_step
                 self._concurrency_hint = float(os.environ.get("PWG_CONCURRENCY_HINT", config.get("conv_concurrency_hint", 0.5)))
+        # discriminators whose feature maps stay in pre-activation form inside a training step (HiFi-GAN MPD / MSD,
+        # MelGAN): needs a feature-matching loss that applies the activation itself (this package's; a foreign
+        # criterion gets the ordinary post-activation maps)
+        from ..losses.feat_match_loss import FeatureMatchLoss as _OwnFM
+
+        # Default: on for the MelGAN discriminators (C4 30.85 -> 30.53 ms), off for HiFi-GAN's: there the activation on the
+        # operand load of the 512 / 1024-channel layers costs more MFMA-loop time than the 143 removed activation-gradient
+        # launches give back (C3 49.0 -> 49.6 ms, C5 45.7 -> 46.5 ms, three alternating runs each,
+        # profiles/r04_deferred_activation_ab.txt).  Config key / PWG_DEFER_ACT=0|1 override.
+        from ..models.melgan import MelGANMultiScaleDiscriminator as _MelD
+
+        fm = criterion.get("feat_match") if hasattr(criterion, "get") else None
+        want = config.get("deferred_discriminator_activation", os.environ.get("PWG_DEFER_ACT"))
+        if want is None:
+            want = isinstance(self._module("discriminator"), _MelD)
+        self._defer_act = bool(want in (True, 1, "1")) and (fm is None or isinstance(fm, _OwnFM))
         # weight preparation of a whole model in two launches per parameter epoch (weight_bank.WeightBank)
         self._banks = {}
         if config.get("use_weight_bank", os.environ.get("PWG_WEIGHT_BANK", "1") == "1"):
@@ -372,6 +388,20 @@ class Trainer(object):
         return True
 
     def _train_step(self, batch):
+        """One optimisation step.  Around it the discriminator runs in deferred-activation form
+        (layers.activation.PreActivated: no activation-gradient launches in the backward pass); outside the step --
+        evaluation, user code -- its feature maps are the reference's post-activation tensors."""
+        if not self._defer_act:
+            return self._train_step_hinted(batch)
+        from ..layers.activation import set_deferred_activation
+
+        set_deferred_activation(self._module("discriminator"), True)
+        try:
+            return self._train_step_hinted(batch)
+        finally:
+            set_deferred_activation(self._module("discriminator"), False)
+
+    def _train_step_hinted(self, batch):
         if self._concurrency_hint != 1.0:
             from .. import _lib
 

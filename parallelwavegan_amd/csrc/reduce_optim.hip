@@ -5,7 +5,12 @@
 namespace pwg {
 
 enum { RED_ABS_DIFF = 0, RED_SQ_DIFF = 1, RED_SQ = 2, RED_SQ_DIFF_CONST = 3, RED_SUM = 4, RED_HINGE_REAL = 5,
-       RED_HINGE_FAKE = 6, RED_NUM_MODES = 7 };
+       RED_HINGE_FAKE = 6,
+       // |lrelu(a) - lrelu(b)| with slope c: the feature-matching term on feature maps kept in pre-activation form
+       // (layers/activation.py: PreActivated); d/da carries the activation's derivative, so no separate activation-
+       // gradient pass exists
+       RED_ABS_DIFF_LRELU = 7, RED_NUM_MODES = 8 };
+__device__ __forceinline__ float red_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 constexpr int RED_BLOCKS = 512;
 
 __device__ __forceinline__ float red_term(int mode, float a, float b, float c) {
@@ -16,6 +21,7 @@ __device__ __forceinline__ float red_term(int mode, float a, float b, float c) {
     case RED_SQ_DIFF_CONST: return (a - c) * (a - c);
     case RED_HINGE_REAL: return -fminf(a - 1.f, 0.f);   // -min(x - 1, 0)   (adversarial_loss.py:119-120)
     case RED_HINGE_FAKE: return -fminf(-a - 1.f, 0.f);  // -min(-x - 1, 0)  (adversarial_loss.py:122-123)
+    case RED_ABS_DIFF_LRELU: return fabsf(red_lrelu(a, c) - red_lrelu(b, c));
     default: return a;
   }
 }
@@ -31,6 +37,10 @@ __device__ __forceinline__ float red_dterm(int mode, float a, float b, float c) 
     case RED_SQ_DIFF_CONST: return 2.f * (a - c);
     case RED_HINGE_REAL: return a < 1.f ? -1.f : (a == 1.f ? -0.5f : 0.f);
     case RED_HINGE_FAKE: return a > -1.f ? 1.f : (a == -1.f ? 0.5f : 0.f);
+    case RED_ABS_DIFF_LRELU: {
+      const float d = red_lrelu(a, c) - red_lrelu(b, c);
+      return (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * (a > 0.f ? 1.f : c);
+    }
     default: return 1.f;
   }
 }
@@ -67,9 +77,10 @@ __global__ void reduce_backward_kernel(const float* a, const float* b, float c, 
                                        const float* gout, float* da, float* db) {
   const float gs = gout[0] * scale;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const float g = gs * red_dterm(mode, a[i], b ? b[i] : 0.f, c);
+    const float bv = b ? b[i] : 0.f;
+    const float g = gs * red_dterm(mode, a[i], bv, c);
     if (da) da[i] = g;
-    if (db) db[i] = -g;
+    if (db) db[i] = mode == RED_ABS_DIFF_LRELU ? gs * red_dterm(mode, bv, a[i], c) : -g;
   }
 }
 
@@ -123,9 +134,11 @@ __global__ void __launch_bounds__(256) multi_reduce_backward_kernel(const RedIte
   const long end = base + RED_CHUNK < it.n ? base + RED_CHUNK : it.n;
   const float gs = gout[it.slot] * it.scale;
   for (long i = base + threadIdx.x; i < end; i += 256) {
-    const float g = gs * red_dterm(it.mode, it.a[i], it.b ? it.b[i] : 0.f, it.c);
+    const float bv = it.b ? it.b[i] : 0.f;
+    const float g = gs * red_dterm(it.mode, it.a[i], bv, it.c);
     if (it.da) it.da[i] = g;
-    if (it.db) it.db[i] = -g;
+    // (diff modes: d/db = -d/da; the pre-activation form swaps the operands so that b's own derivative is used)
+    if (it.db) it.db[i] = it.mode == RED_ABS_DIFF_LRELU ? gs * red_dterm(it.mode, bv, it.a[i], it.c) : -g;
   }
 }
 
@@ -278,7 +291,8 @@ using namespace pwg;
 extern "C" int pwg_reduce_forward(const float* a, const float* b, float c, int64_t n, int32_t mode, float scale,
                                   float* out, float* workspace, void* stream_) {
   PWG_REQUIRE(a && out && workspace, PWG_ERR_NULL, "reduce_forward: NULL pointer");
-  PWG_REQUIRE((mode != RED_ABS_DIFF && mode != RED_SQ_DIFF) || b, PWG_ERR_NULL, "reduce_forward: mode needs b");
+  PWG_REQUIRE((mode != RED_ABS_DIFF && mode != RED_SQ_DIFF && mode != RED_ABS_DIFF_LRELU) || b, PWG_ERR_NULL,
+              "reduce_forward: mode needs b");
   PWG_REQUIRE(n > 0 && mode >= 0 && mode < RED_NUM_MODES, PWG_ERR_BAD_SHAPE, "reduce_forward: bad arguments");
   hipStream_t stream = (hipStream_t)stream_;
   long blocks = (n + 1023) / 1024;
@@ -384,7 +398,7 @@ static int red_build(const pwg_red_item* items, int32_t n_items, int32_t n_slots
     PWG_REQUIRE(it.a, PWG_ERR_NULL, "%s: item %d has no operand", what, i);
     PWG_REQUIRE(it.n > 0 && it.mode >= 0 && it.mode < RED_NUM_MODES && it.slot >= 0 && it.slot < n_slots,
                 PWG_ERR_BAD_SHAPE, "%s: item %d: bad n / mode / slot", what, i);
-    PWG_REQUIRE((it.mode != RED_ABS_DIFF && it.mode != RED_SQ_DIFF) || it.b, PWG_ERR_NULL,
+    PWG_REQUIRE((it.mode != RED_ABS_DIFF && it.mode != RED_SQ_DIFF && it.mode != RED_ABS_DIFF_LRELU) || it.b, PWG_ERR_NULL,
                 "%s: item %d: mode %d needs a second operand", what, i, it.mode);
     t->it[i] = it;
     t->chunk_start[i] = (int)chunks;

@@ -746,7 +746,8 @@ class LogClampFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------
 # loss reductions
 # ---------------------------------------------------------------------------------------------
-RED = {"abs_diff": 0, "sq_diff": 1, "sq": 2, "sq_diff_const": 3, "sum": 4, "hinge_real": 5, "hinge_fake": 6}
+RED = {"abs_diff": 0, "sq_diff": 1, "sq": 2, "sq_diff_const": 3, "sum": 4, "hinge_real": 5, "hinge_fake": 6,
+       "abs_diff_lrelu": 7}  # (7: |lrelu(a) - lrelu(b)|, slope = const: feature maps in pre-activation form)
 
 
 class ReduceFn(torch.autograd.Function):

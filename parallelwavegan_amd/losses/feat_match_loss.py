@@ -26,14 +26,24 @@ class FeatureMatchLoss(torch.nn.Module):
         for maps_hat, maps in zip(feats_hat, feats):
             n_maps = min(len(maps_hat), len(maps)) - drop_last
             w = disc_w / n_maps if self.average_by_layers else disc_w
-            out.extend((maps_hat[k], maps[k], w) for k in range(n_maps))
+            # deferred-activation form (layers.activation.PreActivated): every map but the last (the logits) is the
+            # convolution output BEFORE its LeakyReLU; the reduction kernel applies it to both operands
+            s_hat, s = getattr(maps_hat, "preact_slope", None), getattr(maps, "preact_slope", None)
+            if s_hat != s:
+                raise ValueError("feature maps and targets must both be in (or both out of) pre-activation form")
+            for k in range(n_maps):
+                pre = s_hat if (s_hat is not None and k < len(maps_hat) - 1) else None
+                out.append((maps_hat[k], maps[k], w, pre))
         return out
 
     def forward(self, feats_hat, feats):
         """feats_hat / feats: list (discriminators) of lists (layers) of tensors; the targets ``feats``
         are treated as constants (the reference detaches them)."""
         spec, tensors = [], []
-        for f_hat, f, w in self.weighted_pairs(feats_hat, feats):
-            spec.append(("abs_diff", w / f_hat.numel(), 0.0, 0))
+        for f_hat, f, w, pre in self.weighted_pairs(feats_hat, feats):
+            if pre is None:
+                spec.append(("abs_diff", w / f_hat.numel(), 0.0, 0))
+            else:
+                spec.append(("abs_diff_lrelu", w / f_hat.numel(), pre, 0))
             tensors += [f_hat, f.detach()]
         return Fn.MultiReduceFn.apply(spec, 1, *tensors)[0]

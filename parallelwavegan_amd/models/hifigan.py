@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from .. import functional as Fn
-from ..layers.activation import FusedActivation
+from ..layers.activation import FusedActivation, PreActivated, deferrable
 from ..layers.causal_conv import CausalConv1d, CausalConvTranspose1d
 from ..layers.conv import Conv1d, Conv2d, ConvTranspose1d
 from ..layers.pooling import get_pooling
@@ -212,6 +212,17 @@ class HiFiGANPeriodDiscriminator(torch.nn.Module):
             t += n_pad
         x = x.reshape(b, c, t // self.period, self.period)
         outs = []
+        acts = [layer[1] for layer in self.convs]
+        if self.deferred_activation and deferrable(acts):
+            # deferred form (layers.activation.PreActivated): every LeakyReLU rides on the NEXT convolution's operand load
+            slope, pre = acts[0].slope, None
+            for layer in self.convs:
+                x = layer[0](x, pre_act=pre, pre_slope=slope)
+                pre = "leaky_relu"
+                outs.append(x)
+            x = self.output_conv(x, pre_act=pre, pre_slope=slope)
+            outs.append(torch.flatten(x, 1, -1))
+            return PreActivated(outs, slope)
         for layer in self.convs:
             conv, act = layer[0], layer[1]
             x = conv(x, post_act=act.kind, post_slope=act.slope)
@@ -219,6 +230,8 @@ class HiFiGANPeriodDiscriminator(torch.nn.Module):
         x = self.output_conv(x)
         outs.append(torch.flatten(x, 1, -1))
         return outs
+
+    deferred_activation = False  # set by the trainer (layers.activation.set_deferred_activation)
 
     def apply_weight_norm(self):
         for m in self.modules():
@@ -300,6 +313,16 @@ class HiFiGANScaleDiscriminator(torch.nn.Module):
 
     def forward(self, x):
         outs = []
+        acts = [f[1] for f in self.layers if isinstance(f, torch.nn.Sequential)]
+        if (self.deferred_activation and deferrable(acts) and isinstance(self.layers[0], torch.nn.Sequential)
+                and all(isinstance(f, torch.nn.Sequential) for f in self.layers[:-1])):
+            slope, pre = acts[0].slope, None
+            for f in self.layers:
+                conv = f[0] if isinstance(f, torch.nn.Sequential) else f
+                x = conv(x, pre_act=pre, pre_slope=slope)
+                pre = "leaky_relu"
+                outs.append(x)
+            return PreActivated(outs, slope)
         for f in self.layers:
             if isinstance(f, torch.nn.Sequential):
                 conv, act = f[0], f[1]
@@ -308,6 +331,8 @@ class HiFiGANScaleDiscriminator(torch.nn.Module):
                 x = f(x)
             outs.append(x)
         return outs
+
+    deferred_activation = False  # set by the trainer (layers.activation.set_deferred_activation)
 
     def _convs(self):
         return [m for m in self.modules() if isinstance(m, Conv1d)]

@@ -5,7 +5,7 @@ import logging
 import numpy as np
 import torch
 
-from ..layers.activation import FusedActivation
+from ..layers.activation import FusedActivation, PreActivated, deferrable
 from ..layers.causal_conv import CausalConv1d, CausalConvTranspose1d
 from ..layers.conv import Conv1d, ConvTranspose1d
 from ..layers.padding import FusedPad, get_pad
@@ -164,6 +164,17 @@ class MelGANDiscriminator(torch.nn.Module):
 
     def forward(self, x):
         outs = []
+        seqs = [f for f in self.layers if isinstance(f, torch.nn.Sequential)]
+        acts = [[m for m in f if isinstance(m, FusedActivation)][0] for f in seqs]
+        if self.deferred_activation and deferrable(acts) and len(seqs) == len(self.layers) - 1:
+            # deferred form (layers.activation.PreActivated): every LeakyReLU rides on the NEXT convolution's operand load
+            slope, pre = acts[0].slope, None
+            for f in self.layers:
+                conv = [m for m in f if isinstance(m, Conv1d)][0] if isinstance(f, torch.nn.Sequential) else f
+                x = conv(x, pre_act=pre, pre_slope=slope)
+                pre = "leaky_relu"
+                outs.append(x)
+            return PreActivated(outs, slope)
         for f in self.layers:
             if isinstance(f, torch.nn.Sequential):
                 conv = [m for m in f if isinstance(m, Conv1d)][0]
@@ -173,6 +184,8 @@ class MelGANDiscriminator(torch.nn.Module):
                 x = f(x)
             outs.append(x)
         return outs
+
+    deferred_activation = False  # set by the trainer (layers.activation.set_deferred_activation)
 
     def reset_parameters(self):
         for m in _convs(self):
