@@ -920,6 +920,7 @@ static bool wavenet_ok(const pwg_wavenet_desc* d) {
   if (!d) return false;
   if (d->residual_channels != WN_R || d->gate_channels != WN_G || d->skip_channels != WN_S || d->kernel != WN_K) return false;
   if (d->aux_channels != 80) return false;  // (the one instantiation; other widths: template + a case below)
+  if (d->causal) return false;              // (the fused kernels pad symmetrically; causal layers keep the un-fused path)
   if (d->batch < 1 || d->batch > 65535 || d->t < 1 || d->dilation < 1) return false;
   if ((long)WN_G * d->t * 4 >= (1L << 32)) return false;
   return true;

@@ -209,15 +209,21 @@ class FusedConvFn(torch.autograd.Function):
         wn_row_bytes = 4 * (ctx.w_shape[1] * ctx.w_shape[2])
         # data parallel: results go straight into the parameters' bucket slots where those are free (ops.claim_grad_slot)
         out_w = out_b = out_g = None
+        acc_w = acc_b = acc_g = None  # slots that already hold this pass's first contribution: add into them
         if ctx.slot_keys is not None and ops.GRAD_SLOTS:
             kw, kb, kg = ctx.slot_keys
             if need_b and has_bias:
-                out_b = ops.claim_grad_slot(kb, (desc.c_out,))
+                views, later = ops.claim_grad_slots([(kb, (desc.c_out,))])
+                if views is not None:
+                    out_b, acc_b = (None, views[0]) if later else (views[0], None)
             if ctx.has_g and need_w and need_g:
-                out_w = ops.claim_grad_slot(kw, ctx.w_shape)
-                out_g = ops.claim_grad_slot(kg, tuple(g.reshape(-1).shape))
+                views, later = ops.claim_grad_slots([(kw, ctx.w_shape), (kg, tuple(g.reshape(-1).shape))])
+                if views is not None:
+                    (out_w, out_g), (acc_w, acc_g) = ((None, None), views) if later else (views, (None, None))
             elif not ctx.has_g and need_w:
-                out_w = ops.claim_grad_slot(kw, ctx.w_shape)
+                views, later = ops.claim_grad_slots([(kw, ctx.w_shape)])
+                if views is not None:
+                    out_w, acc_w = (None, views[0]) if later else (views[0], None)
         if ctx.has_g and (need_w or need_g) and wn_row_bytes + 256 <= 64 * 1024:
             # weight-normalised layer: slabs -> (dv, dg) in one fused finishing kernel
             dv, dg, db = ops.conv1d_backward_weight_wn(desc, x3, gsum, v, g.reshape(-1),
@@ -239,6 +245,17 @@ class FusedConvFn(torch.autograd.Function):
                 dw = dv
             if dw is not None:
                 dw = dw.reshape(ctx.w_orig_shape)
+        # later contributions of a backward pass (the discriminator phase differentiates D(y) and D(G(c)) together):
+        # added into the bucket slot here; autograd gets None and has nothing to sum or copy
+        if acc_w is not None and dw is not None:
+            acc_w.add_(dw.reshape(acc_w.shape))
+            dw = None
+        if acc_g is not None and dg is not None:
+            acc_g.add_(dg.reshape(acc_g.shape))
+            dg = None
+        if acc_b is not None and db is not None:
+            acc_b.add_(db.reshape(acc_b.shape))
+            db = None
         gshape = dy.shape if desc.width == 1 else (desc.batch, desc.c_out, desc.t_out, desc.width)
         dadd1 = gsum.reshape(gshape) if has_add1 and ctx.needs_input_grad[3] else None
         dadd2 = gsum.reshape(gshape) if has_add2 and ctx.needs_input_grad[4] else None

@@ -119,9 +119,10 @@ class WaveNetResidualBlock(torch.nn.Module):
             return False
         return ops.wavenet_layer_supported(self.fused_desc(x.shape[0], x.shape[2]))
 
-    def forward(self, x, c, skips=None, skip_scale=1.0, chain_aux=False):
+    def forward(self, x, c, skips=None, skip_scale=1.0, chain_aux=False, inplace_skips=False):
         """Returns (x_out, skips + s) -- the running skip sum is an addend of the skip conv's epilogue
         (``skip_scale`` is the final ``sqrt(1/layers)`` of the generator, applied by the last block).
+        ``inplace_skips``: the no-grad fused path may write the new running sum into ``skips`` itself.
         ``chain_aux``: also return the aux features for the NEXT layer (the same values; on the one-launch autograd
         path an alias whose gradient is chained through the layers' data-gradient epilogues)."""
         if self._fusable(x, c):
@@ -136,7 +137,10 @@ class WaveNetResidualBlock(torch.nn.Module):
                 b_d, b_s, b_o = (None if cv.bias is None else cv.bias.detach() for cv in (convs[0], convs[2], convs[3]))
                 x_out, s_out, _, _ = ops.wavenet_layer_forward(self.fused_desc(x.shape[0], x.shape[2], skip_scale),
                                                                x.contiguous(), c.contiguous(), skips, self.fused_image(),
-                                                               b_d, b_s, b_o, skips_out=skips)
+                                                               b_d, b_s, b_o,
+                                                               # the running skip sum is updated in place only when the caller
+                                                               # owns that buffer and says so (the generator's own loop)
+                                                               skips_out=skips if inplace_skips else None)
                 return (x_out, s_out, c) if chain_aux else (x_out, s_out)
         aux = self.conv1x1_aux(c) if (c is not None and self.conv1x1_aux is not None) else None
         # F.dropout on the dilated conv's input only; the residual path keeps x (residual_block.py:114-116)

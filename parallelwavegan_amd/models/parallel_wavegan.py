@@ -96,7 +96,8 @@ class ParallelWaveGANGenerator(torch.nn.Module, _WeightNormMixin):
         for i, f in enumerate(self.conv_layers):
             # `skips += h` and the final `skips *= sqrt(1/n)` ride on the skip conv's epilogue
             # (c is handed from layer to layer so that its gradient is summed along that chain, see WaveNetLayerFn)
-            x, skips, c = f(x, c, skips=skips, skip_scale=math.sqrt(1.0 / n) if i == n - 1 else 1.0, chain_aux=True)
+            x, skips, c = f(x, c, skips=skips, skip_scale=math.sqrt(1.0 / n) if i == n - 1 else 1.0, chain_aux=True,
+                            inplace_skips=True)
         x = self.last_conv_layers[1](skips, pre_act="relu")
         return self.last_conv_layers[3](x, pre_act="relu")
 

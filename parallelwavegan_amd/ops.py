@@ -44,17 +44,26 @@ def bump_params(params):
 GRAD_SLOTS = {}
 
 
-def claim_grad_slot(key, shape):
-    """A fresh alias (shape ``shape``) of the gradient slot registered for the parameter at address ``key`` -- once
-    per backward pass -- or None."""
-    e = GRAD_SLOTS.get(key)
-    if e is None:
-        return None
-    view, owner, claimed = e
-    if not owner.enabled or not owner.direct_slots or claimed == owner.epoch or view.numel() != _numel(shape):
-        return None
-    e[2] = owner.epoch
-    return view.view(shape)
+def claim_grad_slots(keys_shapes):
+    """Claim the gradient slots of one layer's parameters together.  ``keys_shapes``: [(parameter address, shape)].
+    Returns ``(aliases, accumulate)`` or ``(None, False)`` when any of them has no slot (then nothing is claimed):
+    the FIRST claim of a backward pass gets ``accumulate = False`` -- the caller's kernels write the slots and the
+    aliases go back to autograd as the gradients; a later claim of the same pass gets ``accumulate = True`` -- the
+    caller adds its contribution INTO the slots (same stream, program order) and returns None to autograd, which then
+    neither sums nor copies anything."""
+    entries = []
+    for key, shape in keys_shapes:
+        e = GRAD_SLOTS.get(key)
+        if e is None or not e[1].enabled or not e[1].direct_slots or e[0].numel() != _numel(shape):
+            return None, False
+        entries.append((e, shape))
+    states = {e[2] == e[1].epoch for e, _ in entries}
+    if len(states) != 1:  # (cannot happen while a layer's parameters live in one reducer; stay on the copying path)
+        return None, False
+    later = states.pop()
+    for e, _ in entries:
+        e[2] = e[1].epoch
+    return [e[0].view(shape) for e, shape in entries], later
 
 
 def _numel(shape):

@@ -58,11 +58,13 @@ def test_segmented_graph_ddp_matches_eager_ddp():
     for i, use_graph in enumerate((False, True)):
         mp.spawn(_worker, args=(2, 29620 + i, use_graph, out), nprocs=2, join=True)
     res = {(r, g): torch.load(os.path.join(out, f"r{r}_g{g}.pt")) for r in (0, 1) for g in (0, 1)}
-    # every generator gradient arrives in its bucket slot without a copy; the discriminator phase differentiates D(y) and
-    # D(G(c)) in one pass, so autograd still sums the two contributions of a parameter and the hook copies that sum
+    # every generator gradient arrives in its bucket slot without a copy.  The discriminator phase differentiates D(y) and
+    # D(G(c)) in one pass: the first contribution of a parameter is written into the slot, the second added into it by
+    # its own node (ops.claim_grad_slots), autograd sees one gradient per parameter.  Only the spectral-norm weights of
+    # the first scale discriminator (their gradient is produced by SpectralNormFn, not by a convolution) are still copied.
     cp, npar = res[(0, 0)]["copies"], res[(0, 0)]["n_params"]
     print(f"[ddp] hook copies per step: {cp} of {npar} parameters")
-    assert cp["generator"] == 0 and cp["discriminator"] <= npar["discriminator"]
+    assert cp["generator"] == 0 and cp["discriminator"] <= 8
     for g in (0, 1):  # replicas stay in lock-step: identical parameters on both ranks
         for k in ("generator", "discriminator"):
             assert res[(0, g)]["sums"][k] == res[(1, g)]["sums"][k], (g, k)

@@ -77,13 +77,17 @@ def test_fused_layer_autograd_matches_unfused(dil, skip_scale, first, device):
             assert res[False][k] is None
             continue
         assert _rel(res[True][k], res[False][k]) <= 5e-5, (k, _rel(res[True][k], res[False][k]))
-    # inference path (no grad): same values, skip sum accumulated in place
+    # inference path (no grad): same values; the caller's skip tensor is left alone unless the caller hands the buffer
+    # over (``inplace_skips``, what the generator's own loop does) -- then the running sum is accumulated in place
     blk.fuse_layer = True
     with torch.no_grad():
         s_in = None if s0 is None else s0.clone()
         xo, so = blk(x0, c0, skips=s_in, skip_scale=skip_scale)
-    assert _rel(xo, res[False]["xo"]) <= 3e-5 and _rel(so, res[False]["so"]) <= 3e-5
-    assert s_in is None or so.data_ptr() == s_in.data_ptr()
+        assert s_in is None or (so.data_ptr() != s_in.data_ptr() and torch.equal(s_in, s0))
+        assert _rel(xo, res[False]["xo"]) <= 3e-5 and _rel(so, res[False]["so"]) <= 3e-5
+        xo2, so2 = blk(x0, c0, skips=s_in, skip_scale=skip_scale, inplace_skips=True)
+    assert torch.equal(xo2, xo) and torch.equal(so2, so)
+    assert s_in is None or so2.data_ptr() == s_in.data_ptr()
 
 
 @pytest.mark.parametrize("B,T,dil,with_go", [(3, 4133, 27, True), (1, 64, 1, True), (2, 9000, 512, False), (6, 25600, 4, True)])
