@@ -572,7 +572,51 @@ def uhifigan(name, seed):
     print(name, tuple(y.shape), float(y.abs().max()))
 
 
+def family_train_steps(name, family, seed, n_steps=2):
+    """Two ``Trainer._train_step`` calls of the unmodified reference for the families outside BASELINE's configs
+    ("their training is smoke only"): StyleMelGAN (TADE generator + random-window
+    discriminator: z from torch's CPU generator, window starts from numpy's -- both seeded right before the steps, and
+    drawn in the reference's call order) and UHiFiGAN (U-Net generator on (mel, f0, excitation) + the PWG discriminator).
+    Adam (lr 5e-4 / 1e-4, betas 0.5 / 0.9), multi-resolution STFT loss 256 / 512, mse adversarial losses."""
+    import parallel_wavegan.losses as RL
+    import parallel_wavegan.models as RM
+
+    if family == "style_melgan":
+        g = RM.StyleMelGANGenerator(**synth.STYLE_MELGAN_TRAIN)
+        d = RM.StyleMelGANDiscriminator(**synth.STYLE_MELGAN_TRAIN_D)
+        g.load_state_dict(synth.synth_state_dict(g.state_dict(), seed=seed, g_scale=1.1))
+        d.load_state_dict(synth.synth_state_dict(d.state_dict(), seed=seed + 1, g_scale=1.2, skip=synth.PQMF_BUFFERS),
+                          strict=False)
+        c = synth.synth_input("c", (2, 80, 16), seed=seed)
+        y = 0.3 * synth.synth_input("y", (2, 1, 16 * 256), seed=seed)
+        x, gtype = (c,), "StyleMelGANGenerator"
+    else:
+        g = RM.UHiFiGANGenerator(**synth.UHIFIGAN_TRAIN)
+        d = RM.ParallelWaveGANDiscriminator(layers=4, conv_channels=16)
+        g.load_state_dict(synth.synth_state_dict(g.state_dict(), seed=seed, g_scale=0.6))
+        d.load_state_dict(synth.synth_state_dict(d.state_dict(), seed=seed + 1, g_scale=1.4))
+        frames = 64
+        c = synth.synth_input("c", (2, 80, frames), seed=seed)
+        f0 = synth.synth_input("f0", (2, 1, frames), seed=seed).abs()
+        e = synth.synth_input("excitation", (2, 1, frames * 8), seed=seed)
+        y = 0.3 * synth.synth_input("y", (2, 1, frames * 8), seed=seed)
+        x, gtype = (c, f0, e), "UHiFiGANGenerator"
+    model = {"generator": g, "discriminator": d}
+    criterion = {"gen_adv": RL.GeneratorAdversarialLoss(), "dis_adv": RL.DiscriminatorAdversarialLoss(),
+                 "stft": RL.MultiResolutionSTFTLoss(**synth.FAMILY_TRAIN_STFT)}
+    optimizer = {k: torch.optim.Adam(model[k].parameters(), lr=synth.FAMILY_TRAIN_LR[k], betas=(0.5, 0.9)) for k in model}
+    scheduler = {k: torch.optim.lr_scheduler.StepLR(optimizer[k], step_size=10 ** 6, gamma=0.5) for k in model}
+    cfg = dict(synth.FAMILY_TRAIN_CFG, generator_type=gtype, generator_params={"out_channels": 1})
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    out = _run_reference_trainer(cfg, model, criterion, optimizer, scheduler, [(x, y)] * n_steps, 1)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), meta=np.array([n_steps, seed]), **out)
+    print(name, {k: round(float(v), 6) for k, v in out.items() if k.startswith("step")})
+
+
 JOBS = {
+    "style_melgan_train": lambda: family_train_steps("style_melgan_train", "style_melgan", 195),
+    "uhifigan_train": lambda: family_train_steps("uhifigan_train", "uhifigan", 197),
     "uhifigan": lambda: uhifigan("uhifigan", 97),
     "style_melgan": lambda: style_melgan("style_melgan", 95),
     "causal_variants": lambda: causal_variants("causal_variants", 91),

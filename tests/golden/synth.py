@@ -156,3 +156,14 @@ def adv_logits(seed):
         logit[0, 0, 0], logit[1, 0, 1] = 1.0, -1.0
         outs.append(fm + [logit])
     return outs
+
+
+# ---- training-step fixtures of the remaining families (round 4): shared by make_golden.py and the GPU test
+STYLE_MELGAN_TRAIN = dict(STYLE_MELGAN_TINY, noise_upsample_scales=[4, 4], upsample_scales=[4, 4, 4, 4])  # 16 frames per z
+STYLE_MELGAN_TRAIN_D = dict(repeats=1, window_sizes=[128, 256, 512, 1024])
+UHIFIGAN_TRAIN = dict(UHIFIGAN_TINY, dropout=0.0)  # (the dropout masks are pinned separately, tests/test_pwg_dropout_gpu.py)
+FAMILY_TRAIN_STFT = dict(fft_sizes=[256, 512], hop_sizes=[32, 64], win_lengths=[128, 256])
+FAMILY_TRAIN_CFG = dict(use_stft_loss=True, use_subband_stft_loss=False, use_mel_loss=False, use_feat_match_loss=False,
+                        lambda_aux=1.0, lambda_adv=1.0, generator_grad_norm=-1, discriminator_grad_norm=-1,
+                        generator_train_start_steps=0, discriminator_train_start_steps=0)
+FAMILY_TRAIN_LR = dict(generator=5e-4, discriminator=1e-4)

@@ -73,3 +73,55 @@ def test_uhifigan_training_steps(device):
     y = (0.3 * torch.randn(2, 1, frames * 8, generator=gen)).to(device)
     tr = _run(device, "UHiFiGANGenerator", g, d, ((c, f0, e), y), use_graph=True)
     assert len(tr._graphs) == 1  # dropout inside a captured step (device-resident mask seed)
+
+
+@pytest.mark.parametrize("family", ["style_melgan", "uhifigan"])
+def test_two_training_steps_match_the_reference_trainer(family, device):
+    """Two ``Trainer._train_step`` calls of the UNMODIFIED reference for StyleMelGAN and UHiFiGAN
+    (tests/golden/{style_melgan,uhifigan}_train.npz, made by tests/golden/make_golden.py: family_train_steps): every
+    logged loss of both steps, every parameter's first-moment norm and <first update, first moment>, the final
+    parameter sums.  StyleMelGAN's randomness is reproduced, not avoided: the generator draws z from torch's CPU
+    generator and the discriminator its window starts from numpy's, in the reference's call order, so seeding both
+    right before the steps gives the reference's own draws."""
+    from tests.test_pwg_mb_train_gpu import _run_and_compare
+    from tests.util import load_golden
+
+    gold = load_golden(f"{family}_train")
+    n_steps, seed = (int(v) for v in gold["meta"])
+    if family == "style_melgan":
+        g = models.StyleMelGANGenerator(**synth.STYLE_MELGAN_TRAIN)
+        d = models.StyleMelGANDiscriminator(**synth.STYLE_MELGAN_TRAIN_D)
+        g.load_state_dict(synth.synth_state_dict(g.state_dict(), seed=seed, g_scale=1.1))
+        d.load_state_dict(synth.synth_state_dict(d.state_dict(), seed=seed + 1, g_scale=1.2, skip=synth.PQMF_BUFFERS),
+                          strict=False)
+        c = synth.synth_input("c", (2, 80, 16), seed=seed)
+        y = 0.3 * synth.synth_input("y", (2, 1, 16 * 256), seed=seed)
+        x, gtype = (c,), "StyleMelGANGenerator"
+    else:
+        g = models.UHiFiGANGenerator(**synth.UHIFIGAN_TRAIN)
+        d = models.ParallelWaveGANDiscriminator(layers=4, conv_channels=16)
+        g.load_state_dict(synth.synth_state_dict(g.state_dict(), seed=seed, g_scale=0.6))
+        d.load_state_dict(synth.synth_state_dict(d.state_dict(), seed=seed + 1, g_scale=1.4))
+        frames = 64
+        c = synth.synth_input("c", (2, 80, frames), seed=seed)
+        f0 = synth.synth_input("f0", (2, 1, frames), seed=seed).abs()
+        e = synth.synth_input("excitation", (2, 1, frames * 8), seed=seed)
+        y = 0.3 * synth.synth_input("y", (2, 1, frames * 8), seed=seed)
+        x, gtype = (c, f0, e), "UHiFiGANGenerator"
+    model = {"generator": g.to(device), "discriminator": d.to(device)}
+    criterion = {"gen_adv": losses.GeneratorAdversarialLoss(), "dis_adv": losses.DiscriminatorAdversarialLoss(),
+                 "stft": losses.MultiResolutionSTFTLoss(**synth.FAMILY_TRAIN_STFT).to(device)}
+    opt = {k: optimizers.Adam(model[k].parameters(), lr=synth.FAMILY_TRAIN_LR[k], betas=(0.5, 0.9)) for k in model}
+    sched = {k: optimizers.lr_scheduler.StepLR(opt[k], step_size=10 ** 6, gamma=0.5) for k in model}
+    config = dict(synth.FAMILY_TRAIN_CFG, generator_type=gtype, generator_params={"out_channels": 1},
+                  train_max_steps=1 + n_steps, save_interval_steps=10 ** 9, eval_interval_steps=10 ** 9,
+                  log_interval_steps=10 ** 9, distributed=False, rank=0, outdir=tempfile.mkdtemp(), progress=False)
+    batches = [(x, y)] * n_steps
+    tr = Trainer(steps=1, epochs=0, data_loader={"train": batches, "dev": batches}, sampler={"train": None, "dev": None},
+                 model=model, criterion=criterion, optimizer=opt, scheduler=sched, config=config, device=device)
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    # (final parameter sums at 1e-2, as for multi-band MelGAN: Adam's first steps are +-lr by the SIGN of the gradient, which
+    # is rounding noise on the entries of small tensors whose gradient is ~0; the losses, first moments and <update, moment>
+    # above are held to 2e-4 / 3e-3 / 5e-3)
+    _run_and_compare(tr, batches, gold, model, opt, 0.1, final_rtol=1e-2)
