@@ -47,6 +47,13 @@ SC64 = {"train/spectral_convergence_loss": "sc64/full", "train/sub_spectral_conv
 # GOLDEN_THREADS=3 tests/golden/make_golden.py c4_train_full) give 0.035807 vs 0.035799 = 2.2e-4 apart; every other
 # value of that pair agrees to <= 7e-6.  Bar = 3x the reference's own spread.
 LOOSE = {("c4", "train/fake_loss"): 7e-4}
+# Per-tensor first-moment norms (= (1 - beta1) |gradient| after one step) and <first update, first moment>.  Round 4:
+# bars set per configuration at about 5x the measured deviation instead of one 3e-3 / 5e-3 for all ("would
+# not catch a 0.2 % wgrad error in one layer"): measured worst tensors C2 2.5e-5, C3 1.4e-4, C5 2.0e-4.  C4 keeps 3e-3:
+# its worst tensor (the generator's first convolution) is 2.7e-3 away, driven by the reference's own fp32
+# spectral-convergence accumulation (see SC_TOL above); its discriminator is at 6e-4.
+MOM_TOL = {"c2": 2e-4, "c3": 1e-3, "c5": 1e-3, "c4": 3e-3}
+UPD_TOL = {"c2": 3e-4, "c3": 8e-4, "c5": 8e-4, "c4": 8e-3}  # measured 4.6e-5 / 1.1e-4 / 1.5e-4 / 4.3e-3 (C4: as above)
 
 
 def _build(tag, gold, dev, **overrides):
@@ -108,12 +115,13 @@ def test_one_step_at_the_baseline_batch_shape_matches_the_reference(device, tag)
         assert np.isfinite(got).all(), (tag, key)
         rel = np.abs(got - want) / (np.abs(want) + 1e-3 * np.abs(want).max())
         print(f"[full-shape {tag}] {key}: worst first-moment norm {gn[int(rel.argmax())]} rel {rel.max():.2e}")
-        assert rel.max() <= 3e-3, (tag, key, gn[int(rel.argmax())], rel.max())
+        assert rel.max() <= MOM_TOL[tag], (tag, key, gn[int(rel.argmax())], rel.max())
         dots = {names[p]: float(((p.detach() - p0[key][names[p]]).double() * s["exp_avg"].double()).sum())
                 for p, s in opt[key].state.items()}
         got, want = np.array([dots[n] for n in gn]), gold[f"upddot/{key}"]
         rel = np.abs(got - want) / (np.abs(want) + 1e-3 * np.abs(want).max())
-        assert rel.max() <= 5e-3, (tag, key, "upddot", gn[int(rel.argmax())], rel.max())
+        print(f"[full-shape {tag}] {key}: worst <update, moment> {gn[int(rel.argmax())]} rel {rel.max():.2e}")
+        assert rel.max() <= UPD_TOL[tag], (tag, key, "upddot", gn[int(rel.argmax())], rel.max())
 
 
 @pytest.mark.parametrize("tag", ["c2", "c3", "c4", "c5"])
