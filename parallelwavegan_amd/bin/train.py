@@ -819,7 +819,8 @@ def main(argv=None):
     rank comes from ``--rank/--local_rank`` or ``LOCAL_RANK``, the process group is RCCL (``nccl`` backend; ``gloo`` when
     the ranks share a device or there is none), the training set is sharded by a ``DistributedSampler`` and gradients
     are averaged by ``GradReducer``.  Extra config keys of this engine: ``use_hip_graph`` (default true on a GPU),
-    ``device_collater`` (default true: corpus resident in HBM, one gather launch per batch), ``ddp_grad_groups``."""
+    ``device_collater`` (default true: corpus resident in HBM, one gather launch per batch; falls back to the host
+    DataLoader above ``device_collater_max_bytes``, default 64 GiB of dump files), ``ddp_grad_groups``."""
     import yaml
 
     from ..datasets import AudioMelDataset
@@ -889,7 +890,13 @@ def main(argv=None):
     use_noise_input = "ParallelWaveGAN" in gtype
     acw = config["generator_params"].get("aux_context_window", 0)
     hop = config.get("hop_size")
-    if config.get("remove_short_samples", True):
+    if config.get("remove_short_samples", True) or args.distributed:
+        # Data parallel: always filter at dataset level.  With per-batch dropping (``remove_short_samples: false``) the
+        # ranks could see different batch counts per epoch -- the next all-reduce would wait forever -- and different
+        # batch shapes (a graph capture per shape).
+        if args.distributed and not config.get("remove_short_samples", True):
+            logging.warning("remove_short_samples=false is overridden in distributed runs: every rank must see the same "
+                            "number of equally shaped batches")
         mel_length_threshold = config["batch_max_steps"] // hop + 2 * acw
     else:
         mel_length_threshold = None
@@ -908,7 +915,17 @@ def main(argv=None):
                    "dev": DistributedSampler(dataset["dev"], num_replicas=world_size, rank=rank, shuffle=False)}
     ckw = dict(batch_max_steps=config["batch_max_steps"], hop_size=hop, aux_context_window=acw,
                use_noise_input=use_noise_input)
-    if config.get("device_collater", True):
+    use_device_collater = config.get("device_collater", True)
+    if use_device_collater:
+        # the HBM-resident corpus is uploaded by EVERY rank: fall back to the host DataLoader when it would not fit
+        budget = int(config.get("device_collater_max_bytes", 64 << 30))
+        total = sum(os.path.getsize(f) for split in ("train", "dev")
+                    for f in set(dataset[split].audio_files) | set(dataset[split].mel_files))
+        if total > budget:
+            logging.warning(f"corpus of {total / 2 ** 30:.1f} GiB on disk exceeds device_collater_max_bytes "
+                            f"({budget / 2 ** 30:.1f} GiB): using the host DataLoader / Collater path")
+            use_device_collater = False
+    if use_device_collater:
         data_loader = {split: _DeviceBatches(DeviceCollater([dataset[split][i] for i in range(len(dataset[split]))],
                                                             device, **ckw),
                                              config["batch_size"], sampler[split], shuffle=not args.distributed)

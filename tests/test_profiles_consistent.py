@@ -44,3 +44,20 @@ def test_round3_traffic_summary_is_derived_from_the_committed_raw_counters(tmp_p
     assert abs(old["calibration"]["fetch_factor_used"] - 2.0) < 1e-3 and abs(old["calibration"]["write_factor_used"] - 1.0) < 1e-3
     conv = old["kernels"]["conv1d_mfma_dma_kernel"]
     assert conv["traffic_over_algorithmic"] < 1.3  # (XCD-aware tile order; 1.88 before it)
+
+
+def test_round4_traffic_summary_is_derived_from_the_committed_raw_counters(tmp_path):
+    """Round 4: the same passes (tools/pmc_round3.sh) re-run on the round's final kernels; bench.py cites this file first."""
+    out = tmp_path / "traffic.json"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_round3_summary.py"),
+                           os.path.join(ROOT, "profiles", "r04_pmc_hbm_raw.json"),
+                           os.path.join(ROOT, "profiles", "r04_pmc_infer_bench.json"), str(out)],
+                          stdout=subprocess.DEVNULL)
+    new = json.load(open(out))
+    old = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_hbm_traffic.json")))
+    for fam in ("conv1d_mfma_dma_kernel", "resunit_kernel"):
+        for key in ("hbm_bytes_per_launch", "algorithmic_bytes_per_launch"):
+            assert abs(new["kernels"][fam][key] - old["kernels"][fam][key]) <= 1e-9 * old["kernels"][fam][key]
+    assert abs(old["calibration"]["fetch_factor_used"] - 2.0) < 1e-3 and abs(old["calibration"]["write_factor_used"] - 1.0) < 1e-3
+    assert old["kernel"] == "conv1d_mfma_dma_kernel" and old["launches_per_forward"] == 47.0
+    assert old["kernels"]["conv1d_mfma_dma_kernel"]["traffic_over_algorithmic"] < 1.3
