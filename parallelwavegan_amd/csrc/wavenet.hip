@@ -672,31 +672,44 @@ __global__ void wavenet_pack_bwd_kernel(const float* w_dil, const float* s_dil, 
 //   [dW_skip ; dW_out | db]    = [gs; go] (128)  x  g (64 x T)^T
 //
 // As separate k = 1 / k = 3 launches of the general weight-gradient kernel they are LDS-DMA-issue bound (64 dword-DMA
-// instructions per 64 MFMAs: 34 - 38 TFLOP/s); here a workgroup (8 waves) stages BOTH operands of a 64-column chunk
+// instructions per 64 MFMAs: 34 - 38 TFLOP/s); here a workgroup (8 waves) stages BOTH operands of a 32-column chunk
 // through registers -- 16-B global loads, written to LDS time-major ([column][row], odd row stride), so that the
 // MFMA operand reads "32 rows at one column" are 32 consecutive words -- and owns the whole 128 x N output: 36 (or 8)
-// accumulator tiles, 1152 MFMAs per chunk for 13 loads + 50 ds_write per thread.  Slices of the (item, chunk) range
-// write private slabs; one reduce kernel sums them in order and scatters to the torch layouts (deterministic).
+// accumulator tiles.  Two LDS buffers, ONE barrier per chunk: while the matrix phase runs on chunk c, the registers
+// holding chunk c + 1 (loads issued a whole matrix phase earlier) are written to the other buffer in the second half
+// of the MFMA loop, then the loads of chunk c + 2 are issued.  Operand rows are assigned to the 64-row load slots on
+// the host (every source tensor starts at a multiple of 64 rows), so a slot's base pointer, shift and item stride are
+// wave-uniform (scalar registers) and a thread keeps ONE row offset for all of them: 154 vector registers for N = 272
+// (211 with per-slot pointer tables), which leaves room for a data-gradient / gate workgroup of the same layer beside
+// it on the CU (round 4: the weight path runs on a side stream, functional._join_wgrad_side_stream).  The skip+out
+// contraction (N = 64: few MFMAs per byte) runs three workgroups per CU to keep more loads in flight.  Variants
+// measured and dropped (profiles/r04_wavenet_wgrad_variants.txt): 12 waves x 3 tiles with register-prefetched LDS
+// operands (137 us), the same with the loads interleaved into the matrix phase (132 us: lane-dependent control flow in
+// the load code makes the compiler wait with vmcnt(0) after every load).  Slices of the (item, chunk) range write private
+// slabs; one reduce kernel sums them in order and scatters to the torch layouts (deterministic).
 // =====================================================================================================================
-constexpr int WW_COLS = 64;
+constexpr int WW_COLS = 32;
+constexpr int WW_SLOTS = 7;  // 64-row load slots: (128 + 272) / 64 rounded up
 struct WwArgs {
-  const float* m_src[2];  // M operand: stacked row groups of (B, rows, T) tensors, 128 rows in total; NULL = zeros
-  int m_rows[2];
-  const float* n_src[4];  // N operand row groups, each read at column n + shift
-  int n_rows[4];
-  int n_shift[4];
-  float* slabs;           // [slices][128][NROWS + 1]
+  const float* src[WW_SLOTS];  // row 0 of the slot in item 0 of its tensor; NULL = zeros
+  int rows[WW_SLOTS];          // valid rows of the slot (<= 64)
+  int shift[WW_SLOTS];         // the slot's rows are read at column n + shift
+  int item[WW_SLOTS];          // floats between consecutive items of that tensor
+  float* slabs;                // [slices][128][NROWS + 1]
   int T, chunks_per_item, chunks_total, chunks_per_slice;
 };
 
 template <int NROWS>
-__global__ __launch_bounds__(512, 1) void wavenet_wgrad_kernel(WwArgs a) {
+__global__ __launch_bounds__(512, NROWS > 64 ? 1 : 3) void wavenet_wgrad_kernel(WwArgs a) {
   constexpr int ROWS = WN_G + NROWS;            // staged rows: M operand first, then the N operand
   constexpr int RS2 = ROWS + 1;                 // words between consecutive columns (odd)
-  constexpr int NLD = (ROWS * 16 + 511) / 512;  // 16-B loads per thread and chunk
+  constexpr int NLD = (ROWS + 63) / 64;         // 16-B loads per thread and chunk (one per slot)
   constexpr int NCT = (NROWS + 31) / 32;        // column tiles of the output
   constexpr int NTL = NCT > 2 ? 5 : 1;          // tiles per wave (N = 272: waves 0-3 own 5, waves 4-7 own 4)
-  extern __shared__ __attribute__((aligned(16))) float tile[];  // [64][RS2] (+ 32 floats of slack)
+  constexpr int BUF = WW_COLS * RS2;            // floats per LDS buffer
+  constexpr int STEPS = WW_COLS / 2;
+  static_assert(NLD <= WW_SLOTS, "slot table too small");
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // 2 x [32][RS2] (+ 32 floats of slack)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -707,47 +720,22 @@ __global__ __launch_bounds__(512, 1) void wavenet_wgrad_kernel(WwArgs a) {
   const int T = a.T;
   const int c_begin = blockIdx.x * a.chunks_per_slice;
   const int c_end = min(c_begin + a.chunks_per_slice, a.chunks_total);
+  const int lrow = tid >> 3, q4 = 4 * (tid & 7);  // this thread's row inside every slot, its 4 columns of the chunk
+  const int lane_off = lrow * T;
 
-  // row -> (source row pointer for item 0, item stride, shift); evaluated per load slot once (chunk-invariant)
-  const float* rptr[NLD];
-  int rshift[NLD], ritem[NLD];
-#pragma unroll
-  for (int i = 0; i < NLD; ++i) {
-    const int e = i * 512 + tid;
-    int row = e >> 4;
-    const float* p = nullptr;
-    int shift = 0, rows_of = 0;
-    if (row < WN_G) {
-      int r = row;
-#pragma unroll
-      for (int gI = 0; gI < 2; ++gI) {
-        if (r >= 0 && r < a.m_rows[gI]) { p = a.m_src[gI] ? a.m_src[gI] + (long)r * T : nullptr; rows_of = a.m_rows[gI]; }
-        r -= a.m_rows[gI];
-      }
-    } else if (row < ROWS) {
-      int r = row - WN_G;
-#pragma unroll
-      for (int gI = 0; gI < 4; ++gI) {
-        if (r >= 0 && r < a.n_rows[gI]) { p = a.n_src[gI] + (long)r * T; shift = a.n_shift[gI]; rows_of = a.n_rows[gI]; }
-        r -= a.n_rows[gI];
-      }
-    }
-    rptr[i] = p;
-    rshift[i] = shift + 4 * (e & 15);
-    ritem[i] = rows_of * T;  // floats between consecutive items of that tensor
-  }
   typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
   float4 stage[NLD];
+  // chunk c -> registers.  A slot's tensor, shift and item stride are wave-uniform: scalar base + one lane offset
   auto load_chunk = [&](int c) {
     const int b = c / a.chunks_per_item;
     const int n0 = (c - b * a.chunks_per_item) * WW_COLS;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float* p = rptr[i];
-      const int col = n0 + rshift[i];
-      if (p != nullptr && n0 + 4 * ((i * 512 + tid) & 15) < T) {  // (columns past the item's end stay zero for BOTH operands)
-        p += (long)b * ritem[i];
+      const float* p = a.src[i];
+      const int col = n0 + a.shift[i] + q4;
+      if (p != nullptr && lrow < a.rows[i] && n0 + q4 < T) {  // (columns past the item's end stay zero for BOTH operands)
+        p += (long)b * a.item[i] + lane_off;
         if (col >= 0 && col + 3 < T) {
           const f4u u = *reinterpret_cast<const f4u*>(p + col);
           v = make_float4(u[0], u[1], u[2], u[3]);
@@ -761,18 +749,15 @@ __global__ __launch_bounds__(512, 1) void wavenet_wgrad_kernel(WwArgs a) {
       stage[i] = v;
     }
   };
-  auto store_chunk = [&]() {
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int e = i * 512 + tid;
-      const int row = e >> 4, q = e & 15;
-      if (row < ROWS) {
-        float* d = tile + (4 * q) * RS2 + row;
-        d[0] = stage[i].x;
-        d[RS2] = stage[i].y;
-        d[2 * RS2] = stage[i].z;
-        d[3 * RS2] = stage[i].w;
-      }
+  // slot i of the staged chunk -> LDS buffer ``dst`` ([column][row]); rows past ROWS (last slot) are not stored
+  auto store_slot = [&](float* dst, int i) {
+    const int row = 64 * i + lrow;
+    if (64 * (i + 1) <= ROWS || row < ROWS) {
+      float* d = dst + q4 * RS2 + row;
+      d[0] = stage[i].x;
+      d[RS2] = stage[i].y;
+      d[2 * RS2] = stage[i].z;
+      d[3 * RS2] = stage[i].w;
     }
   };
 
@@ -783,16 +768,22 @@ __global__ __launch_bounds__(512, 1) void wavenet_wgrad_kernel(WwArgs a) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float bsum = 0.f;
 
-  if (c_begin < c_end) load_chunk(c_begin);
+  if (c_begin < c_end) {
+    load_chunk(c_begin);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) store_slot(tile, i);
+    if (c_begin + 1 < c_end) load_chunk(c_begin + 1);
+  }
+  __syncthreads();
   for (int c = c_begin; c < c_end; ++c) {
-    __syncthreads();  // every wave is done reading the previous chunk
-    store_chunk();
-    __syncthreads();
-    if (c + 1 < c_end) load_chunk(c + 1);  // in flight under this chunk's MFMAs
-    const float* al = tile + lhi * RS2 + rt * 32 + l31;
-    const float* bl = tile + lhi * RS2 + WN_G + ct0 * 32 + l31;
-#pragma unroll 4
-    for (int st = 0; st < WW_COLS / 2; ++st) {
+    const int par = (c - c_begin) & 1;
+    const float* cur = tile + par * BUF;
+    float* nxt = tile + (par ^ 1) * BUF;
+    const bool more = c + 1 < c_end;
+    const float* al = cur + lhi * RS2 + rt * 32 + l31;
+    const float* bl = cur + lhi * RS2 + WN_G + ct0 * 32 + l31;
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
       const float av = al[2 * st * RS2];
       bsum += av;
       float bv[NTL];
@@ -801,7 +792,16 @@ __global__ __launch_bounds__(512, 1) void wavenet_wgrad_kernel(WwArgs a) {
 #pragma unroll
       for (int t = 0; t < NTL; ++t)
         if (NTL == 1 || t < 4 || ntl == 5) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+      // second half of the matrix phase: the next chunk (in registers since the previous phase) goes to the other buffer
+      if (st >= STEPS / 2 && more) {
+        constexpr int H = STEPS / 2;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+          if (i * H / NLD == st - H) store_slot(nxt, i);
+      }
     }
+    if (c + 2 < c_end) load_chunk(c + 2);  // in flight under the next chunk's matrix phase
+    __syncthreads();                       // chunk c + 1 is in LDS; every wave is done reading chunk c
   }
   // slab of this slice: [128][NROWS + 1]; D layout col = lane & 31, row = 8 * (r >> 2) + 4 * lhi + (r & 3)
   float* slab = a.slabs + (long)blockIdx.x * WN_G * (NROWS + 1);
@@ -827,7 +827,8 @@ __global__ __launch_bounds__(512, 1) void wavenet_wgrad_kernel(WwArgs a) {
 struct WfArgs {
   const float* slab0;
   const float* slab1;
-  int slices;
+  int slices;   // of slab0
+  int slices1;  // of slab1
   pwg_wavenet_param_grad conv[4];  // dil, aux, skip, out
 };
 constexpr int WF_N0 = WN_K * WN_R + 80 + 1;  // 273
@@ -877,6 +878,7 @@ __global__ __launch_bounds__(WF_THREADS) void wavenet_wgrad_finish_kernel(WfArgs
   const int layer = blockIdx.x >> 7, m = blockIdx.x & 127;
   const int cols = layer == 0 ? WF_N0 : WF_N1;
   const int SL = layer == 0 ? 3 : 12;
+  const int nsl = layer == 0 ? a.slices : a.slices1;
   const int tid = threadIdx.x;
   const int sl = tid / cols, col = tid - sl * cols;
   const long sstride = (long)WN_G * cols;
@@ -884,13 +886,13 @@ __global__ __launch_bounds__(WF_THREADS) void wavenet_wgrad_finish_kernel(WfArgs
   if (sl < SL) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four loads in flight
     int j = sl;
-    for (; j + 3 * SL < a.slices; j += 4 * SL) {
+    for (; j + 3 * SL < nsl; j += 4 * SL) {
       s0 += src[(long)j * sstride];
       s1 += src[(long)(j + SL) * sstride];
       s2 += src[(long)(j + 2 * SL) * sstride];
       s3 += src[(long)(j + 3 * SL) * sstride];
     }
-    for (; j < a.slices; j += SL) s0 += src[(long)j * sstride];
+    for (; j < nsl; j += SL) s0 += src[(long)j * sstride];
     part[sl * cols + col] = (s0 + s1) + (s2 + s3);
   }
   __syncthreads();
@@ -1078,9 +1080,11 @@ int pwg_wavenet_data_backward(const pwg_wavenet_desc* d, const float* dz, const 
   return PWG_OK;
 }
 
-static int ww_slices(const pwg_wavenet_desc* d, int* chunks_per_slice) {
+// ``per_cu`` workgroups (8 waves each) per CU: 1 for the dil+aux contraction (MFMA-bound, 100 KB of LDS), 3 for the
+// skip+out contraction (few MFMAs per byte: more loads in flight)
+static int ww_slices(const pwg_wavenet_desc* d, int* chunks_per_slice, int per_cu) {
   const int chunks = d->batch * ceil_div(d->t, WW_COLS);
-  int per = ceil_div(chunks, 256);  // one workgroup (8 waves) per CU
+  int per = ceil_div(chunks, 256 * per_cu);
   if (per < 2) per = chunks >= 2 ? 2 : 1;
   *chunks_per_slice = per;
   return ceil_div(chunks, per);
@@ -1089,8 +1093,8 @@ static int ww_slices(const pwg_wavenet_desc* d, int* chunks_per_slice) {
 size_t pwg_wavenet_weight_backward_workspace_floats(const pwg_wavenet_desc* d) {
   if (!wavenet_ok(d)) return 0;
   int per;
-  const int slices = ww_slices(d, &per);
-  return (size_t)slices * WN_G * ((size_t)(WN_K * WN_R + d->aux_channels + 1) + (WN_R + 1));
+  const int slices0 = ww_slices(d, &per, 1), slices1 = ww_slices(d, &per, 3);
+  return (size_t)slices0 * WN_G * (size_t)(WN_K * WN_R + d->aux_channels + 1) + (size_t)slices1 * WN_G * (WN_R + 1);
 }
 
 int pwg_wavenet_weight_backward(const pwg_wavenet_desc* d, const float* dz, const float* x, const float* c, const float* gs,
@@ -1107,8 +1111,8 @@ int pwg_wavenet_weight_backward(const pwg_wavenet_desc* d, const float* dz, cons
               "wavenet_weight_backward: workspace too small");
   PWG_REQUIRE(!d->causal, PWG_ERR_UNSUPPORTED, "wavenet_weight_backward: the causal form is not built");
   hipStream_t stream = (hipStream_t)stream_;
-  int per;
-  const int slices = ww_slices(d, &per);
+  int per, per1;
+  const int slices = ww_slices(d, &per, 1), slices1 = ww_slices(d, &per1, 3);
   constexpr int N0 = WN_K * WN_R + 80, N1 = WN_R;
   float* slab0 = workspace;
   float* slab1 = workspace + (size_t)slices * WN_G * (N0 + 1);
@@ -1118,13 +1122,23 @@ int pwg_wavenet_weight_backward(const pwg_wavenet_desc* d, const float* dz, cons
   a.chunks_total = d->batch * a.chunks_per_item;
   a.chunks_per_slice = per;
   const double samples = (double)d->batch * d->t;
+  // 64-row load slots of one operand tensor: rows [r0, r0 + rows) of ``p`` (B, total_rows, T), read at column n + shift
+  auto put = [&](int& slot, const float* p, int rows, int total_rows, int shift) {
+    for (int r0 = 0; r0 < rows; r0 += 64, ++slot) {
+      a.src[slot] = p ? p + (size_t)r0 * d->t : nullptr;
+      a.rows[slot] = rows - r0 < 64 ? rows - r0 : 64;
+      a.shift[slot] = shift;
+      a.item[slot] = total_rows * d->t;
+    }
+  };
   maybe_poison_lds(stream);
   {
-    a.m_src[0] = dz; a.m_rows[0] = WN_G; a.m_src[1] = nullptr; a.m_rows[1] = 0;
-    for (int t = 0; t < WN_K; ++t) { a.n_src[t] = x; a.n_rows[t] = WN_R; a.n_shift[t] = (t - 1) * d->dilation; }
-    a.n_src[3] = c; a.n_rows[3] = d->aux_channels; a.n_shift[3] = 0;
+    int slot = 0;
+    put(slot, dz, WN_G, WN_G, 0);
+    for (int t = 0; t < WN_K; ++t) put(slot, x, WN_R, WN_R, (t - 1) * d->dilation);
+    put(slot, c, d->aux_channels, d->aux_channels, 0);
     a.slabs = slab0;
-    const size_t lds = ((size_t)WW_COLS * (WN_G + N0 + 1) + 32) * sizeof(float);
+    const size_t lds = ((size_t)2 * WW_COLS * (WN_G + N0 + 1) + 32) * sizeof(float);
     void (*kern)(WwArgs) = wavenet_wgrad_kernel<N0>;
     if (!lds_limit_is_set(reinterpret_cast<const void*>(kern), lds)) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1135,14 +1149,17 @@ int pwg_wavenet_weight_backward(const pwg_wavenet_desc* d, const float* dz, cons
     PWG_CHECK_LAUNCH("wavenet_weight_backward");
   }
   {
-    a.m_src[0] = gs; a.m_rows[0] = WN_S; a.m_src[1] = go; a.m_rows[1] = WN_R;
-    a.n_src[0] = g; a.n_rows[0] = WN_R; a.n_shift[0] = 0;
-    for (int t = 1; t < 4; ++t) { a.n_src[t] = g; a.n_rows[t] = 0; a.n_shift[t] = 0; }
+    for (int i = 0; i < WW_SLOTS; ++i) { a.src[i] = nullptr; a.rows[i] = 0; a.shift[i] = 0; a.item[i] = 0; }
+    int slot = 0;
+    put(slot, gs, WN_S, WN_S, 0);
+    if (go) put(slot, go, WN_R, WN_R, 0); else put(slot, nullptr, WN_R, WN_R, 0);
+    put(slot, g, WN_R, WN_R, 0);
     a.slabs = slab1;
-    const size_t lds = ((size_t)WW_COLS * (WN_G + N1 + 1) + 32) * sizeof(float);
-    static_assert(((size_t)WW_COLS * (WN_G + N1 + 1) + 32) * sizeof(float) <= 64 * 1024, "skip+out tile fits the default LDS limit");
+    a.chunks_per_slice = per1;
+    const size_t lds = ((size_t)2 * WW_COLS * (WN_G + N1 + 1) + 32) * sizeof(float);
+    static_assert(((size_t)2 * WW_COLS * (WN_G + N1 + 1) + 32) * sizeof(float) <= 64 * 1024, "skip+out tile fits the default LDS limit");
     ProfScope prof(stream, "wavenet_wgrad_kernel<skip+out>", 2.0 * samples * WN_G * N1, 4.0 * samples * (WN_G + WN_R));
-    hipLaunchKernelGGL(wavenet_wgrad_kernel<N1>, dim3(slices), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL(wavenet_wgrad_kernel<N1>, dim3(slices1), dim3(512), lds, stream, a);
     PWG_CHECK_LAUNCH("wavenet_weight_backward");
   }
   {
@@ -1150,8 +1167,9 @@ int pwg_wavenet_weight_backward(const pwg_wavenet_desc* d, const float* dz, cons
     f.slab0 = slab0;
     f.slab1 = slab1;
     f.slices = slices;
+    f.slices1 = slices1;
     for (int i = 0; i < 4; ++i) f.conv[i] = grads[i];
-    ProfScope prof(stream, "wavenet_wgrad_finish_kernel", 0, 4.0 * slices * WN_G * (double)(N0 + N1 + 2));
+    ProfScope prof(stream, "wavenet_wgrad_finish_kernel", 0, 4.0 * WN_G * ((double)slices * (N0 + 1) + (double)slices1 * (N1 + 1)));
     hipLaunchKernelGGL(wavenet_wgrad_finish_kernel, dim3(2 * WN_G), dim3(WF_THREADS), 0, stream, f);
     PWG_CHECK_LAUNCH("wavenet_wgrad_finish");
   }

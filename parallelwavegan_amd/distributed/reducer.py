@@ -144,7 +144,11 @@ class GradReducer:
         if not self.enabled:
             return
         b = self.bucket_of[p]
-        if p.grad.data_ptr() != b.views[p].data_ptr():  # (else: the kernel wrote the slot itself, see direct_slots)
+        if p.grad is None:
+            # (torch fires the hook also when the incoming gradient is undefined, e.g. the unused residual 1x1 of the
+            # last WaveNet layer: the zero-filled slot is that parameter's contribution)
+            pass
+        elif p.grad.data_ptr() != b.views[p].data_ptr():  # (else: the kernel wrote the slot itself, see direct_slots)
             b.views[p].copy_(p.grad)
             self.copies += 1
         p.grad = None  # the bucket slot now owns this gradient

@@ -262,6 +262,73 @@ class FusedConvFn(torch.autograd.Function):
         return dx, dw, db, dadd1, dadd2, None, None, None, dg
 
 
+# ---------------------------------------------------------------------------------------------
+# weight-gradient launches beside the data path
+# ---------------------------------------------------------------------------------------------
+# The WaveNet layers' backward is a strict chain (gate -> data gradient -> the previous layer's gate ...) whose
+# kernels leave half of the matrix pipes idle, and every layer's three weight-gradient launches depend on the chain
+# but nothing in the chain depends on them.  They go to a side stream: in a captured step they become a parallel
+# branch of the graph and run beside the data gradient of their layer and the (HBM-bound) gate kernel of the next.
+# The caller's stream is joined with the side stream (a) right away when something consumes the parameter gradients
+# inside the backward pass (an existing ``.grad`` to add to, tensor or post-accumulate hooks -- the data-parallel
+# reducer), else (b) once, by an engine callback at the end of the backward pass.
+# Measured on the PWG.v1 step (B6 x 25600, profiles/r04_wavenet_wgrad_variants.txt): eager launches 29.08 -> 28.11 ms;
+# inside a captured hipGraph the two branches run concurrently but stretch each other (27.97 vs 28.10 ms), so the
+# default ("auto") forks only when the stream is not being captured.  PWG_WAVENET_WGRAD_STREAM=0 / 1: never / always.
+WGRAD_SIDE_STREAM = {"0": False, "1": True}.get(os.environ.get("PWG_WAVENET_WGRAD_STREAM", "auto"), "auto")
+
+
+def _wgrad_fork_now():
+    if WGRAD_SIDE_STREAM == "auto":
+        return not torch.cuda.is_current_stream_capturing()
+    return bool(WGRAD_SIDE_STREAM)
+
+
+_WGRAD_STREAMS = {}
+_WGRAD_JOIN_QUEUED = set()
+
+
+def _wgrad_side_stream(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    s = _WGRAD_STREAMS.get(key)
+    if s is None:
+        s = _WGRAD_STREAMS[key] = torch.cuda.Stream(device=device)
+    return s
+
+
+def _grads_consumed_in_pass(params):
+    for p in params:
+        if p is None:
+            continue
+        if p.grad is not None or getattr(p, "_post_accumulate_grad_hooks", None) or getattr(p, "_backward_hooks", None):
+            return True
+    return False
+
+
+def _join_wgrad_side_stream(device, deferred):
+    """Make the current stream wait for the side stream's weight-gradient launches: now, or (``deferred``) when the
+    running backward pass ends (the engine runs such callbacks on the caller's streams, before ``backward()`` returns)."""
+    side = _wgrad_side_stream(device)
+    if not deferred:
+        torch.cuda.current_stream(device).wait_stream(side)
+        return
+    # one callback per (device, backward pass); entries of a pass that died with an exception are harmless (ids are unique)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch._C._current_graph_task_id())
+    if key in _WGRAD_JOIN_QUEUED:
+        return
+    _WGRAD_JOIN_QUEUED.add(key)
+    node_stream = torch.cuda.current_stream(device)  # (= the stream of the layer's forward: the engine set it)
+
+    def join():
+        _WGRAD_JOIN_QUEUED.discard(key)
+        node_stream.wait_stream(side)
+        cur = torch.cuda.current_stream(device)  # the stream around the caller's backward() (see GraphTask post-processing)
+        if cur != node_stream:
+            cur.wait_stream(side)
+
+    torch.autograd.Variable._execution_engine.queue_callback(join)
+
+
 def conv_param_grads(desc, x3, gsum, w_shape3, w_orig_shape, v, g, need_w, need_g, need_b):
     """(dw or dv, dg, db) of a convolution from its input ``x3`` and the gradient ``gsum`` w.r.t. its
     pre-activation output: the weight-gradient kernel + the weight-norm finish when ``g`` is given."""
@@ -308,6 +375,7 @@ class WaveNetLayerFn(torch.autograd.Function):
         ctx.block, ctx.desc = block, desc
         ctx.holders = [cv.prepared() for cv in convs]  # (the parameter values this forward used)
         ctx.has_skips = skips is not None
+        ctx.param_refs = params
         ctx.save_for_backward(x, c, z, gt)
         ctx.set_materialize_grads(False)
         # third output: c itself, for the NEXT layer -- the gradient of the shared aux features then arrives here
@@ -332,11 +400,10 @@ class WaveNetLayerFn(torch.autograd.Function):
         if ds_out is None:  # (cannot happen in the generator: every layer's skip sum reaches the loss)
             ds_out = torch.zeros_like(x)
         ds_out = _c(ds_out)
-        # data path: two launches (csrc/wavenet.hip): dz and go = out_mul * dx_out, then dx (+ go) and dc
+        # data path: two launches (csrc/wavenet.hip): dz and go = out_mul * dx_out, then (below, after the weight
+        # path has been forked off) dx (+ go) and dc
         img = block.fused_image_bwd(desc.skip_mul)
         dz, go = ops.wavenet_gate_backward(desc, z, dx_out, ds_out, img)
-        dx, dc = ops.wavenet_data_backward(desc, dz, go, img, need_dx=need[0], need_dc=need[1],
-                                           dc_accum=None if dc_next is None else _c(dc_next))
         # gradient w.r.t. the pre-scale sum of the skip convolution (its weight-gradient operand / the incoming skips)
         gs = ds_out
         if desc.skip_mul != 1.0:
@@ -346,13 +413,29 @@ class WaveNetLayerFn(torch.autograd.Function):
         grads = []
         pi = 5
         fused_w = None
+        forked = False
         if os.environ.get("PWG_NO_WAVENET_WGRAD", "0") != "1":
-            # weight path: every parameter gradient of the layer in three launches (csrc/wavenet.hip)
-            fused_w = ops.wavenet_weight_backward(
-                desc, dz, x, c, gs, go, gt,
-                convs=[(hd.w if cv.has_weight_norm else None,
-                        cv.weight_g.detach().reshape(-1) if cv.has_weight_norm else None, cv.bias is not None)
-                       for cv, hd in ((conv_d, h_d), (conv_a, h_a), (conv_s, h_s), (conv_o, h_o))])
+            # weight path: every parameter gradient of the layer in three launches (csrc/wavenet.hip), issued on the
+            # side stream right after the gate kernel (see _join_wgrad_side_stream)
+            wn = [(hd.w if cv.has_weight_norm else None,
+                   cv.weight_g.detach().reshape(-1) if cv.has_weight_norm else None, cv.bias is not None)
+                  for cv, hd in ((conv_d, h_d), (conv_a, h_a), (conv_s, h_s), (conv_o, h_o))]
+            forked = _wgrad_fork_now()
+            if forked:
+                dev = dz.device
+                cur, side = torch.cuda.current_stream(dev), _wgrad_side_stream(dev)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    fused_w = ops.wavenet_weight_backward(desc, dz, x, c, gs, go, gt, convs=wn)
+                for t_ in (dz, x, c, gs, go, gt):  # allocated on the caller's stream, read on the side stream
+                    if t_ is not None:
+                        t_.record_stream(side)
+            else:
+                fused_w = ops.wavenet_weight_backward(desc, dz, x, c, gs, go, gt, convs=wn)
+        dx, dc = ops.wavenet_data_backward(desc, dz, go, img, need_dx=need[0], need_dc=need[1],
+                                           dc_accum=None if dc_next is None else _c(dc_next))
+        if fused_w is not None and forked:
+            _join_wgrad_side_stream(dz.device, deferred=not _grads_consumed_in_pass(ctx.param_refs))
         for i, (cv, hd, dsc, xin, gsum) in enumerate(((conv_d, h_d, d_d, x, dz), (conv_a, h_a, d_a, c, dz),
                                                       (conv_s, h_s, d_s, gt, gs), (conv_o, h_o, d_o, gt, go))):
             has_g = cv.has_weight_norm

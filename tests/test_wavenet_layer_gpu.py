@@ -208,3 +208,56 @@ def test_aux_gradient_chained_through_layers(c_requires_grad, device):
                 assert torch.isfinite(got).all(), (mode, k)
                 assert _rel(got, want) <= 5e-5, (mode, k, _rel(got, want))
     assert (res["chained"]["dc"] is not None) == c_requires_grad
+
+
+def test_weight_gradients_on_the_side_stream_equal_the_in_line_ones(device):
+    """The layers' weight-gradient launches run on a side stream (functional._join_wgrad_side_stream): same bits as
+    in-line launches, (a) joined by the end-of-pass callback (fresh gradients), (b) joined per layer when the pass
+    accumulates into existing ``.grad`` tensors, (c) with a post-accumulate hook that reads the gradient."""
+    from parallelwavegan_amd import functional
+
+    torch.manual_seed(11)
+    blks = [WaveNetResidualBlock(dilation=d).to(device) for d in (1, 2, 4, 8, 16, 32)]
+    for blk in blks:
+        for cv in (blk.conv, blk.conv1x1_aux, blk.conv1x1_skip, blk.conv1x1_out):
+            cv.apply_weight_norm()
+    B, T = 3, 4000
+    x0, c0 = torch.randn(B, 64, T, device=device), torch.randn(B, 80, T, device=device)
+    w = torch.randn(B, 64, T, device=device)
+    params = [p for blk in blks for p in blk.parameters()]
+
+    def run(passes):
+        for p in params:
+            p.grad = None
+        with poison_lds(), poison_empty():
+            for _ in range(passes):
+                h, skips, cc = x0, None, c0
+                for blk in blks:
+                    h, skips, cc = blk(h, cc, skips=skips, skip_scale=1.0, chain_aux=True)
+                (skips * w).sum().backward()
+        # (no synchronize: reading .grad on the current stream must already be ordered after the side stream)
+        return [None if p.grad is None else p.grad.clone() for p in params]
+
+    saved = functional.WGRAD_SIDE_STREAM
+    try:
+        functional.WGRAD_SIDE_STREAM = False
+        want1, want2 = run(1), run(2)
+        functional.WGRAD_SIDE_STREAM = True
+        got1, got2 = run(1), run(2)
+        seen = []
+        # (torch also fires the hook of a parameter whose incoming gradient is undefined -- the unused residual 1x1)
+        handles = [p.register_post_accumulate_grad_hook(lambda p: seen.append(p.grad.clone()) if p.grad is not None else None)
+                   for p in params]
+        got_hook = run(1)
+        for h in handles:
+            h.remove()
+    finally:
+        functional.WGRAD_SIDE_STREAM = saved
+    assert sum(t is not None for t in want1) >= len(params) - 3  # (the last layer's residual output is unused)
+    for got, want in ((got1, want1), (got2, want2), (got_hook, want1)):
+        for a, b in zip(got, want):
+            assert (a is None) == (b is None)
+            assert a is None or torch.equal(a, b)
+    assert len(seen) == sum(t is not None for t in want1)
+    want_sorted = sorted(float(t.double().abs().sum()) for t in want1 if t is not None)
+    assert sorted(float(t.double().abs().sum()) for t in seen) == want_sorted

@@ -81,4 +81,5 @@ def main():
         print(line, flush=True)
     print(f"TOTAL(default) {tot_ms:.2f} ms/step  {tot_fl/tot_ms/1e9:.1f} TFLOP/s  -> {B*F*256/tot_ms*1e3/1e6:.1f} Msamples/s")
 
-main()
+if __name__ == "__main__":
+    main()
