@@ -376,6 +376,9 @@ class WaveNetLayerFn(torch.autograd.Function):
         ctx.holders = [cv.prepared() for cv in convs]  # (the parameter values this forward used)
         ctx.has_skips = skips is not None
         ctx.param_refs = params
+        # the backward reads the weights through ``block`` (packed images, weight-norm tensors), not through
+        # saved_tensors: remember their versions so that an update between forward and backward is an error here too
+        ctx.param_keys = tuple(cv._params_key()[1:] for cv in convs)
         ctx.save_for_backward(x, c, z, gt)
         ctx.set_materialize_grads(False)
         # third output: c itself, for the NEXT layer -- the gradient of the shared aux features then arrives here
@@ -391,6 +394,9 @@ class WaveNetLayerFn(torch.autograd.Function):
         x, c, z, gt = ctx.saved_tensors
         block, desc = ctx.block, ctx.desc
         conv_d, conv_a, conv_s, conv_o = block.fused_convs()
+        if tuple(cv._params_key()[1:] for cv in (conv_d, conv_a, conv_s, conv_o)) != ctx.param_keys:
+            raise RuntimeError("WaveNetLayerFn.backward: a parameter of the layer was modified after the forward pass "
+                               "(in-place update or optimizer step between forward and backward)")
         h_d, h_a, h_s, h_o = ctx.holders
         b, t = x.shape[0], x.shape[2]
         need = ctx.needs_input_grad

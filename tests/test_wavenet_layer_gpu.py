@@ -261,3 +261,18 @@ def test_weight_gradients_on_the_side_stream_equal_the_in_line_ones(device):
     assert len(seen) == sum(t is not None for t in want1)
     want_sorted = sorted(float(t.double().abs().sum()) for t in want1 if t is not None)
     assert sorted(float(t.double().abs().sum()) for t in seen) == want_sorted
+
+
+def test_backward_rejects_parameters_modified_after_the_forward(device):
+    """The fused layer's backward reads the weights through the block: like autograd's version check on saved tensors,
+    an update between forward and backward must raise instead of mixing old and new values."""
+    torch.manual_seed(3)
+    blk = WaveNetResidualBlock(dilation=2).to(device)
+    for cv in (blk.conv, blk.conv1x1_aux, blk.conv1x1_skip, blk.conv1x1_out):
+        cv.apply_weight_norm()
+    x, c = torch.randn(1, 64, 256, device=device), torch.randn(1, 80, 256, device=device)
+    h, skips = blk(x, c)
+    with torch.no_grad():
+        blk.conv1x1_skip.weight_g.mul_(1.5)
+    with pytest.raises(RuntimeError, match="modified after the forward"):
+        (h.sum() + skips.sum()).backward()
