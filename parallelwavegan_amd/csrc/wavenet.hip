@@ -24,6 +24,7 @@
 #include "common.h"
 
 #include <stdint.h>
+#include <type_traits>
 #include <stdlib.h>
 
 namespace pwg {
@@ -679,9 +680,8 @@ __global__ void wavenet_pack_bwd_kernel(const float* w_dil, const float* s_dil, 
 // holding chunk c + 1 (loads issued a whole matrix phase earlier) are written to the other buffer in the second half
 // of the MFMA loop, then the loads of chunk c + 2 are issued.  Operand rows are assigned to the 64-row load slots on
 // the host (every source tensor starts at a multiple of 64 rows), so a slot's base pointer, shift and item stride are
-// wave-uniform (scalar registers) and a thread keeps ONE row offset for all of them: 154 vector registers for N = 272
-// (211 with per-slot pointer tables), which leaves room for a data-gradient / gate workgroup of the same layer beside
-// it on the CU (round 4: the weight path runs on a side stream, functional._join_wgrad_side_stream).  The skip+out
+// wave-uniform (scalar registers) and a thread keeps ONE row offset for all of them (211 -> 154 vector registers for
+// N = 272 in the single-instantiation form; 232 with the two branch-free matrix phases below).  The skip+out
 // contraction (N = 64: few MFMAs per byte) runs three workgroups per CU to keep more loads in flight.  Variants
 // measured and dropped (profiles/r04_wavenet_wgrad_variants.txt): 12 waves x 3 tiles with register-prefetched LDS
 // operands (137 us), the same with the loads interleaved into the matrix phase (132 us: lane-dependent control flow in
@@ -697,6 +697,7 @@ struct WwArgs {
   int item[WW_SLOTS];          // floats between consecutive items of that tensor
   float* slabs;                // [slices][128][NROWS + 1]
   int T, chunks_per_item, chunks_total, chunks_per_slice;
+  int maxshift;  // largest |shift| of the slots
 };
 
 template <int NROWS>
@@ -768,40 +769,87 @@ __global__ __launch_bounds__(512, NROWS > 64 ? 1 : 3) void wavenet_wgrad_kernel(
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float bsum = 0.f;
 
+  // interior chunk (every column of every slot inside its item: n0 - maxshift >= 0, n0 + 32 + maxshift <= T): one
+  // 16-B load per slot, no lane-dependent control flow; lanes past the last slot's rows read its last row (not stored)
+  const int lane_off_last = (lrow < a.rows[NLD - 1] ? lrow : a.rows[NLD - 1] - 1) * T;
+  auto load_chunk_interior = [&](int b, int n0) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const float* p = a.src[i];
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p != nullptr) {  // (wave-uniform)
+        p += (long)b * a.item[i] + (i == NLD - 1 ? lane_off_last : lane_off);
+        const f4u u = *reinterpret_cast<const f4u*>(p + (n0 + a.shift[i] + q4));
+        v = make_float4(u[0], u[1], u[2], u[3]);
+      }
+      stage[i] = v;
+    }
+  };
+  auto load_any = [&](int c) {
+    const int b = c / a.chunks_per_item;
+    const int n0 = (c - b * a.chunks_per_item) * WW_COLS;
+    if (n0 - a.maxshift >= 0 && n0 + WW_COLS + a.maxshift <= T) load_chunk_interior(b, n0);
+    else load_chunk(c);
+  };
+  // matrix phase of one chunk for a wave that owns NT tiles: branch-free; the LDS operands of step st + 1 are read
+  // before the MFMAs of step st are issued; in its second half the next chunk (in registers since the previous phase;
+  // stale values after the last chunk -- never read) goes to the other buffer
+  auto matrix_phase = [&](auto ntc, const float* cur, float* nxt) {
+    constexpr int NT = decltype(ntc)::value;
+    constexpr int H = STEPS / 2;
+    const float* al = cur + lhi * RS2 + rt * 32 + l31;
+    const float* bl = cur + lhi * RS2 + WN_G + ct0 * 32 + l31;
+    float av = al[0];
+    float bv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bv[t] = bl[t * 32];
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+      float an = 0.f;
+      float bn[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bn[t] = 0.f;
+      if (st + 1 < STEPS) {
+        an = al[2 * (st + 1) * RS2];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bn[t] = bl[2 * (st + 1) * RS2 + t * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // (keep the reads of step st + 1 ahead of this step's MFMAs)
+      bsum += av;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+      if (st >= H) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+          if (i * H / NLD == st - H) store_slot(nxt, i);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      av = an;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bv[t] = bn[t];
+    }
+  };
+
   if (c_begin < c_end) {
     load_chunk(c_begin);
 #pragma unroll
     for (int i = 0; i < NLD; ++i) store_slot(tile, i);
-    if (c_begin + 1 < c_end) load_chunk(c_begin + 1);
+    if (c_begin + 1 < c_end) load_any(c_begin + 1);
   }
   __syncthreads();
   for (int c = c_begin; c < c_end; ++c) {
     const int par = (c - c_begin) & 1;
     const float* cur = tile + par * BUF;
     float* nxt = tile + (par ^ 1) * BUF;
-    const bool more = c + 1 < c_end;
-    const float* al = cur + lhi * RS2 + rt * 32 + l31;
-    const float* bl = cur + lhi * RS2 + WN_G + ct0 * 32 + l31;
-#pragma unroll
-    for (int st = 0; st < STEPS; ++st) {
-      const float av = al[2 * st * RS2];
-      bsum += av;
-      float bv[NTL];
-#pragma unroll
-      for (int t = 0; t < NTL; ++t) bv[t] = bl[2 * st * RS2 + (t < ntl ? t : 0) * 32];
-#pragma unroll
-      for (int t = 0; t < NTL; ++t)
-        if (NTL == 1 || t < 4 || ntl == 5) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
-      // second half of the matrix phase: the next chunk (in registers since the previous phase) goes to the other buffer
-      if (st >= STEPS / 2 && more) {
-        constexpr int H = STEPS / 2;
-#pragma unroll
-        for (int i = 0; i < NLD; ++i)
-          if (i * H / NLD == st - H) store_slot(nxt, i);
-      }
+    if (NTL == 1) {
+      matrix_phase(std::integral_constant<int, 1>{}, cur, nxt);
+    } else if (ntl == NTL) {
+      matrix_phase(std::integral_constant<int, NTL>{}, cur, nxt);
+    } else {
+      matrix_phase(std::integral_constant<int, (NTL > 1 ? NTL - 1 : 1)>{}, cur, nxt);
     }
-    if (c + 2 < c_end) load_chunk(c + 2);  // in flight under the next chunk's matrix phase
-    __syncthreads();                       // chunk c + 1 is in LDS; every wave is done reading chunk c
+    if (c + 2 < c_end) load_any(c + 2);  // in flight under the next chunk's matrix phase
+    __syncthreads();                     // chunk c + 1 is in LDS; every wave is done reading chunk c
   }
   // slab of this slice: [128][NROWS + 1]; D layout col = lane & 31, row = 8 * (r >> 2) + 4 * lhi + (r & 3)
   float* slab = a.slabs + (long)blockIdx.x * WN_G * (NROWS + 1);
@@ -1121,6 +1169,7 @@ int pwg_wavenet_weight_backward(const pwg_wavenet_desc* d, const float* dz, cons
   a.chunks_per_item = ceil_div(d->t, WW_COLS);
   a.chunks_total = d->batch * a.chunks_per_item;
   a.chunks_per_slice = per;
+  a.maxshift = d->dilation;
   const double samples = (double)d->batch * d->t;
   // 64-row load slots of one operand tensor: rows [r0, r0 + rows) of ``p`` (B, total_rows, T), read at column n + shift
   auto put = [&](int& slot, const float* p, int rows, int total_rows, int shift) {
@@ -1150,6 +1199,7 @@ int pwg_wavenet_weight_backward(const pwg_wavenet_desc* d, const float* dz, cons
   }
   {
     for (int i = 0; i < WW_SLOTS; ++i) { a.src[i] = nullptr; a.rows[i] = 0; a.shift[i] = 0; a.item[i] = 0; }
+    a.maxshift = 0;
     int slot = 0;
     put(slot, gs, WN_S, WN_S, 0);
     if (go) put(slot, go, WN_R, WN_R, 0); else put(slot, nullptr, WN_R, WN_R, 0);
