@@ -7,6 +7,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("PWG_PROF_SHAPES", "1")
+os.environ.setdefault("PWG_WAVENET_WGRAD_STREAM", "0")  # serial launches: every kernel is timed alone
 import torch  # noqa: E402
 
 import bench  # noqa: E402
