@@ -243,6 +243,26 @@ int pwg_resunit_pack_weight(int32_t channels, int32_t kernel, const float* w, co
 int pwg_resunit_forward(const pwg_resunit_desc* d, const float* x, const float* w1_packed, const float* b1,
                         const float* w2_packed, const float* b2, const float* add2, float* y, void* stream);
 
+/* ------------------------------------------------------------------------- */
+/* One MelGAN residual stack as ONE launch (channels 48 / 96 / 192, kernel 3; csrc/resstack.hip)             */
+/*                                                                            */
+/*   h = conv_{3,dilation}(reflect_pad_dilation(lrelu(x))) + b1;   y = conv_{1x1}(lrelu(h)) + b2 + conv_{1x1}(x) + bs
+ * replaces ResidualStack.forward (layers/residual_stack.py:75-85: `self.stack(c) + self.skip_layer(c)` with the
+ * Sequential of :45-53 and the skip layer of :73).  All channels of a column tile stay resident in LDS; `h` (the
+ * pre-activation output of the dilated convolution, what a backward pass needs) is written out only when the pointer
+ * is given.  t % 4 == 0, t >= 64, 1 <= dilation <= 27, 0 < slope < 1; pwg_resstack_supported() tells whether a unit
+ * fits (otherwise use three pwg_conv1d_forward calls: identical result up to fp32 summation order).  Weights: torch
+ * layouts (C, C, 3), (C, C, 1), (C, C, 1) re-laid into ONE image by pwg_resstack_pack_weight (`scale*` = optional
+ * weight-norm row scales as in pwg_conv1d_pack_weight).  x / y / h: (batch, channels, t), x 16-B aligned, y and h must
+ * not alias x.                                                                                                   */
+int pwg_resstack_supported(int32_t channels, int32_t t, int32_t dilation);
+size_t pwg_resstack_packed_weight_floats(int32_t channels);
+int pwg_resstack_pack_weight(int32_t channels, const float* w1, const float* scale1, const float* w2,
+                             const float* scale2, const float* ws, const float* scale_s, float* w_packed, void* stream);
+int pwg_resstack_forward(int32_t batch, int32_t channels, int32_t t, int32_t dilation, float slope, const float* x,
+                         const float* w_packed, const float* b1, const float* b2, const float* bs, float* y, float* h,
+                         void* stream);
+
 /* One gated residual layer of the Parallel WaveGAN generator as ONE launch (csrc/wavenet.hip):
  *   z = conv_{k=3,dilation}(x) + b_dil + conv1x1_aux(c);  g = tanh(z[:64]) * sigmoid(z[64:]);
  *   skips_out = (conv1x1_skip(g) + b_skip + skips) * skip_mul;   x_out = (conv1x1_out(g) + b_out + x) * out_mul

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libpwgkernels.so")
 
 PWG_ACT_NONE, PWG_ACT_LEAKY_RELU, PWG_ACT_TANH, PWG_ACT_RELU = 0, 1, 2, 3
 PWG_PAD_ZERO, PWG_PAD_REFLECT, PWG_PAD_REPLICATE = 0, 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class ConvDesc(ctypes.Structure):
@@ -151,6 +151,10 @@ SIGNATURES = {
     "pwg_resunit_packed_weight_floats": (ctypes.c_size_t, [_i32, _i32]),
     "pwg_resunit_pack_weight": (ctypes.c_int, [_i32, _i32, _vp, _vp, _vp, _vp]),
     "pwg_resunit_forward": (ctypes.c_int, [ctypes.POINTER(ResUnitDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pwg_resstack_supported": (ctypes.c_int, [_i32, _i32, _i32]),
+    "pwg_resstack_packed_weight_floats": (ctypes.c_size_t, [_i32]),
+    "pwg_resstack_pack_weight": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pwg_resstack_forward": (ctypes.c_int, [_i32, _i32, _i32, _i32, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pwg_wavenet_layer_supported": (ctypes.c_int, [ctypes.POINTER(WaveNetDesc)]),
     "pwg_wavenet_packed_weight_floats": (ctypes.c_size_t, [ctypes.POINTER(WaveNetDesc)]),
     "pwg_wavenet_pack_weights": (ctypes.c_int, [ctypes.POINTER(WaveNetDesc)] + [_vp] * 10),

@@ -1,0 +1,321 @@
+// resstack.hip -- one MelGAN residual stack as ONE launch (C = 48 / 96 / 192, kernel 3):
+//
+//     h = conv_{3,d}( reflect_pad_d( lrelu(x) ) ) + b1            (pre-activation, optionally written out for the backward pass)
+//     y = conv_{1x1}( lrelu(h) ) + b2  +  conv_{1x1}( x ) + bs
+//
+// (/root/reference/parallel_wavegan/layers/residual_stack.py:45-85: `self.stack(c) + self.skip_layer(c)` with
+//  stack = [LeakyReLU, ReflectionPad1d(d), Conv1d(k=3, dilation=d), LeakyReLU, Conv1d(1)], skip_layer = Conv1d(1).)
+//
+// As three launches of the general kernel the unit reads / writes its (B, C, T) tensors seven times and the two 1 x 1
+// convolutions run far below both roofs (C4, B64: 18.7 TFLOP/s at 1.9 TB/s for C = 48, profiles/r04_z_train_shapes_c4.txt).
+// Here a workgroup keeps ALL channels of a column tile resident, as csrc/resunit.hip does for the HiFi-GAN unit:
+//   * the x tile (C x (N + halo) floats) is staged once by LDS-DMA; the reflected columns of the first / last tile come
+//     through the same DMA (4-B pieces take a per-lane source offset: the mirror is an index computation);
+//   * phase 1 (K = 3 C) writes h in MFMA D layout into a second LDS tile (and to HBM when the caller wants it);
+//   * phase 2 (K = 2 C) contracts W2 with lrelu(h) and Ws with the raw x tile into the same accumulators;
+//   * the reduction loops have no barrier and no DMA: B operands are LDS reads, A operands (weights) stream from L2
+//     through a pre-swizzled image whose 16-B records are v_mfma_f32_32x32x2_f32 A operands, three 8-channel-pair
+//     groups ahead in a register ring.  A 1 x 1 convolution needs no halo, so nothing is recomputed.
+// Every wave owns ONE 32 x 32 accumulator tile: waves = (C / 32 row blocks) x (N / 32 column groups):
+//     C = 192: 6 x 2 = 12 waves, N = 64, 141 KB of LDS (one workgroup per CU, three waves per SIMD);
+//     C =  96: 3 x 2 =  6 waves, N = 64,  71 KB (two workgroups per CU);
+//     C =  48: 2 x 3 =  6 waves, N = 96,  47 KB (three per CU; rows 48..63 of the second row block are zero weights).
+// HBM traffic of a unit: x read once, y written once (+ h written once in training) instead of seven passes.
+#include "common.h"
+
+#include <stdint.h>
+#include <stdlib.h>
+
+namespace pwg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+struct ResStackArgs {
+  const float* x;
+  const float* w;  // packed image, see resstack_pack_kernel
+  const float* b1;
+  const float* b2;
+  const float* bs;
+  float* y;
+  float* h;  // nullptr: the intermediate is not written out
+  int T;
+  int d;    // dilation = reflect padding on each side
+  int hl;   // x-tile column of output column 0 (d rounded up to a multiple of 4)
+  int xw4;  // 16-B pieces staged per x row
+  float slope;
+};
+
+template <int C>
+struct RsCfg {
+  static constexpr int MB = (C + 31) / 32;           // 32-row blocks
+  static constexpr int NG = C == 48 ? 3 : 2;         // 32-column groups
+  static constexpr int N = 32 * NG;                  // output columns per workgroup
+  static constexpr int NW = MB * NG;                 // waves
+  static constexpr int XS = C == 48 ? 152 : 120;     // x-tile row stride (floats) >= N + 28 + 27, multiple of 4
+  static constexpr int CP = C / 2;                   // channel pairs = MFMA k-steps per source
+  static constexpr int GPT = CP / 8;                 // operand groups (8 channel pairs) per source: 3 / 6 / 12
+  static constexpr int SRC_FLOATS = (CP / 4) * 256;  // floats of one (row block, source) of the packed image
+  static_assert(C % 16 == 0 && GPT % 3 == 0, "channel count must give whole triples of operand groups");
+};
+
+// acc += sum over (source s < nsrc, channel pair) of A[s] (*) act_s(B_s).  ``al``: this wave's row block of the packed
+// image + 4 * lane -- a linear stream of 512-float groups (8 channel pairs each) over the sources; B operand of source s:
+// LDS rows of stride rs0 + s * drs starting at b0 + s * dbase (lane's column; the lane's channel-pair half is applied
+// here), pre-activation max(v, v * (slope0 + s * dslope)) (slope 1 = identity).  The A ring is three groups deep and is
+// refilled right after a group's MFMAs have been issued; the stream is read up to 3 groups past its end (the image is
+// padded).
+// ``A``: the ring; ``primed``: it already holds groups 0..2 of this stream (the previous call on the preceding part of
+// the same stream left them there: it reads 3 groups past its own end).
+template <int CP>
+__device__ __forceinline__ void rs_contract(const float* __restrict__ al, const float* b0, int dbase, int rs0, int drs,
+                                            float slope0, float dslope, int nsrc, int lhi, f32x16& acc,
+                                            float4 (&A)[3][2], bool primed) {
+  constexpr int GPT = CP / 8;
+  const int ngroups = nsrc * GPT;
+  float B[3][8];
+  auto load_a = [&](float4(&A2)[2], int g) {
+    const float* p = al + (long)g * 512;
+    A2[0] = *reinterpret_cast<const float4*>(p);
+    A2[1] = *reinterpret_cast<const float4*>(p + 256);
+  };
+  auto load_b = [&](float(&Bg)[8], int g) {
+    const int s = g / GPT, cg = g - s * GPT;
+    const int rs = rs0 + s * drs;
+    const float* p = b0 + s * dbase + (16 * cg + lhi) * rs;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) Bg[i] = p[2 * i * rs];
+  };
+  auto mma = [&](const float4(&A2)[2], const float(&Bg)[8], float slope) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float v = Bg[i];
+      v = __builtin_fmaxf(v, v * slope);  // LeakyReLU for 0 < slope < 1 (exact), identity for slope = 1
+      const float4& q = A2[i >> 2];
+      const float av = (i & 3) == 0 ? q.x : (i & 3) == 1 ? q.y : (i & 3) == 2 ? q.z : q.w;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, v, acc, 0, 0, 0);
+    }
+  };
+  if (!primed) {
+    load_a(A[0], 0);
+    load_a(A[1], 1);
+    load_a(A[2], 2);
+  }
+  load_b(B[0], 0);
+  for (int g = 0; g < ngroups; g += 3) {
+    const float slope = slope0 + (g / GPT) * dslope;  // (a triple never straddles two sources: GPT % 3 == 0)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      load_b(B[(s + 1) % 3], g + s + 1 < ngroups ? g + s + 1 : ngroups - 1);  // (after the last group: a harmless re-read)
+      __builtin_amdgcn_sched_barrier(0);  // (keep the next group's LDS reads ahead of this group's MFMAs)
+      mma(A[s], B[s], slope);
+      load_a(A[s], g + s + 3);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(64 * RsCfg<C>::NW, C == 192 ? 1 : 2) void resstack_kernel(ResStackArgs a) {
+  using Cfg = RsCfg<C>;
+  constexpr int NG = Cfg::NG, N = Cfg::N, NW = Cfg::NW, XS = Cfg::XS, CP = Cfg::CP;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;           // [C][XS] raw x (reflected at the sequence ends)
+  float* hs = smem + C * XS;  // [C][N]  conv_{3,d} + b1 (pre-activation)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / NG, wn = wave - wm * NG;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * N;
+  const int f0 = t0 - a.hl;  // sample of x-tile column 0
+  const int T = a.T;
+
+  // ---- stage the x tile
+  const float* xb = a.x + (long)b * C * T;
+  __amdgpu_buffer_rsrc_t x_rs = uniform_buffer_rsrc(xb, (unsigned)(C * T) * 4u);
+  const int XW = a.xw4 * 4;
+  if (__builtin_amdgcn_readfirstlane((f0 >= 0 && f0 + XW <= T) ? 1 : 0)) {
+    for (int r = wave; r < C; r += NW)
+      if (lane < a.xw4) {
+        const unsigned off = (unsigned)(r * T + f0 + 4 * lane) * 4u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr_t)(xs + r * XS), 16, off, 0, 0, 0);
+      }
+  } else {
+    // first / last tiles of a sequence: 4-B pieces, reflected source index (ReflectionPad1d: x[-j] = x[j],
+    // x[T-1+j] = x[T-1-j]); columns that are neither inside the sequence nor a reflection of it read zero
+    for (int r = wave; r < C; r += NW)
+      for (int i0 = 0; i0 < XW; i0 += 64) {
+        const int j = i0 + lane;
+        int f = f0 + j;
+        if (f < 0) f = -f;
+        if (f >= T) f = 2 * (T - 1) - f;
+        const unsigned off = (j < XW && f >= 0 && f < T) ? (unsigned)(r * T + f) * 4u : 0xFFFFFFFCu;
+        if (j < XW) __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr_t)(xs + r * XS + i0), 4, off, 0, 0, 0);
+      }
+  }
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // biases of this lane's 16 accumulator rows (row = 8 * (r >> 2) + 4 * lhi + (r & 3) of the wave's block), loaded
+  // while the tile's DMA is in flight / under the second phase's MFMAs
+  auto load_bias = [&](const float* p0, const float* p1, float(&bias)[16]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = wm * 32 + 8 * (r >> 2) + 4 * lhi + (r & 3);
+      const int cc = c < C ? c : C - 1;
+      bias[r] = (p0 ? p0[cc] : 0.f) + (p1 ? p1[cc] : 0.f);
+    }
+  };
+  float bias[16];
+  load_bias(a.b1, nullptr, bias);
+  float4 A[3][2];
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- phase 1: h column m reads x-tile columns m + (hl - d) + tap * d of lrelu(x)
+  const float* wl = a.w + (long)wm * 5 * Cfg::SRC_FLOATS + lane * 4;
+  rs_contract<CP>(wl, xs + wn * 32 + l31 + (a.hl - a.d), a.d, XS, 0, a.slope, 0.f, 3, lhi, acc, A, false);
+
+  const int m = wn * 32 + l31;      // this lane's output column inside the tile
+  const bool t_ok = t0 + m < T;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int c = wm * 32 + 8 * (r >> 2) + 4 * lhi + (r & 3);
+    if (c < C) {
+      const float v = acc[r] + bias[r];
+      hs[c * N + m] = v;
+      if (a.h != nullptr && t_ok) a.h[((long)b * C + c) * T + t0 + m] = v;
+    }
+    acc[r] = 0.f;
+  }
+  load_bias(a.b2, a.bs, bias);
+  __syncthreads();
+
+  // ---- phase 2: W2 (*) lrelu(h)  +  Ws (*) x   (source 0: the h tile; source 1: the raw x tile at column m + hl);
+  // the ring already holds the first three groups of this part of the stream (phase 1 read them past its end)
+  {
+    const float* hb = hs + m;
+    const float* xb2 = xs + m + a.hl;
+    rs_contract<CP>(wl + 3 * Cfg::SRC_FLOATS, hb, (int)(xb2 - hb), N, XS - N, a.slope, 1.f - a.slope, 2, lhi, acc, A, true);
+  }
+  if (t_ok) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = wm * 32 + 8 * (r >> 2) + 4 * lhi + (r & 3);
+      if (c < C) a.y[((long)b * C + c) * T + t0 + m] = acc[r] + bias[r];
+    }
+  }
+}
+
+// packed image: [row block mb][source: W1 tap 0, 1, 2, W2, Ws][channel pair / 4][lane][4] (+ 3 groups of padding);
+// element j of a lane's 16 B is the A operand of channel pair cp = 4 q + j: lane -> (row = mb * 32 + (lane & 31),
+// channel = 2 cp + (lane >> 5)) of v_mfma_f32_32x32x2_f32; rows >= C are zero.
+__global__ void resstack_pack_kernel(const float* w1, const float* s1, const float* w2, const float* s2, const float* ws,
+                                     const float* ss, float* out, int C, int total) {
+  const int mbs = (C + 31) / 32, q4 = C / 8;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int j = i & 3;
+    const int lane = (i >> 2) & 63;
+    int r = i >> 8;
+    const int q = r % q4;
+    r /= q4;
+    const int src = r % 5;
+    const int mb = r / 5;
+    float v = 0.f;
+    const int m = mb * 32 + (lane & 31);
+    const int ci = 2 * (4 * q + j) + (lane >> 5);
+    if (mb < mbs && m < C) {
+      if (src < 3) v = w1[((long)m * C + ci) * 3 + src] * (s1 ? s1[m] : 1.f);
+      else if (src == 3) v = w2[(long)m * C + ci] * (s2 ? s2[m] : 1.f);
+      else v = ws[(long)m * C + ci] * (ss ? ss[m] : 1.f);
+    }
+    out[i] = v;
+  }
+}
+
+static bool resstack_geometry(int channels, int t, int dilation, int* hl, int* xw4) {
+  if (channels != 48 && channels != 96 && channels != 192) return false;
+  if (t < 64 || (t & 3) || dilation < 1 || dilation > 27 || dilation >= t) return false;
+  if ((long)channels * t * 4 >= (1L << 32)) return false;  // one buffer descriptor per item
+  const int n = channels == 48 ? RsCfg<48>::N : RsCfg<96>::N;
+  const int xs = channels == 48 ? RsCfg<48>::XS : RsCfg<96>::XS;
+  *hl = (dilation + 3) & ~3;
+  const int need = n + *hl + dilation;
+  *xw4 = (need + 3) / 4;
+  return 4 * *xw4 <= xs && *xw4 <= 64;
+}
+
+static size_t resstack_image_floats(int channels) {
+  return (size_t)((channels + 31) / 32) * 5 * (channels / 8) * 256 + 3 * 512;
+}
+
+}  // namespace pwg
+
+using namespace pwg;
+
+extern "C" {
+
+int pwg_resstack_supported(int32_t channels, int32_t t, int32_t dilation) {
+  int hl, xw4;
+  return resstack_geometry(channels, t, dilation, &hl, &xw4) ? 1 : 0;
+}
+
+size_t pwg_resstack_packed_weight_floats(int32_t channels) {
+  return (channels == 48 || channels == 96 || channels == 192) ? resstack_image_floats(channels) : 0;
+}
+
+int pwg_resstack_pack_weight(int32_t channels, const float* w1, const float* scale1, const float* w2, const float* scale2,
+                             const float* ws, const float* scale_s, float* w_packed, void* stream) {
+  PWG_REQUIRE(w1 && w2 && ws && w_packed, PWG_ERR_NULL, "resstack_pack_weight: null pointer");
+  PWG_REQUIRE(channels == 48 || channels == 96 || channels == 192, PWG_ERR_UNSUPPORTED, "resstack_pack_weight: channels=%d",
+              channels);
+  const int total = (int)resstack_image_floats(channels);
+  hipLaunchKernelGGL(resstack_pack_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, w1, scale1, w2,
+                     scale2, ws, scale_s, w_packed, channels, total);
+  PWG_CHECK_LAUNCH("resstack_pack_weight");
+  return PWG_OK;
+}
+
+int pwg_resstack_forward(int32_t batch, int32_t channels, int32_t t, int32_t dilation, float slope, const float* x,
+                         const float* w_packed, const float* b1, const float* b2, const float* bs, float* y, float* h,
+                         void* stream_) {
+  PWG_REQUIRE(x && w_packed && y, PWG_ERR_NULL, "resstack_forward: null pointer");
+  PWG_REQUIRE(x != y && x != h, PWG_ERR_BAD_SHAPE, "resstack_forward: y / h must not alias x (tiles read their neighbours' halo)");
+  int hl, xw4;
+  PWG_REQUIRE(resstack_geometry(channels, t, dilation, &hl, &xw4) && batch >= 1 && batch <= 65535, PWG_ERR_UNSUPPORTED,
+              "resstack_forward: unsupported unit (C=%d T=%d d=%d B=%d): use three pwg_conv1d_forward calls", channels, t,
+              dilation, batch);
+  PWG_REQUIRE(slope > 0.f && slope < 1.f, PWG_ERR_UNSUPPORTED, "resstack_forward: LeakyReLU slope %g outside (0, 1)", slope);
+  PWG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15u) == 0, PWG_ERR_BAD_SHAPE, "resstack_forward: x must be 16-B aligned");
+  hipStream_t stream = (hipStream_t)stream_;
+  ResStackArgs a;
+  a.x = x; a.w = w_packed; a.b1 = b1; a.b2 = b2; a.bs = bs; a.y = y; a.h = h;
+  a.T = t; a.d = dilation; a.hl = hl; a.xw4 = xw4; a.slope = slope;
+  void (*kern)(ResStackArgs) = channels == 48 ? resstack_kernel<48> : channels == 96 ? resstack_kernel<96> : resstack_kernel<192>;
+  const int n = channels == 48 ? RsCfg<48>::N : RsCfg<96>::N;
+  const int xs = channels == 48 ? RsCfg<48>::XS : RsCfg<96>::XS;
+  const int nw = channels == 48 ? RsCfg<48>::NW : channels == 96 ? RsCfg<96>::NW : RsCfg<192>::NW;
+  const size_t lds = (size_t)channels * (xs + n) * sizeof(float);
+  if (lds > 64 * 1024 && !lds_limit_is_set(reinterpret_cast<const void*>(kern), lds)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    PWG_REQUIRE(e == hipSuccess, PWG_ERR_LAUNCH, "resstack_forward: cannot raise LDS limit to %zu: %s", lds, hipGetErrorString(e));
+  }
+  const double C = channels;
+  const double elems = (double)batch * C * t;
+  maybe_poison_lds(stream);
+  {
+    ProfScope prof(stream, prof_shape_name("resstack_kernel", "resstack_kernel B%d C%d T%d d%d save%d", batch, channels, t,
+                                           dilation, h != nullptr),
+                   2.0 * elems * C * 5, 4.0 * (elems * (2 + (h != nullptr)) + 5 * C * C));
+    hipLaunchKernelGGL(kern, dim3(ceil_div(t, n), batch), dim3(64 * nw), lds, stream, a);
+  }
+  PWG_CHECK_LAUNCH("resstack_forward");
+  return PWG_OK;
+}
+
+}  // extern "C"

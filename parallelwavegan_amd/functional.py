@@ -135,7 +135,9 @@ class FusedConvFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, w, bias, add1, add2, geom, fused, packed, g=None):
+    def forward(ctx, x, w, bias, add1, add2, geom, fused, packed, g=None, precomputed=None):
+        """``precomputed``: the value of this convolution, already produced by a kernel that fuses several layers
+        (csrc/resstack.hip): nothing is launched here, the node only records what its backward needs."""
         x = _c(x)
         b = x.shape[0]
         width = geom.get("width", 1)
@@ -166,7 +168,13 @@ class FusedConvFn(torch.autograd.Function):
             holder = PreparedWeights(None, wc, scale, fwd)
         add1c = None if add1 is None else _c(add1).reshape(b, c_out, -1)
         add2c = None if add2 is None else _c(add2).reshape(b, c_out, -1)
-        y = ops.conv1d_forward(desc, x3, holder.fwd, None if bias is None else _c(bias), add1c, add2c)
+        if precomputed is None:
+            y = ops.conv1d_forward(desc, x3, holder.fwd, None if bias is None else _c(bias), add1c, add2c)
+        else:
+            if tuple(precomputed.shape) != (b, c_out, t_out * width) or not precomputed.is_contiguous():
+                raise ValueError(f"FusedConvFn: precomputed output has shape {tuple(precomputed.shape)}, "
+                                 f"expected {(b, c_out, t_out * width)}")
+            y = precomputed.view(b, c_out, t_out * width)  # (a new tensor object: the output of this node)
         ctx.desc = desc
         ctx.has = (bias is not None, add1 is not None, add2 is not None)
         ctx.fused = fused
@@ -259,7 +267,7 @@ class FusedConvFn(torch.autograd.Function):
         gshape = dy.shape if desc.width == 1 else (desc.batch, desc.c_out, desc.t_out, desc.width)
         dadd1 = gsum.reshape(gshape) if has_add1 and ctx.needs_input_grad[3] else None
         dadd2 = gsum.reshape(gshape) if has_add2 and ctx.needs_input_grad[4] else None
-        return dx, dw, db, dadd1, dadd2, None, None, None, dg
+        return dx, dw, db, dadd1, dadd2, None, None, None, dg, None
 
 
 # ---------------------------------------------------------------------------------------------

@@ -224,8 +224,9 @@ class _ConvNd(torch.nn.Module):
         return any(t is not None and t.requires_grad for t in tensors)
 
     def forward(self, x, pre_act=None, pre_slope=0.0, post_act=None, post_slope=0.0, add1=None, add2=None,
-                out_mul=1.0, out_div=1.0):
-        """Fused ``post((conv(pre(x)) + bias + add1 + add2) * out_mul / out_div)``."""
+                out_mul=1.0, out_div=1.0, precomputed=None):
+        """Fused ``post((conv(pre(x)) + bias + add1 + add2) * out_mul / out_div)``.  ``precomputed`` (autograd path
+        only): this layer's output as produced by a multi-layer kernel -- no launch, the node is recorded for backward."""
         fused = dict(pre_act=pre_act, pre_slope=pre_slope, post_act=post_act, post_slope=post_slope,
                      out_mul=out_mul, out_div=out_div)
         if self._needs_grad(x, add1, add2):
@@ -239,11 +240,14 @@ class _ConvNd(torch.nn.Module):
                 geom["padding"], geom["padding_right"], geom["pad_mode"] = 0, 0, "zero"
             if self.has_spectral_norm:
                 # one power iteration per training forward: the weight is a fresh autograd node
+                assert precomputed is None
                 return Fn.FusedConvFn.apply(x, self.weight_tensor(), self.bias, add1, add2, geom, fused, None)
             if self.has_weight_norm:
                 return Fn.FusedConvFn.apply(x, self.weight_v, self.bias, add1, add2, geom, fused, self.prepared(),
-                                            self.weight_g)
-            return Fn.FusedConvFn.apply(x, self.weight, self.bias, add1, add2, geom, fused, self.prepared())
+                                            self.weight_g, precomputed)
+            return Fn.FusedConvFn.apply(x, self.weight, self.bias, add1, add2, geom, fused, self.prepared(), None,
+                                        precomputed)
+        assert precomputed is None, "precomputed outputs only make sense on the autograd path"
         with torch.no_grad():
             b = x.shape[0]
             if self.width_mode:

@@ -1,6 +1,9 @@
 """MelGAN residual stack (drop-in for parallel_wavegan.layers.residual_stack)."""
+import os
+
 import torch
 
+from .. import ops
 from .activation import FusedActivation
 from .causal_conv import CausalConv1d
 from .conv import Conv1d
@@ -8,9 +11,12 @@ from .padding import get_pad
 
 
 class ResidualStack(torch.nn.Module):
-    """``[act, pad(d), conv k3 dil d, act, conv 1x1](c) + skip 1x1(c)`` (layers/residual_stack.py:13-85)
-    as three launches: skip conv; dilated conv with activation + reflect padding fused on its input;
-    1x1 conv with activation fused on its input and the skip branch fused as addend."""
+    """``[act, pad(d), conv k3 dil d, act, conv 1x1](c) + skip 1x1(c)`` (layers/residual_stack.py:13-85).
+    MelGAN's geometries (48 / 96 / 192 channels, kernel 3, reflect padding, LeakyReLU) run as ONE launch
+    (csrc/resstack.hip; ``fuse_unit``); everything else as three: skip conv; dilated conv with activation + reflect
+    padding fused on its input; 1x1 conv with activation fused on its input and the skip branch fused as addend."""
+
+    fuse_unit = os.environ.get("PWG_RESSTACK", "1") != "0"  # (0: the three-launch path, for A/B measurements)
 
     def __init__(self, kernel_size=3, channels=32, dilation=1, bias=True, nonlinear_activation="LeakyReLU",
                  nonlinear_activation_params={"negative_slope": 0.2}, pad="ReflectionPad1d", pad_params={},
@@ -39,11 +45,51 @@ class ResidualStack(torch.nn.Module):
             )
         self.skip_layer = Conv1d(channels, channels, 1, bias=bias)
 
+    def _unit_image(self, convs):
+        """MFMA A-operand image of the three weights for the current parameter values (cached)."""
+        key = tuple(cv._params_key() for cv in convs)
+        if getattr(self, "_unit_key", None) != key:
+            hs = [cv.prepared() for cv in convs]
+            with torch.no_grad():
+                self._unit_img = ops.resstack_pack_weight(hs[0].w, hs[0].scale, hs[1].w, hs[1].scale, hs[2].w, hs[2].scale)
+            self._unit_key = key
+        return self._unit_img
+
+    def _unit_ok(self, c, a0, conv0, a1, conv1):
+        if not self.fuse_unit or self.use_causal_conv or not c.is_cuda or c.dim() != 3 or c.dtype != torch.float32:
+            return False
+        skip = self.skip_layer
+        if any(cv.has_spectral_norm or cv.groups != 1 or cv.stride != 1 for cv in (conv0, conv1, skip)):
+            return False
+        if (conv0.kernel_size != 3 or conv0.pad_mode != "reflect" or conv0.padding != conv0.dilation
+                or conv0.padding_right != conv0.dilation or conv1.kernel_size != 1 or skip.kernel_size != 1):
+            return False
+        if a0.kind != "leaky_relu" or a1.kind != "leaky_relu" or a0.slope != a1.slope or not 0.0 < a0.slope < 1.0:
+            return False
+        ch = conv0.in_channels
+        if any(cv.in_channels != ch or cv.out_channels != ch for cv in (conv0, conv1, skip)) or c.shape[1] != ch:
+            return False
+        return ops.resstack_supported(ch, c.shape[2], conv0.dilation)
+
     def forward(self, c):
         if self.use_causal_conv:
             a0, conv0, a1, conv1 = self.stack[0], self.stack[1], self.stack[2], self.stack[3]
         else:
             a0, conv0, a1, conv1 = self.stack[0], self.stack[2], self.stack[3], self.stack[4]
+        if self._unit_ok(c, a0, conv0, a1, conv1):
+            convs = (conv0, conv1, self.skip_layer)
+            c = c.contiguous()
+            bias = [None if cv.bias is None else cv.bias.detach() for cv in convs]
+            needs_grad = torch.is_grad_enabled() and (c.requires_grad or any(p.requires_grad for p in self.parameters()))
+            with torch.no_grad():
+                y, h = ops.resstack_forward(c, self._unit_image(convs), conv0.dilation, a0.slope, *bias, save_h=needs_grad)
+            if not needs_grad:
+                return y
+            # the three layers' autograd nodes, without their launches: the values come from the one-launch unit, the
+            # backward pass is the layers' own (the skip branch's value is never read: only its gradient path matters)
+            skip = self.skip_layer(c, precomputed=torch.empty_like(y))
+            t = conv0(c, pre_act=a0.kind, pre_slope=a0.slope, precomputed=h)
+            return conv1(t, pre_act=a1.kind, pre_slope=a1.slope, add1=skip, precomputed=y)
         skip = self.skip_layer(c)
         t = conv0(c, pre_act=a0.kind, pre_slope=a0.slope)
         return conv1(t, pre_act=a1.kind, pre_slope=a1.slope, add1=skip)

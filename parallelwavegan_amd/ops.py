@@ -184,6 +184,35 @@ def resunit_forward(desc, x, w1_packed, b1, w2_packed=None, b2=None, add2=None, 
     return out
 
 
+def resstack_supported(channels, t, dilation):
+    """Does the one-launch MelGAN residual stack (csrc/resstack.hip) cover this geometry?"""
+    return bool(_lib.lib().pwg_resstack_supported(int(channels), int(t), int(dilation)))
+
+
+def resstack_pack_weight(w1, s1, w2, s2, ws, ss):
+    """(C, C, 3), (C, C, 1), (C, C, 1) weights (+ optional weight-norm row scales) -> the unit's MFMA A-operand image."""
+    _require_device(w1, s1, w2, s2, ws, ss)
+    c = w1.shape[0]
+    n = _lib.lib().pwg_resstack_packed_weight_floats(c)
+    if n == 0:
+        _lib.check(-1, "resstack_packed_weight_floats")
+    out = torch.empty(n, device=w1.device, dtype=torch.float32)
+    _lib.check(_lib.lib().pwg_resstack_pack_weight(c, _ptr(w1), _ptr(s1), _ptr(w2), _ptr(s2), _ptr(ws), _ptr(ss), _ptr(out),
+                                                   _stream()), "resstack_pack_weight")
+    return out
+
+
+def resstack_forward(x, w_packed, dilation, slope, b1=None, b2=None, bs=None, save_h=False):
+    """y (and h, the dilated convolution's pre-activation output, when ``save_h``) of one residual stack."""
+    _require_device(x, w_packed, b1, b2, bs)
+    b, c, t = x.shape
+    y = torch.empty_like(x)
+    h = torch.empty_like(x) if save_h else None
+    _lib.check(_lib.lib().pwg_resstack_forward(b, c, t, int(dilation), float(slope), _ptr(x), _ptr(w_packed), _ptr(b1), _ptr(b2),
+                                               _ptr(bs), _ptr(y), _ptr(h), _stream()), "resstack_forward")
+    return y, h
+
+
 def make_wavenet_desc(batch, t, dilation, residual_channels=64, gate_channels=128, skip_channels=64, aux_channels=80,
                       kernel=3, causal=False, out_mul=1.0, skip_mul=1.0):
     return WaveNetDesc(int(batch), int(t), int(residual_channels), int(gate_channels), int(skip_channels),
