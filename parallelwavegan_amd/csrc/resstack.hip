@@ -16,10 +16,11 @@
 //   * the reduction loops have no barrier and no DMA: B operands are LDS reads, A operands (weights) stream from L2
 //     through a pre-swizzled image whose 16-B records are v_mfma_f32_32x32x2_f32 A operands, three 8-channel-pair
 //     groups ahead in a register ring.  A 1 x 1 convolution needs no halo, so nothing is recomputed.
-// Every wave owns ONE 32 x 32 accumulator tile: waves = (C / 32 row blocks) x (N / 32 column groups):
-//     C = 192: 6 x 2 = 12 waves, N = 64, 141 KB of LDS (one workgroup per CU, three waves per SIMD);
-//     C =  96: 3 x 2 =  6 waves, N = 64,  71 KB (two workgroups per CU);
-//     C =  48: 2 x 3 =  6 waves, N = 96,  47 KB (three per CU; rows 48..63 of the second row block are zero weights).
+// Every wave owns ONE 32 x 32 accumulator tile: 12 waves = (C / 32 row blocks) x (N / 32 column groups), one workgroup
+// per CU (three waves per SIMD):
+//     C = 192: 6 x 2, N =  64, 141 KB of LDS;     C = 96: 3 x 4, N = 128, 120 KB;
+//     C =  48: 2 x 6, N = 192,  84 KB (rows 48..63 of the second row block are zero weights).
+// (Measured against 6-wave workgroups with N = 64 / 96, two per CU: C96 178 -> 133 us, C48 122 -> 110 us per unit at B64.)
 // HBM traffic of a unit: x read once, y written once (+ h written once in training) instead of seven passes.
 #include "common.h"
 
@@ -49,10 +50,10 @@ struct ResStackArgs {
 template <int C>
 struct RsCfg {
   static constexpr int MB = (C + 31) / 32;           // 32-row blocks
-  static constexpr int NG = C == 48 ? 3 : 2;         // 32-column groups
+  static constexpr int NG = C == 48 ? 6 : (C == 96 ? 4 : 2);  // 32-column groups
   static constexpr int N = 32 * NG;                  // output columns per workgroup
   static constexpr int NW = MB * NG;                 // waves
-  static constexpr int XS = C == 48 ? 152 : 120;     // x-tile row stride (floats) >= N + 28 + 27, multiple of 4
+  static constexpr int XS = N + 56;                  // x-tile row stride (floats) >= N + 28 + 27, multiple of 4
   static constexpr int CP = C / 2;                   // channel pairs = MFMA k-steps per source
   static constexpr int GPT = CP / 8;                 // operand groups (8 channel pairs) per source: 3 / 6 / 12
   static constexpr int SRC_FLOATS = (CP / 4) * 256;  // floats of one (row block, source) of the packed image
@@ -116,7 +117,7 @@ __device__ __forceinline__ void rs_contract(const float* __restrict__ al, const 
 }
 
 template <int C>
-__global__ __launch_bounds__(64 * RsCfg<C>::NW, C == 192 ? 1 : 2) void resstack_kernel(ResStackArgs a) {
+__global__ __launch_bounds__(64 * RsCfg<C>::NW, 1) void resstack_kernel(ResStackArgs a) {
   using Cfg = RsCfg<C>;
   constexpr int NG = Cfg::NG, N = Cfg::N, NW = Cfg::NW, XS = Cfg::XS, CP = Cfg::CP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -242,8 +243,8 @@ static bool resstack_geometry(int channels, int t, int dilation, int* hl, int* x
   if (channels != 48 && channels != 96 && channels != 192) return false;
   if (t < 64 || (t & 3) || dilation < 1 || dilation > 27 || dilation >= t) return false;
   if ((long)channels * t * 4 >= (1L << 32)) return false;  // one buffer descriptor per item
-  const int n = channels == 48 ? RsCfg<48>::N : RsCfg<96>::N;
-  const int xs = channels == 48 ? RsCfg<48>::XS : RsCfg<96>::XS;
+  const int n = channels == 48 ? RsCfg<48>::N : channels == 96 ? RsCfg<96>::N : RsCfg<192>::N;
+  const int xs = n + 56;
   *hl = (dilation + 3) & ~3;
   const int need = n + *hl + dilation;
   *xw4 = (need + 3) / 4;
@@ -297,8 +298,8 @@ int pwg_resstack_forward(int32_t batch, int32_t channels, int32_t t, int32_t dil
   a.x = x; a.w = w_packed; a.b1 = b1; a.b2 = b2; a.bs = bs; a.y = y; a.h = h;
   a.T = t; a.d = dilation; a.hl = hl; a.xw4 = xw4; a.slope = slope;
   void (*kern)(ResStackArgs) = channels == 48 ? resstack_kernel<48> : channels == 96 ? resstack_kernel<96> : resstack_kernel<192>;
-  const int n = channels == 48 ? RsCfg<48>::N : RsCfg<96>::N;
-  const int xs = channels == 48 ? RsCfg<48>::XS : RsCfg<96>::XS;
+  const int n = channels == 48 ? RsCfg<48>::N : channels == 96 ? RsCfg<96>::N : RsCfg<192>::N;
+  const int xs = n + 56;
   const int nw = channels == 48 ? RsCfg<48>::NW : channels == 96 ? RsCfg<96>::NW : RsCfg<192>::NW;
   const size_t lds = (size_t)channels * (xs + n) * sizeof(float);
   if (lds > 64 * 1024 && !lds_limit_is_set(reinterpret_cast<const void*>(kern), lds)) {
