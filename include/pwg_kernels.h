@@ -262,6 +262,19 @@ int pwg_resstack_pack_weight(int32_t channels, const float* w1, const float* sca
 int pwg_resstack_forward(int32_t batch, int32_t channels, int32_t t, int32_t dilation, float slope, const float* x,
                          const float* w_packed, const float* b1, const float* b2, const float* bs, float* y, float* h,
                          void* stream);
+/* Data gradient of the same unit in ONE launch (the backward of the three convolutions' data paths and of both
+ * LeakyReLUs, layers/residual_stack.py:45-85 under autograd), in the padded domain of the dilated convolution:
+ *   dh[t]  = lrelu'(h[t]) * (W2^T dy)[t]                                              (batch, channels, t)
+ *   dxp[p] = lrelu'(xp[p]) * sum_tap (W1[tap]^T dh)[p - tap*dilation] + (Ws^T dy)[p - dilation]   (batch, channels, t + 2*dilation)
+ * with xp = ReflectionPad1d(dilation)(x) and dy, dh zero outside [0, t): dx = pwg_pad1d_backward(dxp) (the
+ * reflection's adjoint), dh is the dilated layer's weight-gradient operand.  `h` as written by pwg_resstack_forward;
+ * weights re-laid (transposed) by pwg_resstack_pack_weight_bwd (same size as the forward image).                  */
+int pwg_resstack_pack_weight_bwd(int32_t channels, const float* w1, const float* scale1, const float* w2,
+                                 const float* scale2, const float* ws, const float* scale_s, float* w_packed,
+                                 void* stream);
+int pwg_resstack_backward_data(int32_t batch, int32_t channels, int32_t t, int32_t dilation, float slope,
+                               const float* dy, const float* h, const float* x, const float* w_packed_bwd, float* dh,
+                               float* dxp, void* stream);
 
 /* One gated residual layer of the Parallel WaveGAN generator as ONE launch (csrc/wavenet.hip):
  *   z = conv_{k=3,dilation}(x) + b_dil + conv1x1_aux(c);  g = tanh(z[:64]) * sigmoid(z[64:]);

@@ -155,6 +155,8 @@ SIGNATURES = {
     "pwg_resstack_packed_weight_floats": (ctypes.c_size_t, [_i32]),
     "pwg_resstack_pack_weight": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pwg_resstack_forward": (ctypes.c_int, [_i32, _i32, _i32, _i32, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pwg_resstack_pack_weight_bwd": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pwg_resstack_backward_data": (ctypes.c_int, [_i32, _i32, _i32, _i32, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pwg_wavenet_layer_supported": (ctypes.c_int, [ctypes.POINTER(WaveNetDesc)]),
     "pwg_wavenet_packed_weight_floats": (ctypes.c_size_t, [ctypes.POINTER(WaveNetDesc)]),
     "pwg_wavenet_pack_weights": (ctypes.c_int, [ctypes.POINTER(WaveNetDesc)] + [_vp] * 10),

@@ -103,6 +103,7 @@ __device__ __forceinline__ void rs_contract(const float* __restrict__ al, const 
     load_a(A[2], 2);
   }
   load_b(B[0], 0);
+#pragma unroll 1
   for (int g = 0; g < ngroups; g += 3) {
     const float slope = slope0 + (g / GPT) * dslope;  // (a triple never straddles two sources: GPT % 3 == 0)
 #pragma unroll
@@ -213,6 +214,221 @@ __global__ __launch_bounds__(64 * RsCfg<C>::NW, 1) void resstack_kernel(ResStack
   }
 }
 
+// The same contraction for TWO column tiles that share the A stream (one source, no activation): data-gradient phase A.
+template <int CP>
+__device__ __forceinline__ void rs_contract2(const float* __restrict__ al, const float* b0a, const float* b0b, int rs, int lhi,
+                                             f32x16& acc0, f32x16& acc1, float4 (&A)[3][2], bool primed) {
+  constexpr int GPT = CP / 8;
+  float B[3][16];
+  auto load_a = [&](float4(&A2)[2], int g) {
+    const float* p = al + (long)g * 512;
+    A2[0] = *reinterpret_cast<const float4*>(p);
+    A2[1] = *reinterpret_cast<const float4*>(p + 256);
+  };
+  auto load_b = [&](float(&Bg)[16], int g) {
+    const int o = (16 * g + lhi) * rs;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      Bg[i] = b0a[o + 2 * i * rs];
+      Bg[8 + i] = b0b[o + 2 * i * rs];
+    }
+  };
+  auto mma = [&](const float4(&A2)[2], const float(&Bg)[16]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4& q = A2[i >> 2];
+      const float av = (i & 3) == 0 ? q.x : (i & 3) == 1 ? q.y : (i & 3) == 2 ? q.z : q.w;
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Bg[i], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Bg[8 + i], acc1, 0, 0, 0);
+    }
+  };
+  if (!primed) {
+    load_a(A[0], 0);
+    load_a(A[1], 1);
+    load_a(A[2], 2);
+  }
+  load_b(B[0], 0);
+#pragma unroll 1
+  for (int g = 0; g < GPT; g += 3) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      load_b(B[(s + 1) % 3], g + s + 1 < GPT ? g + s + 1 : GPT - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(A[s], B[s]);
+      load_a(A[s], g + s + 3);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Data gradient of the unit, one launch, in the PADDED domain of the dilated convolution (p = t + d in [0, T + 2d)):
+//
+//     dh[t]  = lrelu'(h[t]) * (W2^T dy)[t]                                     (gradient w.r.t. the dilated convolution's output)
+//     dxp[p] = lrelu'(xp[p]) * sum_tap (W1[tap]^T dh)[p - tap d]  +  (Ws^T dy)[p - d]   (xp = reflect-padded x; dy, dh = 0 outside [0, T))
+//
+// dx = the reflection's adjoint applied to dxp (pwg_pad1d_backward: one streaming launch), dh is the dilated layer's
+// weight-gradient operand.  A workgroup owns N columns of p and stages the window [p0 - 2d, p0 + N) of dy (N + 64
+// columns) once: phase A contracts W2^T with the whole window (two column tiles per wave: the h-masked result replaces
+// dy in the LDS tile) and Ws^T with the owned columns; phase B contracts the three taps of W1^T with the dh tile.
+// The weight stream ([W2^T][Ws^T][W1^T tap 0..2] per row block) runs through the same register ring as the forward pass.
+// ---------------------------------------------------------------------------------------------------------------------
+struct ResStackBwdArgs {
+  const float* dy;
+  const float* h;
+  const float* x;
+  const float* w;  // packed image, see resstack_pack_bwd_kernel
+  float* dh;
+  float* dxp;
+  int T;
+  int d;
+  float slope;
+};
+
+template <int C>
+__global__ __launch_bounds__(64 * RsCfg<C>::NW, 1) void resstack_bwd_kernel(ResStackBwdArgs a) {
+  using Cfg = RsCfg<C>;
+  constexpr int NG = Cfg::NG, N = Cfg::N, NW = Cfg::NW, CP = Cfg::CP;
+  constexpr int NA = N + 64;    // window columns (2 d <= 54)
+  constexpr int NGA = NA / 32;  // its 32-column groups
+  constexpr int TS = NA;        // LDS row stride
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [C][TS]: the dy window, then the dh window
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / NG, wn = wave - wm * NG;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int b = blockIdx.y;
+  const int p0 = blockIdx.x * N;
+  const int j0 = p0 - 2 * a.d;  // sample of window column 0
+  const int T = a.T, Tp = a.T + 2 * a.d;
+
+  // ---- stage the dy window (zero outside the sequence)
+  {
+    __amdgpu_buffer_rsrc_t rs = uniform_buffer_rsrc(a.dy + (long)b * C * T, (unsigned)(C * T) * 4u);
+    if (__builtin_amdgcn_readfirstlane((j0 >= 0 && j0 + NA <= T) ? 1 : 0)) {
+      for (int r = wave; r < C; r += NW)
+        if (lane < NA / 4) {
+          const unsigned off = (unsigned)(r * T + j0 + 4 * lane) * 4u;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(tile + r * TS), 16, off, 0, 0, 0);
+        }
+    } else {
+      for (int r = wave; r < C; r += NW)
+        for (int i0 = 0; i0 < NA; i0 += 64) {
+          const int i = i0 + lane, j = j0 + i;
+          const unsigned off = (i < NA && j >= 0 && j < T) ? (unsigned)(r * T + j) * 4u : 0xFFFFFFFCu;
+          if (i < NA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(tile + r * TS + i0), 4, off, 0, 0, 0);
+        }
+    }
+  }
+  f32x16 acc0, acc1, acc_s, acc_b;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+  // phase A column groups of this wave (the second one may repeat another wave's: same values, written twice)
+  const int ga0 = wn, ga1 = wn + NG < NGA ? wn + NG : NGA - 1;
+  const int i0c = ga0 * 32 + l31, i1c = ga1 * 32 + l31;  // window columns of this lane
+  const int ja = j0 + i0c, jb = j0 + i1c;
+  const bool ja_ok = ja >= 0 && ja < T, jb_ok = jb >= 0 && jb < T;
+  const int m = wn * 32 + l31;  // this lane's owned column: p = p0 + m
+  const int p = p0 + m;
+  // LeakyReLU masks of this lane's elements as bit sets (bit r = row r of the accumulator layout): h at the 2 x 16
+  // phase-A elements, x (the reflected sample of the padded position p) at the 16 outputs.  The loads fly beside the
+  // window's DMA; only three registers stay live through the contractions.
+  unsigned hm0 = 0, hm1 = 0, xm = 0;
+  {
+    const float* hb = a.h + (long)b * C * T;
+    const float* xb = a.x + (long)b * C * T;
+    int f = p - a.d;
+    if (f < 0) f = -f;
+    if (f >= T) f = 2 * (T - 1) - f;
+    if (f < 0 || f >= T) f = 0;  // (p >= T + 2 d: not stored)
+    float hv0[16], hv1[16], xv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = wm * 32 + 8 * (r >> 2) + 4 * lhi + (r & 3);
+      const long row = (long)(c < C ? c : C - 1) * T;
+      hv0[r] = hb[row + (ja_ok ? ja : 0)];
+      hv1[r] = hb[row + (jb_ok ? jb : 0)];
+      xv[r] = xb[row + f];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      hm0 |= (hv0[r] > 0.f ? 1u : 0u) << r;
+      hm1 |= (hv1[r] > 0.f ? 1u : 0u) << r;
+      xm |= (xv[r] > 0.f ? 1u : 0u) << r;
+    }
+  }
+  float4 A[3][2];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- phase A: W2^T (*) dy over the window, Ws^T (*) dy at the owned columns (window column m + d)
+  const float* wl = a.w + (long)wm * 5 * Cfg::SRC_FLOATS + lane * 4;
+  rs_contract2<CP>(wl, tile + i0c, tile + i1c, TS, lhi, acc0, acc1, A, false);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc_s[r] = 0.f;
+  rs_contract<CP>(wl + Cfg::SRC_FLOATS, tile + m + a.d, 0, TS, 0, 1.f, 0.f, 1, lhi, acc_s, A, true);
+  __syncthreads();  // every wave is done reading the dy window
+  {
+    float* dhb = a.dh + (long)b * C * T;
+    const bool own0 = i0c >= 2 * a.d && i0c < 2 * a.d + N && ja_ok;
+    const bool own1 = i1c >= 2 * a.d && i1c < 2 * a.d + N && jb_ok;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = wm * 32 + 8 * (r >> 2) + 4 * lhi + (r & 3);
+      if (c < C) {
+        const float v0 = ja_ok ? acc0[r] * ((hm0 >> r) & 1u ? 1.f : a.slope) : 0.f;
+        const float v1 = jb_ok ? acc1[r] * ((hm1 >> r) & 1u ? 1.f : a.slope) : 0.f;
+        tile[c * TS + i0c] = v0;
+        tile[c * TS + i1c] = v1;
+        if (own0) dhb[(long)c * T + ja] = v0;
+        if (own1) dhb[(long)c * T + jb] = v1;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase B: sum over taps of W1[tap]^T (*) dh at window column m + 2 d - tap d
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc_b[r] = 0.f;
+  rs_contract<CP>(wl + 2 * Cfg::SRC_FLOATS, tile + m + 2 * a.d, -a.d, TS, 0, 1.f, 0.f, 3, lhi, acc_b, A, true);
+  if (p < Tp) {
+    float* ob = a.dxp + (long)b * C * Tp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = wm * 32 + 8 * (r >> 2) + 4 * lhi + (r & 3);
+      if (c < C) ob[(long)c * Tp + p] = acc_b[r] * ((xm >> r) & 1u ? 1.f : a.slope) + acc_s[r];
+    }
+  }
+}
+
+// backward image: [row block mb of INPUT channels][source: W2^T, Ws^T, W1^T tap 0, 1, 2][output-channel pair / 4][lane][4]
+// (+ 3 groups of padding): lane -> (row = input channel mb * 32 + (lane & 31), k = output channel 2 cp + (lane >> 5));
+// weight-norm scales belong to the output channel, i.e. to k here.
+__global__ void resstack_pack_bwd_kernel(const float* w1, const float* s1, const float* w2, const float* s2, const float* ws,
+                                         const float* ss, float* out, int C, int total) {
+  const int mbs = (C + 31) / 32, q4 = C / 8;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int j = i & 3;
+    const int lane = (i >> 2) & 63;
+    int r = i >> 8;
+    const int q = r % q4;
+    r /= q4;
+    const int src = r % 5;
+    const int mb = r / 5;
+    float v = 0.f;
+    const int ci = mb * 32 + (lane & 31);
+    const int co = 2 * (4 * q + j) + (lane >> 5);
+    if (mb < mbs && ci < C) {
+      if (src == 0) v = w2[(long)co * C + ci] * (s2 ? s2[co] : 1.f);
+      else if (src == 1) v = ws[(long)co * C + ci] * (ss ? ss[co] : 1.f);
+      else v = w1[((long)co * C + ci) * 3 + (src - 2)] * (s1 ? s1[co] : 1.f);
+    }
+    out[i] = v;
+  }
+}
+
 // packed image: [row block mb][source: W1 tap 0, 1, 2, W2, Ws][channel pair / 4][lane][4] (+ 3 groups of padding);
 // element j of a lane's 16 B is the A operand of channel pair cp = 4 q + j: lane -> (row = mb * 32 + (lane & 31),
 // channel = 2 cp + (lane >> 5)) of v_mfma_f32_32x32x2_f32; rows >= C are zero.
@@ -318,5 +534,52 @@ int pwg_resstack_forward(int32_t batch, int32_t channels, int32_t t, int32_t dil
   PWG_CHECK_LAUNCH("resstack_forward");
   return PWG_OK;
 }
+
+int pwg_resstack_pack_weight_bwd(int32_t channels, const float* w1, const float* scale1, const float* w2, const float* scale2,
+                                 const float* ws, const float* scale_s, float* w_packed, void* stream) {
+  PWG_REQUIRE(w1 && w2 && ws && w_packed, PWG_ERR_NULL, "resstack_pack_weight_bwd: null pointer");
+  PWG_REQUIRE(channels == 48 || channels == 96 || channels == 192, PWG_ERR_UNSUPPORTED,
+              "resstack_pack_weight_bwd: channels=%d", channels);
+  const int total = (int)resstack_image_floats(channels);
+  hipLaunchKernelGGL(resstack_pack_bwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, w1, scale1, w2,
+                     scale2, ws, scale_s, w_packed, channels, total);
+  PWG_CHECK_LAUNCH("resstack_pack_weight_bwd");
+  return PWG_OK;
+}
+
+int pwg_resstack_backward_data(int32_t batch, int32_t channels, int32_t t, int32_t dilation, float slope, const float* dy,
+                               const float* h, const float* x, const float* w_packed_bwd, float* dh, float* dxp,
+                               void* stream_) {
+  PWG_REQUIRE(dy && h && x && w_packed_bwd && dh && dxp, PWG_ERR_NULL, "resstack_backward_data: null pointer");
+  int hl, xw4;
+  PWG_REQUIRE(resstack_geometry(channels, t, dilation, &hl, &xw4) && batch >= 1 && batch <= 65535, PWG_ERR_UNSUPPORTED,
+              "resstack_backward_data: unsupported unit (C=%d T=%d d=%d B=%d)", channels, t, dilation, batch);
+  PWG_REQUIRE(slope > 0.f && slope < 1.f, PWG_ERR_UNSUPPORTED, "resstack_backward_data: LeakyReLU slope %g outside (0, 1)", slope);
+  hipStream_t stream = (hipStream_t)stream_;
+  ResStackBwdArgs a;
+  a.dy = dy; a.h = h; a.x = x; a.w = w_packed_bwd; a.dh = dh; a.dxp = dxp;
+  a.T = t; a.d = dilation; a.slope = slope;
+  void (*kern)(ResStackBwdArgs) =
+      channels == 48 ? resstack_bwd_kernel<48> : channels == 96 ? resstack_bwd_kernel<96> : resstack_bwd_kernel<192>;
+  const int n = channels == 48 ? RsCfg<48>::N : channels == 96 ? RsCfg<96>::N : RsCfg<192>::N;
+  const int nw = channels == 48 ? RsCfg<48>::NW : channels == 96 ? RsCfg<96>::NW : RsCfg<192>::NW;
+  const size_t lds = (size_t)channels * (n + 64) * sizeof(float);
+  if (lds > 64 * 1024 && !lds_limit_is_set(reinterpret_cast<const void*>(kern), lds)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    PWG_REQUIRE(e == hipSuccess, PWG_ERR_LAUNCH, "resstack_backward_data: cannot raise LDS limit to %zu: %s", lds,
+                hipGetErrorString(e));
+  }
+  const double C = channels;
+  const double elems = (double)batch * C * t;
+  maybe_poison_lds(stream);
+  {
+    ProfScope prof(stream, prof_shape_name("resstack_bwd_kernel", "resstack_bwd_kernel B%d C%d T%d d%d", batch, channels, t, dilation),
+                   2.0 * elems * C * 5, 4.0 * (elems * 5 + 5 * C * C));
+    hipLaunchKernelGGL(kern, dim3(ceil_div(t + 2 * dilation, n), batch), dim3(64 * nw), lds, stream, a);
+  }
+  PWG_CHECK_LAUNCH("resstack_backward_data");
+  return PWG_OK;
+}
+
 
 }  // extern "C"

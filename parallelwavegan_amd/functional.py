@@ -479,6 +479,78 @@ class WaveNetLayerFn(torch.autograd.Function):
         return (dx, dc, (gs if ctx.has_skips else None), None, None) + tuple(grads)
 
 
+class ResStackFn(torch.autograd.Function):
+    """One MelGAN residual stack (layers/residual_stack.py:75-85 of the reference): forward = ONE launch
+    (csrc/resstack.hip, also writes the dilated convolution's output h for this backward); backward = the unit's data
+    gradient in one launch (dh and the padded-domain dx), the reflection's adjoint, and the three layers' own
+    weight-gradient kernels.
+
+    ``stack``: the :class:`layers.ResidualStack`.  Tensor arguments after it are its parameters in the order of
+    ``stack.unit_params()`` -- passed so that autograd routes their gradients; values are read through ``stack``."""
+
+    @staticmethod
+    def forward(ctx, x, stack, *params):
+        x = _c(x)
+        _require_device(x)
+        convs = stack.unit_convs()
+        d, slope = convs[0].dilation, stack.unit_slope()
+        bias = [None if cv.bias is None else cv.bias.detach() for cv in convs]
+        y, h = ops.resstack_forward(x, stack.unit_image(), d, slope, *bias, save_h=True)
+        ctx.stack, ctx.geom = stack, (d, slope)
+        ctx.holders = [cv.prepared() for cv in convs]  # (the parameter values this forward used)
+        ctx.param_keys = tuple(cv._params_key()[1:] for cv in convs)
+        ctx.save_for_backward(x, h)
+        ctx.set_materialize_grads(False)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, h = ctx.saved_tensors
+        stack = ctx.stack
+        convs = stack.unit_convs()
+        n_par = [1 + int(cv.has_weight_norm) + int(cv.bias is not None) for cv in convs]
+        if dy is None:
+            return (None, None) + (None,) * sum(n_par)
+        if tuple(cv._params_key()[1:] for cv in convs) != ctx.param_keys:
+            raise RuntimeError("ResStackFn.backward: a parameter of the unit was modified after the forward pass")
+        d, slope = ctx.geom
+        dy = _c(dy)
+        _require_device(dy)
+        b, c, t = x.shape
+        need = ctx.needs_input_grad
+        dh, dxp = ops.resstack_backward_data(dy, h, x, stack.unit_image_bwd(), d, slope)
+        dx = None
+        if need[0]:
+            dx = torch.empty_like(x)
+            _lib.check(_L().pwg_pad1d_backward(_ptr(dxp), _ptr(dx), b * c, t, d, d, ops.PAD["reflect"], _stream()),
+                       "pad1d_backward")
+        # weight path: the three layers' own kernels (dilated layer: on the explicitly padded input, as its un-fused
+        # autograd node does)
+        xp = torch.empty((b, c, t + 2 * d), device=x.device, dtype=torch.float32)
+        _lib.check(_L().pwg_pad1d_forward(_ptr(x), _ptr(xp), b * c, t, d, d, ops.PAD["reflect"], _stream()), "pad1d_forward")
+        descs = (ops.make_conv_desc(b, c, c, t + 2 * d, t, 3, dilation=d, pre_act="leaky_relu", pre_slope=slope),
+                 ops.make_conv_desc(b, c, c, t, t, 1, pre_act="leaky_relu", pre_slope=slope),
+                 ops.make_conv_desc(b, c, c, t, t, 1))
+        grads = []
+        pi = 2
+        for cv, hd, dsc, xin, gsum, n in zip(convs, ctx.holders, descs, (xp, h, x), (dh, dy, dy), n_par):
+            has_g = cv.has_weight_norm
+            need_w = need[pi]
+            need_g = has_g and need[pi + 1]
+            need_b = cv.bias is not None and need[pi + 1 + int(has_g)]
+            v = hd.w
+            g = cv.weight_g.detach() if has_g else None
+            dw, dg, db = conv_param_grads(dsc, xin, gsum, tuple(v.shape), tuple(cv.raw_weight.shape), v, g, need_w,
+                                          need_g, need_b)
+            grads.append(dw)
+            if has_g:
+                grads.append(dg)
+            if cv.bias is not None:
+                grads.append(db)
+            pi += n
+        return (dx, None) + tuple(grads)
+
+
 class Add3DivFn(torch.autograd.Function):
     """((a + b) + c) / div with c optional -- the MRF combine when blocks run as parallel branches."""
 

@@ -3,6 +3,7 @@ import os
 
 import torch
 
+from .. import functional as Fn
 from .. import ops
 from .activation import FusedActivation
 from .causal_conv import CausalConv1d
@@ -17,6 +18,8 @@ class ResidualStack(torch.nn.Module):
     padding fused on its input; 1x1 conv with activation fused on its input and the skip branch fused as addend."""
 
     fuse_unit = os.environ.get("PWG_RESSTACK", "1") != "0"  # (0: the three-launch path, for A/B measurements)
+    # backward of the unit: its data gradient as one launch (functional.ResStackFn) instead of the three layers' own
+    fuse_unit_backward = os.environ.get("PWG_RESSTACK_BWD", "1") != "0"
 
     def __init__(self, kernel_size=3, channels=32, dilation=1, bias=True, nonlinear_activation="LeakyReLU",
                  nonlinear_activation_params={"negative_slope": 0.2}, pad="ReflectionPad1d", pad_params={},
@@ -45,15 +48,41 @@ class ResidualStack(torch.nn.Module):
             )
         self.skip_layer = Conv1d(channels, channels, 1, bias=bias)
 
-    def _unit_image(self, convs):
-        """MFMA A-operand image of the three weights for the current parameter values (cached)."""
+    def unit_convs(self):
+        """(dilated convolution, 1x1 convolution, skip 1x1) of the non-causal form."""
+        return self.stack[2], self.stack[4], self.skip_layer
+
+    def unit_slope(self):
+        return self.stack[0].slope
+
+    def unit_params(self):
+        """Parameters in the order functional.ResStackFn returns their gradients."""
+        ps = []
+        for cv in self.unit_convs():
+            ps.append(cv.raw_weight)
+            if cv.has_weight_norm:
+                ps.append(cv.weight_g)
+            if cv.bias is not None:
+                ps.append(cv.bias)
+        return ps
+
+    def _image(self, attr, pack):
+        convs = self.unit_convs()
         key = tuple(cv._params_key() for cv in convs)
-        if getattr(self, "_unit_key", None) != key:
+        if getattr(self, attr + "_key", None) != key:
             hs = [cv.prepared() for cv in convs]
             with torch.no_grad():
-                self._unit_img = ops.resstack_pack_weight(hs[0].w, hs[0].scale, hs[1].w, hs[1].scale, hs[2].w, hs[2].scale)
-            self._unit_key = key
-        return self._unit_img
+                setattr(self, attr, pack(hs[0].w, hs[0].scale, hs[1].w, hs[1].scale, hs[2].w, hs[2].scale))
+            setattr(self, attr + "_key", key)
+        return getattr(self, attr)
+
+    def unit_image(self):
+        """MFMA A-operand image of the three weights for the current parameter values (cached)."""
+        return self._image("_unit_img", ops.resstack_pack_weight)
+
+    def unit_image_bwd(self):
+        """The same for the unit's data gradient (transposed weights)."""
+        return self._image("_unit_img_bwd", ops.resstack_pack_weight_bwd)
 
     def _unit_ok(self, c, a0, conv0, a1, conv1):
         if not self.fuse_unit or self.use_causal_conv or not c.is_cuda or c.dim() != 3 or c.dtype != torch.float32:
@@ -81,8 +110,10 @@ class ResidualStack(torch.nn.Module):
             c = c.contiguous()
             bias = [None if cv.bias is None else cv.bias.detach() for cv in convs]
             needs_grad = torch.is_grad_enabled() and (c.requires_grad or any(p.requires_grad for p in self.parameters()))
+            if needs_grad and self.fuse_unit_backward:
+                return Fn.ResStackFn.apply(c, self, *self.unit_params())
             with torch.no_grad():
-                y, h = ops.resstack_forward(c, self._unit_image(convs), conv0.dilation, a0.slope, *bias, save_h=needs_grad)
+                y, h = ops.resstack_forward(c, self.unit_image(), conv0.dilation, a0.slope, *bias, save_h=needs_grad)
             if not needs_grad:
                 return y
             # the three layers' autograd nodes, without their launches: the values come from the one-launch unit, the

@@ -213,6 +213,32 @@ def resstack_forward(x, w_packed, dilation, slope, b1=None, b2=None, bs=None, sa
     return y, h
 
 
+def resstack_pack_weight_bwd(w1, s1, w2, s2, ws, ss):
+    """The unit's weights re-laid for its data gradient (transposed; weight-norm scales on the reduction index)."""
+    _require_device(w1, s1, w2, s2, ws, ss)
+    c = w1.shape[0]
+    n = _lib.lib().pwg_resstack_packed_weight_floats(c)
+    if n == 0:
+        _lib.check(-1, "resstack_packed_weight_floats")
+    out = torch.empty(n, device=w1.device, dtype=torch.float32)
+    _lib.check(_lib.lib().pwg_resstack_pack_weight_bwd(c, _ptr(w1), _ptr(s1), _ptr(w2), _ptr(s2), _ptr(ws), _ptr(ss),
+                                                       _ptr(out), _stream()), "resstack_pack_weight_bwd")
+    return out
+
+
+def resstack_backward_data(dy, h, x, w_packed_bwd, dilation, slope):
+    """(dh, dxp): gradient w.r.t. the dilated convolution's output and w.r.t. its reflect-padded input (+ the skip
+    branch's contribution at the interior positions), shapes (B, C, T) and (B, C, T + 2 * dilation)."""
+    _require_device(dy, h, x, w_packed_bwd)
+    b, c, t = x.shape
+    dh = torch.empty_like(x)
+    dxp = torch.empty((b, c, t + 2 * int(dilation)), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().pwg_resstack_backward_data(b, c, t, int(dilation), float(slope), _ptr(dy), _ptr(h), _ptr(x),
+                                                     _ptr(w_packed_bwd), _ptr(dh), _ptr(dxp), _stream()),
+               "resstack_backward_data")
+    return dh, dxp
+
+
 def make_wavenet_desc(batch, t, dilation, residual_channels=64, gate_channels=128, skip_channels=64, aux_channels=80,
                       kernel=3, causal=False, out_mul=1.0, skip_mul=1.0):
     return WaveNetDesc(int(batch), int(t), int(residual_channels), int(gate_channels), int(skip_channels),

@@ -68,8 +68,9 @@ def test_residual_stack_layer_with_and_without_the_one_launch_unit(C, T, d, weig
     x0 = torch.randn(2, C, T, device=device)
     w = torch.randn(2, C, T, device=device)
     res = {}
-    for fused in (False, True):
-        blk.fuse_unit = fused
+    for fused in (False, True, "bwd"):
+        blk.fuse_unit = bool(fused)
+        blk.fuse_unit_backward = fused == "bwd"  # True: one-launch forward + the three layers' own backward nodes
         blk.zero_grad()
         x = x0.clone().requires_grad_()
         with poison_lds(), poison_empty():
@@ -78,8 +79,47 @@ def test_residual_stack_layer_with_and_without_the_one_launch_unit(C, T, d, weig
             with torch.no_grad():
                 y_ng = blk(x0)
         res[fused] = dict(y=y.detach(), y_ng=y_ng, dx=x.grad, **{n: p.grad.clone() for n, p in blk.named_parameters()})
-    assert set(res[True]) == set(res[False])
-    for k, want in res[False].items():
-        got = res[True][k]
-        err = (got - want).abs().max().item() / (want.abs().max().item() + 1e-12)
-        assert err <= 2e-5, (k, err)
+    for mode in (True, "bwd"):
+        assert set(res[mode]) == set(res[False])
+        for k, want in res[False].items():
+            got = res[mode][k]
+            err = (got - want).abs().max().item() / (want.abs().max().item() + 1e-12)
+            assert err <= 2e-5, (mode, k, err)
+
+
+@pytest.mark.parametrize("C,B,T,d", [(48, 2, 4096, 1), (48, 2, 200, 27), (48, 1, 64, 9), (96, 2, 2048, 3), (96, 1, 68, 27),
+                                     (96, 3, 320, 9), (192, 2, 512, 27), (192, 1, 128, 1), (192, 2, 76, 3)])
+def test_resstack_data_gradient_kernel_matches_float64(C, B, T, d, device):
+    """dh and dx of the one-launch data gradient against float64 ATen on the CPU (adjoint of the dilated convolution
+    via conv_transpose1d, adjoint of the reflection via autograd), with the LeakyReLU masks taken from the same h / x."""
+    torch.manual_seed(C + T + 3 * d)
+    slope = 0.2
+    x = torch.randn(B, C, T, device=device)
+    dy = torch.randn(B, C, T, device=device)
+    w1 = torch.randn(C, C, 3, device=device) / (3 * C) ** 0.5
+    w2 = torch.randn(C, C, 1, device=device) / C ** 0.5
+    ws = torch.randn(C, C, 1, device=device) / C ** 0.5
+    s1, s2, ss = (torch.rand(C, device=device) + 0.5 for _ in range(3))
+    b1 = torch.randn(C, device=device)
+    with poison_lds(), poison_empty():
+        img = ops.resstack_pack_weight(w1, s1, w2, s2, ws, ss)
+        _, h = ops.resstack_forward(x, img, d, slope, b1, None, None, save_h=True)
+        imgb = ops.resstack_pack_weight_bwd(w1, s1, w2, s2, ws, ss)
+        dh, dxp = ops.resstack_backward_data(dy, h, x, imgb, d, slope)
+        dh2, dxp2 = ops.resstack_backward_data(dy, h, x, imgb, d, slope)
+    assert torch.equal(dh, dh2) and torch.equal(dxp, dxp2)
+    e1, e2, es = ((w * s.view(-1, 1, 1)).cpu().double() for w, s in ((w1, s1), (w2, s2), (ws, ss)))
+    xc, hc, dyc = x.cpu().double(), h.cpu().double(), dy.cpu().double()
+    want_dh = F.conv_transpose1d(dyc, e2) * torch.where(hc > 0, 1.0, slope)
+    xv = xc.clone().requires_grad_()
+    xp = F.pad(xv, (d, d), mode="reflect")
+    want_dxp = F.conv_transpose1d(want_dh, e1, dilation=d) * torch.where(xp.detach() > 0, 1.0, slope) \
+        + F.pad(F.conv_transpose1d(dyc, es), (d, d))
+    (want_dx,) = torch.autograd.grad(xp, xv, grad_outputs=want_dxp)
+    assert tuple(dxp.shape) == (B, C, T + 2 * d)
+    got_dxp = dxp.cpu().double()
+    xg = x.clone().requires_grad_()
+    (got_dx,) = torch.autograd.grad(F.pad(xg, (d, d), mode="reflect"), xg, grad_outputs=dxp)
+    for name, got, want in (("dh", dh.cpu().double(), want_dh), ("dxp", got_dxp, want_dxp), ("dx", got_dx.cpu().double(), want_dx)):
+        err = (got - want).abs().max().item() / want.abs().max().item()
+        assert err <= 3e-6, (name, err)
