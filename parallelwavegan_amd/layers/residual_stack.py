@@ -98,6 +98,8 @@ class ResidualStack(torch.nn.Module):
         ch = conv0.in_channels
         if any(cv.in_channels != ch or cv.out_channels != ch for cv in (conv0, conv1, skip)) or c.shape[1] != ch:
             return False
+        if not c.is_contiguous() or c.data_ptr() % 16:  # (the x tile is staged with 16-B LDS-DMA pieces)
+            return False
         return ops.resstack_supported(ch, c.shape[2], conv0.dilation)
 
     def forward(self, c):
@@ -107,7 +109,6 @@ class ResidualStack(torch.nn.Module):
             a0, conv0, a1, conv1 = self.stack[0], self.stack[2], self.stack[3], self.stack[4]
         if self._unit_ok(c, a0, conv0, a1, conv1):
             convs = (conv0, conv1, self.skip_layer)
-            c = c.contiguous()
             bias = [None if cv.bias is None else cv.bias.detach() for cv in convs]
             needs_grad = torch.is_grad_enabled() and (c.requires_grad or any(p.requires_grad for p in self.parameters()))
             if needs_grad and self.fuse_unit_backward:
