@@ -128,17 +128,19 @@ def cpu_baseline(g_params, budget_s=(6.0, 14.0)):
     }
 
 
-def cpu_train_baseline(conf, budget_steps=2):
+def cpu_train_baseline(conf, budget_steps=1, batch=None):
     """The reference's own ``Trainer._train_step`` (bin/train.py:189-340; staged copy oracle/_ref) -- or, when that is
-    absent, oracle.train_step, its torch-CPU restatement -- on a B=2 slice of the C3 batch.
-    Reported as an UPPER BOUND on full-batch steps/s: per-step time is assumed linear in the batch."""
+    absent, oracle.train_step, its torch-CPU restatement -- at the recipe's OWN batch (B = 16 x 8192 for C3): one
+    warm-up step, then ``budget_steps`` timed steps (~9 s each on the GPU boxes' hosts)."""
     from oracle import ref_run
 
     cores = os.cpu_count() or 1
     nthreads = min(cores, 32)
     torch.set_num_threads(nthreads)
-    b, full = 2, conf["batch_size"]
-    c, y = torch.randn(b, 80, 32), 0.3 * torch.randn(b, 1, 8192)
+    b = batch or conf["batch_size"]
+    t = conf["batch_max_steps"]
+    gen = torch.Generator(device="cpu").manual_seed(77)
+    c, y = torch.randn(b, 80, t // conf["hop_size"], generator=gen), 0.3 * torch.randn(b, 1, t, generator=gen)
     use_ref = ref_run.available()
     if use_ref:
         tr = ref_run.trainer(conf, ((c,), y))
@@ -163,14 +165,16 @@ def cpu_train_baseline(conf, budget_steps=2):
         step()
     dt = (time.time() - t0) / budget_steps
     return {
-        "value": 1.0 / (dt * full / b),
-        "unit": f"steps/s at B={full} x 8192 -- a BOUND: measured at B={b} and scaled by {full // b}x, not run at full batch",
+        "value": 1.0 / dt,
+        "unit": f"steps/s at B={b} x {t} (the recipe's batch, run as is)",
+        "batch": b,
         "cores": nthreads,
         "kind": "reference" if use_ref else "port",
         "sample": ("parallel_wavegan.bin.train.Trainer._train_step of the unmodified reference package (oracle/_ref), "
                    if use_ref else
                    "oracle.train_step.HiFiGANTrainState.step (restatement of the reference Trainer._train_step), ") +
-                  f"B={b} x 8192 samples, {budget_steps} timed steps ({dt:.2f} s each), {nthreads} of {cores} host threads",
+                  f"B={b} x {t} samples, 1 warm-up + {budget_steps} timed steps ({dt:.2f} s each), "
+                  f"{nthreads} of {cores} host threads",
     }
 
 
@@ -484,6 +488,84 @@ def rccl_log_summary(max_lines=6):
             "algo_proto_counts": algos, "large_allreduce": large, "sample_lines": samples}
 
 
+COMPACT_LIMIT = 1900  # the driver keeps a 2000-byte tail of stdout: the ONE stdout line must fit inside it
+
+
+def _r(x, nd=4):
+    return round(x, nd) if isinstance(x, float) else x
+
+
+def compact_line(out):
+    """The single stdout line: every key of the bench contract + roofline + cpu_baseline + parity + the per-config
+    training steps/s, well under the driver's 2000-byte stdout tail.  The full record (per-kernel tables, loss
+    histories, latency, distributed detail) goes to ``gpurun_out/bench_detail.json`` and to stderr."""
+    rf, cb, par, tr = out.get("roofline"), out.get("cpu_baseline"), out.get("parity"), out.get("train")
+    cfg = out["config"]
+    line = {
+        "metric": out["metric"], "value": _r(out["value"], 1), "unit": out["unit"], "n_gpus": out["n_gpus"],
+        "steps": out["steps"], "warmup": out["warmup"], "ms_per_step": _r(out["ms_per_step"]),
+        "higher_is_better": True, "scaling": out["scaling"], "vs_baseline": out["vs_baseline"], "dtype": out["dtype"],
+        "data": out["data"],
+        "config": {"workload": f"HiFi-GAN V1 generator fwd, LJSpeech 22.05 kHz, B{cfg['batch_per_gpu']} x "
+                               f"{cfg['frames']} mel frames per GPU, fp32, random init",
+                   "global_batch": cfg["batch_per_gpu"] * out["n_gpus"], "parallelism": cfg["parallelism"]},
+    }
+    if rf:
+        line["roofline"] = {k: _r(rf.get(k), 4 if k == "frac" else 2) for k in
+                            ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
+                             "avg_launch_us", "flops_per_launch", "algorithmic_bytes_per_launch")}
+        line["roofline"]["launches"] = rf.get("launches_timed")
+    if cb:
+        line["cpu_baseline"] = {"value": _r(cb["value"], 1), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                "sample": f"reference HiFiGANGenerator B1 x 800 frames, best of {cb['frames_800']['calls']}"
+                                if cb["kind"] == "reference" else "oracle restatement B1 x 800 frames"}
+    if par:
+        line["parity"] = {"max_abs_vs_oracle": float(f"{par['max_abs_vs_oracle']:.3g}"), "tol": par["tolerance"],
+                          "ok": par["ok"]}
+    line["train_steps_per_s"] = out.get("train_steps_per_s")
+    line["train_ok"] = out.get("train_ok")
+    line["hip_graph"] = out.get("hip_graph")
+    if tr:
+        line["train"] = {"config": out.get("train_config"), "batch_per_gpu": tr.get("batch_per_gpu"),
+                         "ms_per_step": _r(tr.get("ms_per_step"), 3),
+                         "frac_of_fp32_peak": _r(tr.get("reference_flop_frac_of_fp32_matrix_peak"), 4)}
+        tcb = tr.get("cpu_baseline")
+        if tcb:
+            line["train"]["cpu_baseline"] = {"value": _r(tcb["value"], 4), "unit": "steps/s", "batch": tcb.get("batch"),
+                                             "cores": tcb["cores"], "kind": tcb["kind"]}
+        d = tr.get("dist")
+        if d:
+            rc = d.get("rccl") or {}
+            line["train"]["dist"] = {"backend": d["backend"], "world_size": d["world_size"],
+                                     "exposed_comm_ms_per_exchange": {k: _r(v, 3) for k, v in
+                                                                      d.get("exposed_comm_ms_per_exchange", {}).items()},
+                                     "rccl": {"nranks": rc.get("nranks"), "large_allreduce": rc.get("large_allreduce")}}
+    line["detail"] = out.get("detail_file")
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > COMPACT_LIMIT:  # never exceed the tail: drop the optional objects, least important first
+        for key in ("detail", "train", "parity"):
+            line.pop(key, None)
+            text = json.dumps(line, separators=(",", ":"))
+            if len(text) <= COMPACT_LIMIT:
+                break
+    return text
+
+
+def write_detail(out):
+    """Full record -> gpurun_out/bench_detail.json (merged back by gpurun) and stderr; returns the path or None."""
+    text = json.dumps(out)
+    print("[bench detail] " + text, file=sys.stderr, flush=True)
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, os.environ.get("PWG_BENCH_DETAIL", "bench_detail.json"))
+        with open(path, "w") as f:
+            f.write(text + "\n")
+        return os.path.relpath(path, ROOT)
+    except OSError:
+        return None
+
+
 def self_launch(args):
     """``python bench.py --gpus N`` without a launcher: one rank per GPU through the package's launcher."""
     from parallelwavegan_amd.distributed import launch
@@ -647,6 +729,7 @@ def main():
             "traffic": traffic,
             "traffic_source": traffic_src,
             "launches_per_step": r["launches"] / prof_steps,
+            "launches_timed": r["launches"],
             "avg_launch_us": r["ms"] * 1e3 / r["launches"],
             "flops_per_launch": r["flops"] / r["launches"],
             "algorithmic_bytes_per_launch": r["bytes"] / r["launches"],
@@ -757,12 +840,17 @@ def main():
             out["cpu_baseline"] = cpu_baseline(g_params)
             if train is not None:
                 train["cpu_baseline"] = cpu_train_baseline(load_conf("hifigan.v1"))
-        # the last key of the line (the driver keeps the TAIL of stdout): every training configuration in brief
+        out["train_config"] = main_tag
+        # the per-config truth, not the flag: true only if EVERY training configuration really replayed a hipGraph
+        runs_all = ([train] if train is not None else []) + [v for k, v in configs.items() if k.endswith("_train")]
+        out["hip_graph"] = (not args.no_graph) and all(v.get("hip_graph", False) for v in runs_all)
         out["summary"] = {"infer_samples_per_s": round(value, 1), "roofline_frac": roofline and round(roofline["frac"], 4),
                           "train_config": main_tag, "train_steps_per_s": train_brief, "train_ok": train_ok,
                           "n_gpus": world}
+        out["detail_file"] = "gpurun_out/" + os.environ.get("PWG_BENCH_DETAIL", "bench_detail.json")
+        write_detail(out)
         sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        os.write(real_stdout, (compact_line(out) + "\n").encode())
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -97,3 +97,62 @@ def test_product_package_never_imports_the_oracle_or_the_staged_reference():
                     if needle in src:
                         bad.append((os.path.join(base, n), needle))
     assert not bad, bad
+
+
+def _canned_record(world=1):
+    """A full bench record of the shape main() builds: the committed round-4 record plus the keys round 5 added."""
+    import json
+
+    with open(os.path.join(ROOT, "profiles", "r04_z_bench.json")) as f:
+        out = json.load(f)
+    out["train_config"] = "c3" if world == 1 else "c5"
+    out["detail_file"] = "gpurun_out/bench_detail.json"
+    out["roofline"]["launches_timed"] = 141
+    out["train"]["cpu_baseline"].setdefault("batch", 16)
+    out["n_gpus"] = world
+    if world > 1:  # the distributed detail a --gpus 8 run carries
+        out["train"]["dist"] = {
+            "backend": "nccl", "world_size": world,
+            "exposed_comm_ms_per_exchange": {"generator": 0.61234567, "discriminator": 0.123456789},
+            "rccl": {"nranks": world, "large_allreduce": {"bytes": 67108864, "algo": "Ring", "proto": "Simple",
+                                                          "channels": 32}, "sample_lines": ["x" * 200] * 6}}
+    return out
+
+
+@pytest.mark.parametrize("world", [1, 8])
+def test_stdout_line_is_compact_strict_json_with_the_contract_keys(world):
+    """VERDICT r04 item 1 / ADVICE r04: the driver keeps a 2000-byte tail of stdout; the ONE stdout line has to be a
+    standalone JSON object inside it that carries the contract keys, ``roofline`` and ``cpu_baseline``."""
+    import json
+
+    bench = _bench()
+    line = bench.compact_line(_canned_record(world))
+    assert "\n" not in line and len(line.encode()) < 2000, len(line)
+    rec = json.loads(line, parse_constant=lambda c: pytest.fail(f"non-strict JSON constant {c}"))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "train_steps_per_s", "train_ok",
+              "hip_graph"):
+        assert k in rec, k
+    assert rec["config"]["workload"] and "model" not in rec["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rec["roofline"], k
+    assert abs(rec["roofline"]["frac"] - rec["roofline"]["achieved"] / rec["roofline"]["peak"]) < 1e-3
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in rec["cpu_baseline"], k
+    assert set(rec["train_steps_per_s"]) == {"c2", "c3", "c4", "c5"}
+    if world > 1:
+        d = rec["train"]["dist"]
+        assert d["rccl"]["nranks"] == world and d["rccl"]["large_allreduce"]["algo"] == "Ring"
+        assert set(d["exposed_comm_ms_per_exchange"]) == {"generator", "discriminator"}
+
+
+def test_compact_line_sheds_optional_objects_rather_than_exceed_the_tail():
+    bench = _bench()
+    out = _canned_record(8)
+    out["train"]["dist"]["rccl"]["large_allreduce"]["algo"] = "R" * 3000  # a pathological field
+    line = bench.compact_line(out)
+    assert len(line.encode()) < 2000
+    import json
+
+    rec = json.loads(line)
+    assert "roofline" in rec and "cpu_baseline" in rec and "train_steps_per_s" in rec
