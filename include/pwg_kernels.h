@@ -374,7 +374,9 @@ int pwg_weight_norm_backward(const float* dw, const float* v, const float* g, fl
  * tmp: max(rows, 32 * cols) floats of workspace (row-sliced partial sums of W^T u). */
 int pwg_spectral_norm_forward(const float* w_orig, float* u, float* v, float* sigma, float* w, float* tmp,
                               int32_t rows, int32_t cols, int32_t do_iter, float eps, void* stream);
-/* dw_orig = dw / sigma - (<dw, w_orig> / sigma^2) u v^T ;  scratch: 1 float.       */
+/* dw_orig = dw / sigma - (<dw, w_orig> / sigma^2) u v^T ;  scratch: PWG_SPECTRAL_NORM_SCRATCH_FLOATS floats
+ * (the dot product is summed through per-block shares in a fixed order: no atomics).  */
+#define PWG_SPECTRAL_NORM_SCRATCH_FLOATS 257
 int pwg_spectral_norm_backward(const float* dw, const float* w_orig, const float* u, const float* v,
                                const float* sigma, float* dw_orig, float* scratch, int32_t rows,
                                int32_t cols, void* stream);
@@ -388,15 +390,34 @@ int pwg_gate_forward(const float* z, float* out, int32_t batch, int32_t channels
 int pwg_gate_backward(const float* z, const float* dout, float* dz, int32_t batch, int32_t channels,
                       int64_t t, void* stream);
 /* One stage of the mel upsampler: F.interpolate(nearest, x scale) followed by the
- * (1, 2*scale+1) single-channel Conv2d, fused (layers/upsample.py:43-45,97-103,121-127):
- *   y[r][t] = sum_j w[j] * x[r][(t + j - pad_left) / scale],  rows = B * mel channels;
+ * (freq_kernel, 2*scale+1) single-channel Conv2d over (mel channel, time), fused
+ * (layers/upsample.py:43-45,88-103,121-127):
+ *   y[b][c][t] = sum_f sum_j w[f][j] * x[b][c + f - (F-1)/2][(t + j - pad_left) / scale],
+ * rows = B * channels (zero padding on the channel axis; freq_kernel = 1 is the shipped recipes' case);
  * pad_left = scale (centred) or 2*scale (use_causal_conv: :96-99,121-125, output trimmed
- * to the stretched length).                                                          */
+ * to the stretched length).  `act` / `slope`: the optional nonlinearity after the stage (:105-110), applied in the
+ * epilogue; its backward is pwg_act_backward on the stage output, then pwg_stretch_conv_backward.  The weight
+ * gradient is summed through per-block shares in `workspace` in a fixed order (no atomics).           */
+#define PWG_STRETCH_CONV_WGRAD_BLOCKS 512
 int pwg_stretch_conv_forward(const float* x, const float* w, float* y, int64_t rows, int32_t t_in,
-                             int32_t scale, int32_t kernel, int32_t pad_left, void* stream);
+                             int32_t scale, int32_t kernel, int32_t pad_left, int32_t channels,
+                             int32_t freq_kernel, int32_t act, float slope, void* stream);
+size_t pwg_stretch_conv_backward_workspace_floats(int32_t kernel, int32_t freq_kernel);
 int pwg_stretch_conv_backward(const float* dy, const float* x, const float* w, float* dx, float* dw,
                               int64_t rows, int32_t t_in, int32_t scale, int32_t kernel, int32_t pad_left,
+                              int32_t channels, int32_t freq_kernel, float* workspace, size_t workspace_floats,
                               void* stream);
+/* Pseudo-QMF filterbank as polyphase kernels (layers/pqmf.py:120-149; csrc/pqmf.hip), 1 <= subbands <= 8:
+ *   down:  y[b][k][i] = sum_j  h[k][j]               * x[b][i K + j - pad]     x (B, 1, t_in) -> y (B, K, n_out)
+ *   up:    x[b][t]    = sum_k sum_i g[k][t + pad - i K] * y[b][k][i]           y (B, K, n_in) -> x (B, 1, t_out)
+ * (zero outside the signals).  PQMF.analysis = down with h = analysis_filter, pad = taps / 2,
+ * n_out = floor(T / K) for ANY T (the reference's stride-K pick after the full-rate FIR, pqmf.py:120-131);
+ * PQMF.synthesis = up with g[k][m] = K * synthesis_filter[k][taps - m], t_out = K * n_in (pqmf.py:133-149).
+ * Each is the adjoint of the other with the same filter, which is how the backward passes run.  */
+int pwg_pqmf_down(const float* x, const float* h, float* y, int32_t batch, int64_t t_in, int64_t n_out,
+                  int32_t subbands, int32_t len, int32_t pad, void* stream);
+int pwg_pqmf_up(const float* y, const float* g, float* x, int32_t batch, int64_t n_in, int64_t t_out,
+                int32_t subbands, int32_t len, int32_t pad, void* stream);
 
 /* ---- StyleMelGAN pieces (layers/tade_res_block.py, models/style_melgan.py) ---- */
 /* torch.nn.InstanceNorm1d(affine=False) over `rows` = B*C rows of t samples (tade_res_block.py:27,66):

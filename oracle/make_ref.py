@@ -9,6 +9,10 @@ reference's OWN modules (``kind: "reference"``) instead of the restatement (``ki
 path imports is staged: the ``parallel_wavegan`` Python package (models / layers / losses / optimizers / utils /
 bin / datasets / distributed), byte for byte, plus a MANIFEST with the sha256 of every staged file so a test can
 prove that nothing was edited on the way.  Nothing under ``parallelwavegan_amd/`` may import it.
+
+Round 5: the reference's own unit tests, ``test/*.py``, are staged next to it as
+``oracle/_ref/test/`` (same manifest) -- ``tests/test_reference_unit_tests_gpu.py`` runs those files, unedited,
+against the DROP-IN package (``parallelwavegan_amd.compat.install()``) on the GPU box.
 """
 import hashlib
 import json
@@ -35,17 +39,19 @@ def stage(force=False):
     dst = os.path.join(DST_ROOT, "parallel_wavegan")
     manifest_path = os.path.join(DST_ROOT, "MANIFEST.json")
     files = {}
-    for base, _, names in os.walk(src):
-        for n in sorted(names):
-            if n.endswith(".py"):
-                p = os.path.join(base, n)
-                files[os.path.relpath(p, SRC_ROOT)] = _sha(p)
+    for top in (src, os.path.join(SRC_ROOT, "test")):
+        for base, _, names in os.walk(top):
+            for n in sorted(names):
+                if n.endswith(".py"):
+                    p = os.path.join(base, n)
+                    files[os.path.relpath(p, SRC_ROOT)] = _sha(p)
     if not force and os.path.exists(manifest_path):
         with open(manifest_path) as f:
             old = json.load(f)
         if old.get("files") == files and all(os.path.exists(os.path.join(DST_ROOT, r)) for r in files):
             return old
     shutil.rmtree(dst, ignore_errors=True)
+    shutil.rmtree(os.path.join(DST_ROOT, "test"), ignore_errors=True)
     for rel in files:
         out = os.path.join(DST_ROOT, rel)
         os.makedirs(os.path.dirname(out), exist_ok=True)

@@ -11,7 +11,8 @@ LIB_PATH = os.path.join(_HERE, "libpwgkernels.so")
 
 PWG_ACT_NONE, PWG_ACT_LEAKY_RELU, PWG_ACT_TANH, PWG_ACT_RELU = 0, 1, 2, 3
 PWG_PAD_ZERO, PWG_PAD_REFLECT, PWG_PAD_REPLICATE = 0, 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
+SPECTRAL_NORM_SCRATCH_FLOATS = 257  # PWG_SPECTRAL_NORM_SCRATCH_FLOATS (include/pwg_kernels.h)
 
 
 class ConvDesc(ctypes.Structure):
@@ -189,8 +190,12 @@ SIGNATURES = {
     "pwg_spectral_norm_backward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "pwg_gate_forward": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i64, _vp]),
     "pwg_gate_backward": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i64, _vp]),
-    "pwg_stretch_conv_forward": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
-    "pwg_stretch_conv_backward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "pwg_stretch_conv_forward": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "pwg_stretch_conv_backward_workspace_floats": (ctypes.c_size_t, [_i32, _i32]),
+    "pwg_stretch_conv_backward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp,
+                                                 ctypes.c_size_t, _vp]),
+    "pwg_pqmf_down": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "pwg_pqmf_up": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _vp]),
     "pwg_avg_pool1d_forward": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pwg_avg_pool1d_backward": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pwg_pad1d_forward": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),

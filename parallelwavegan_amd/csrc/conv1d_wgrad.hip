@@ -412,21 +412,63 @@ __global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* __r
   }
 }
 
-// db[c] += sum over one (item, 4096-sample segment) of dy[b][c][:]; grid (channels, items * segments);
-// db is zeroed first (zero_fill kernel) and the per-segment partial sums are combined with atomics.
-constexpr int BG_SEG = 4096;
-__global__ void bias_grad_kernel(const float* dy, float* db, int channels, int n, int segs) {
-  __shared__ float red[4];
+// db[c] = sum over (item, time) of dy[b][c][:]: ONE workgroup of 1024 lanes per channel walks the items in order
+// (lane-strided partial sums, fixed shuffle / LDS tree), so the result is bit-reproducible -- the round-4 kernel
+// combined per-segment partial sums with fp32 atomics, one of the three sources of run-to-run drift of a training
+// step.  Used only by ConvTranspose1d layers and bias-only calls (<= 128 KB of dy per channel at the training
+// shapes); plain convolutions get their bias gradient from the weight-gradient kernel's fused row.
+__global__ __launch_bounds__(1024) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db, int channels,
+                                                         int n, int batch) {
+  __shared__ float red[16];
   const int c = blockIdx.x;
-  const int b = blockIdx.y / segs, sg = blockIdx.y - b * segs;
-  const float* p = dy + ((long)b * channels + c) * n;
-  const int lo = sg * BG_SEG, hi = min(n, lo + BG_SEG);
-  float s = 0.f;
-  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) s += p[i];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const long plane = (long)channels * n;
+  const float* pc = dy + (long)c * n;
+  // the (item, time) pairs of this channel as ONE index space (row lengths are often < 1024 * 4 at the coarse layers:
+  // a per-item loop would leave most lanes idle and serialise the items' latencies); four independent loads per trip
+  if ((n & 3) == 0 && (((unsigned long long)dy) & 15) == 0) {  // rows start 16-B aligned
+    const int n4 = n >> 2;
+    const long tot = (long)batch * n4;
+    auto ld = [&](long idx) {
+      const long bb = idx / n4;
+      const float4 a = *reinterpret_cast<const float4*>(pc + bb * plane + ((idx - bb * n4) << 2));
+      return (a.x + a.y) + (a.z + a.w);
+    };
+    long i = threadIdx.x;
+    for (; i + 3072 < tot; i += 4096) {
+      const float a = ld(i), e = ld(i + 1024), f = ld(i + 2048), g = ld(i + 3072);
+      s0 += a;
+      s1 += e;
+      s2 += f;
+      s3 += g;
+    }
+    for (; i < tot; i += 1024) s0 += ld(i);
+  } else {
+    const long tot = (long)batch * n;
+    auto ld = [&](long idx) {
+      const long bb = idx / n;
+      return pc[bb * plane + (idx - bb * n)];
+    };
+    long i = threadIdx.x;
+    for (; i + 3072 < tot; i += 4096) {
+      const float a = ld(i), e = ld(i + 1024), f = ld(i + 2048), g = ld(i + 3072);
+      s0 += a;
+      s1 += e;
+      s2 += f;
+      s3 += g;
+    }
+    for (; i < tot; i += 1024) s0 += ld(i);
+  }
+  float s = (s0 + s1) + (s2 + s3);
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(db + c, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    float t = red[0];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) t += red[q];
+    db[c] = t;
+  }
 }
 
 
@@ -866,11 +908,8 @@ static int backward_weight_impl(const pwg_conv1d_desc* d_in, const float* x, con
   const bool fuse_bias = db && dw && !d->transposed;
   if (db && !fuse_bias) {
     const int n = d->t_out * d->width;
-    const int segs = ceil_div(n, BG_SEG);
-    zero_fill(db, d->c_out, stream);
     ProfScope prof(stream, "bias_grad_kernel", 0, 4.0 * y_elems);
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(d->c_out, d->batch * segs), dim3(256), 0, stream, dy, db, d->c_out, n,
-                       segs);
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(d->c_out), dim3(1024), 0, stream, dy, db, d->c_out, n, d->batch);
     PWG_CHECK_LAUNCH("bias_grad");
   }
   if (!dw) return PWG_OK;

@@ -313,12 +313,20 @@ __global__ void spectral_norm_bwd_kernel(const float* dw, const float* u, const 
     dwo[i] = dw[i] / sg - coef * u[r] * v[c];
   }
 }
-__global__ void dot_big_kernel(const float* a, const float* b, float* out, long n) {  // atomics; out pre-zeroed
+// part[block] = this block's share of <a, b>; dot_finish_kernel adds the shares in block order (no atomics)
+__global__ void dot_big_kernel(const float* a, const float* b, float* part, long n) {
   __shared__ float red[4];
   float s = 0.f;
   GRID_STRIDE(i, n) s += a[i] * b[i];
   s = block_sum_256(s, red);
-  if (threadIdx.x == 0) atomicAdd(out, s);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ void dot_finish_kernel(const float* part, float* out, int nb) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) s += part[i];
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) out[0] = s;
 }
 // w = w_orig / sigma
 __global__ void div_scalar_kernel(const float* x, const float* s, float* y, long n) {
@@ -352,58 +360,85 @@ __global__ void gate_bwd_kernel(const float* z, const float* dout, float* dz, in
   }
 }
 
-// ---- PWG mel upsampler stage: nearest stretch x s along time fused with the (1, 2s+1) smoothing
-// conv (layers/upsample.py:43-45,97-103):  y[r][t] = sum_j w[j] * x[r][(t + j - s) / s]   (zero pad)
+// ---- PWG mel upsampler stage: nearest stretch x s along time fused with the (F, 2s+1) smoothing
+// conv over (mel channel, time) (layers/upsample.py:43-45,88-103; F = freq_axis_kernel_size, zero padding (F-1)/2 on
+// the channel axis):  y[b][c][t] = sum_f sum_j w[f][j] * x[b][c + f - pf][(t + j - pad) / s]
 __global__ void stretch_conv_fwd_kernel(const float* x, const float* w, float* y, long rows, int t_in, int s, int k,
-                                        int pad) {
+                                        int pad, int channels, int fk, int act, float slope) {
   const int t_out = t_in * s;
   const long n = rows * t_out;
+  const int pf = (fk - 1) / 2;
   GRID_STRIDE(i, n) {
     const long r = i / t_out;
     const int t = (int)(i - r * t_out);
-    const float* xr = x + r * t_in;
+    const int c = (int)(r % channels);
     float acc = 0.f;
-    for (int j = 0; j < k; ++j) {
-      const int u = t + j - pad;
-      if (u >= 0 && u < t_out) acc += w[j] * xr[u / s];
+    for (int f = 0; f < fk; ++f) {
+      const int cc = c + f - pf;
+      if (cc < 0 || cc >= channels) continue;
+      const float* xr = x + (r + f - pf) * t_in;
+      const float* wf = w + f * k;
+      for (int j = 0; j < k; ++j) {
+        const int u = t + j - pad;
+        if (u >= 0 && u < t_out) acc += wf[j] * xr[u / s];
+      }
     }
-    y[i] = acc;
+    y[i] = apply_act(acc, act, slope);  // the optional nonlinearity after each stage (layers/upsample.py:105-110)
   }
 }
 __global__ void stretch_conv_bwd_data_kernel(const float* dy, const float* w, float* dx, long rows, int t_in, int s,
-                                             int k, int pad) {
+                                             int k, int pad, int channels, int fk) {
   const int t_out = t_in * s;
   const long n = rows * t_in;
+  const int pf = (fk - 1) / 2;
   GRID_STRIDE(i, n) {
     const long r = i / t_in;
     const int q = (int)(i - r * t_in);
-    const float* g = dy + r * t_out;
+    const int c = (int)(r % channels);
     float acc = 0.f;
-    for (int u = q * s; u < q * s + s; ++u)
-      for (int j = 0; j < k; ++j) {
-        const int t = u - j + pad;
-        if (t >= 0 && t < t_out) acc += w[j] * g[t];
-      }
+    for (int f = 0; f < fk; ++f) {
+      const int co = c - f + pf;  // the output channel that read x[c] through tap row f
+      if (co < 0 || co >= channels) continue;
+      const float* g = dy + (r - f + pf) * t_out;
+      const float* wf = w + f * k;
+      for (int u = q * s; u < q * s + s; ++u)
+        for (int j = 0; j < k; ++j) {
+          const int t = u - j + pad;
+          if (t >= 0 && t < t_out) acc += wf[j] * g[t];
+        }
+    }
     dx[i] = acc;
   }
 }
-// dw[j] = sum_{r,t} dy[r][t] * xs[r][t + j - pad];  dw must be zeroed (block partials + atomics, k <= 64)
-__global__ void stretch_conv_bwd_weight_kernel(const float* dy, const float* x, float* dw, long rows, int t_in, int s,
-                                               int k, int pad) {
+// part[(f k + j) * gridDim.x + block] = this block's share of sum_{r,t} dy[r][t] * xs[r + f - pf][t + j - pad];
+// sum_partials_kernel adds the blocks' shares in a fixed order (deterministic: no atomics)
+__global__ void stretch_conv_bwd_weight_kernel(const float* dy, const float* x, float* part, long rows, int t_in, int s,
+                                               int k, int pad, int channels, int fk) {
   __shared__ float red[4];
   const int t_out = t_in * s;
   const long n = rows * t_out;
-  for (int j = 0; j < k; ++j) {
-    float acc = 0.f;
-    GRID_STRIDE(i, n) {
-      const long r = i / t_out;
-      const int t = (int)(i - r * t_out);
-      const int u = t + j - pad;
-      if (u >= 0 && u < t_out) acc += dy[i] * x[r * t_in + u / s];
+  const int pf = (fk - 1) / 2;
+  for (int f = 0; f < fk; ++f)
+    for (int j = 0; j < k; ++j) {
+      float acc = 0.f;
+      GRID_STRIDE(i, n) {
+        const long r = i / t_out;
+        const int t = (int)(i - r * t_out);
+        const int cc = (int)(r % channels) + f - pf;
+        const int u = t + j - pad;
+        if (u >= 0 && u < t_out && cc >= 0 && cc < channels) acc += dy[i] * x[(r + f - pf) * t_in + u / s];
+      }
+      acc = block_sum_256(acc, red);
+      if (threadIdx.x == 0) part[(long)(f * k + j) * gridDim.x + blockIdx.x] = acc;
     }
-    acc = block_sum_256(acc, red);
-    if (threadIdx.x == 0) atomicAdd(dw + j, acc);
-  }
+}
+// out[o] = sum_i part[o * nb + i], every launch in the same order (thread-strided partial sums, fixed tree)
+__global__ void sum_partials_kernel(const float* part, float* out, int nb) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) s += part[(long)blockIdx.x * nb + i];
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 
 
@@ -747,7 +782,8 @@ extern "C" int pwg_pad1d_backward(const float* dy, float* dx, int64_t rows, int3
 extern "C" int pwg_frame_fold_forward(const float* x, float* y, int32_t batch, int32_t t, int32_t pad, int32_t hop,
                                       int32_t n_cols, void* stream) {
   PWG_REQUIRE(x && y, PWG_ERR_NULL, "frame_fold_forward: NULL pointer");
-  PWG_REQUIRE(batch > 0 && t > pad && pad >= 0 && hop > 0 && n_cols > 0, PWG_ERR_BAD_SHAPE,
+  // pad < 0 (torch.stft(center=False) with a window shorter than n_fft): the fold starts at x[-pad]
+  PWG_REQUIRE(batch > 0 && t > pad && pad > -t && hop > 0 && n_cols > 0, PWG_ERR_BAD_SHAPE,
               "frame_fold: bad geometry (T=%d pad=%d hop=%d)", t, pad, hop);
   const long n = (long)batch * hop * n_cols;
   ProfScope prof((hipStream_t)stream, "frame_fold_fwd_kernel", 0, 4.0 * ((double)batch * t + n));
@@ -758,7 +794,7 @@ extern "C" int pwg_frame_fold_forward(const float* x, float* y, int32_t batch, i
 extern "C" int pwg_frame_fold_backward(const float* dy, float* dx, int32_t batch, int32_t t, int32_t pad,
                                        int32_t hop, int32_t n_cols, void* stream) {
   PWG_REQUIRE(dy && dx, PWG_ERR_NULL, "frame_fold_backward: NULL pointer");
-  PWG_REQUIRE(batch > 0 && t > pad && pad >= 0 && hop > 0 && n_cols > 0, PWG_ERR_BAD_SHAPE, "frame_fold: bad geometry");
+  PWG_REQUIRE(batch > 0 && t > pad && pad > -t && hop > 0 && n_cols > 0, PWG_ERR_BAD_SHAPE, "frame_fold: bad geometry");
   const long n = (long)batch * t;
   LAUNCH1D(frame_fold_bwd_kernel, n, stream, dy, dx, batch, t, pad, hop, n_cols);
   return PWG_OK;
@@ -825,7 +861,8 @@ extern "C" int pwg_spectral_norm_forward(const float* w_orig, float* u, float* v
   return PWG_OK;
 }
 
-// dw_orig = dw / sigma - (<dw, w_orig> / sigma^2) u v^T ; scratch: one float
+// dw_orig = dw / sigma - (<dw, w_orig> / sigma^2) u v^T ; scratch: PWG_SPECTRAL_NORM_SCRATCH_FLOATS floats
+// ([0] = the dot product, [1 ..] = per-block shares)
 extern "C" int pwg_spectral_norm_backward(const float* dw, const float* w_orig, const float* u, const float* v,
                                           const float* sigma, float* dw_orig, float* scratch, int32_t rows,
                                           int32_t cols, void* stream_) {
@@ -833,8 +870,9 @@ extern "C" int pwg_spectral_norm_backward(const float* dw, const float* w_orig, 
   PWG_REQUIRE(rows > 0 && cols > 0, PWG_ERR_BAD_SHAPE, "spectral_norm: bad shape");
   hipStream_t stream = (hipStream_t)stream_;
   const long n = (long)rows * cols;
-  zero_fill(scratch, 1, stream);
-  hipLaunchKernelGGL(dot_big_kernel, dim3(grid_for(n, 256, 256)), dim3(256), 0, stream, dw, w_orig, scratch, n);
+  const int nb = grid_for(n, 256, PWG_SPECTRAL_NORM_SCRATCH_FLOATS - 1);
+  hipLaunchKernelGGL(dot_big_kernel, dim3(nb), dim3(256), 0, stream, dw, w_orig, scratch + 1, n);
+  hipLaunchKernelGGL(dot_finish_kernel, dim3(1), dim3(256), 0, stream, scratch + 1, scratch, nb);
   hipLaunchKernelGGL(spectral_norm_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, dw, u, v, sigma, scratch,
                      dw_orig, rows, cols);
   PWG_CHECK_LAUNCH("spectral_norm_backward");
@@ -859,33 +897,59 @@ extern "C" int pwg_gate_backward(const float* z, const float* dout, float* dz, i
   return PWG_OK;
 }
 
-extern "C" int pwg_stretch_conv_forward(const float* x, const float* w, float* y, int64_t rows, int32_t t_in,
-                                        int32_t scale, int32_t kernel, int32_t pad_left, void* stream) {
-  PWG_REQUIRE(x && w && y, PWG_ERR_NULL, "stretch_conv_forward: NULL pointer");
+static int stretch_conv_check(int64_t rows, int32_t t_in, int32_t scale, int32_t kernel, int32_t pad_left,
+                              int32_t channels, int32_t freq_kernel) {
   PWG_REQUIRE(rows > 0 && t_in > 0 && scale > 0 && kernel > 0 && kernel <= 64 && pad_left >= 0 && pad_left < kernel,
               PWG_ERR_BAD_SHAPE, "stretch_conv: bad geometry");
-  const long n = rows * (long)t_in * scale;
-  ProfScope prof((hipStream_t)stream, "stretch_conv_fwd_kernel", 2.0 * n * kernel, 4.0 * (rows * (double)t_in + n));
-  LAUNCH1D(stretch_conv_fwd_kernel, n, stream, x, w, y, (long)rows, t_in, scale, kernel, pad_left);
+  PWG_REQUIRE(channels > 0 && rows % channels == 0 && freq_kernel >= 1 && freq_kernel <= 15 && (freq_kernel & 1),
+              PWG_ERR_BAD_SHAPE, "stretch_conv: rows %lld not a multiple of channels %d, or freq kernel %d not odd in 1..15",
+              (long long)rows, channels, freq_kernel);
   return PWG_OK;
+}
+
+extern "C" int pwg_stretch_conv_forward(const float* x, const float* w, float* y, int64_t rows, int32_t t_in,
+                                        int32_t scale, int32_t kernel, int32_t pad_left, int32_t channels,
+                                        int32_t freq_kernel, int32_t act, float slope, void* stream) {
+  PWG_REQUIRE(x && w && y, PWG_ERR_NULL, "stretch_conv_forward: NULL pointer");
+  PWG_REQUIRE(act == PWG_ACT_NONE || act == PWG_ACT_LEAKY_RELU || act == PWG_ACT_RELU || act == PWG_ACT_TANH,
+              PWG_ERR_UNSUPPORTED, "stretch_conv_forward: activation %d", act);
+  const int rc = stretch_conv_check(rows, t_in, scale, kernel, pad_left, channels, freq_kernel);
+  if (rc != PWG_OK) return rc;
+  const long n = rows * (long)t_in * scale;
+  ProfScope prof((hipStream_t)stream, "stretch_conv_fwd_kernel", 2.0 * n * kernel * freq_kernel,
+                 4.0 * (rows * (double)t_in + n));
+  LAUNCH1D(stretch_conv_fwd_kernel, n, stream, x, w, y, (long)rows, t_in, scale, kernel, pad_left, channels, freq_kernel,
+           act, slope);
+  return PWG_OK;
+}
+
+extern "C" size_t pwg_stretch_conv_backward_workspace_floats(int32_t kernel, int32_t freq_kernel) {
+  return (size_t)PWG_STRETCH_CONV_WGRAD_BLOCKS * (size_t)kernel * (size_t)freq_kernel;
 }
 
 extern "C" int pwg_stretch_conv_backward(const float* dy, const float* x, const float* w, float* dx, float* dw,
                                          int64_t rows, int32_t t_in, int32_t scale, int32_t kernel, int32_t pad_left,
-                                         void* stream) {
+                                         int32_t channels, int32_t freq_kernel, float* workspace,
+                                         size_t workspace_floats, void* stream) {
   PWG_REQUIRE(dy && w && (dx || dw), PWG_ERR_NULL, "stretch_conv_backward: NULL pointer");
-  PWG_REQUIRE(rows > 0 && t_in > 0 && scale > 0 && kernel > 0 && kernel <= 64 && pad_left >= 0 && pad_left < kernel,
-              PWG_ERR_BAD_SHAPE, "stretch_conv: bad geometry");
+  const int rc = stretch_conv_check(rows, t_in, scale, kernel, pad_left, channels, freq_kernel);
+  if (rc != PWG_OK) return rc;
   if (dx) {
     const long n = rows * (long)t_in;
-    LAUNCH1D(stretch_conv_bwd_data_kernel, n, stream, dy, w, dx, (long)rows, t_in, scale, kernel, pad_left);
+    LAUNCH1D(stretch_conv_bwd_data_kernel, n, stream, dy, w, dx, (long)rows, t_in, scale, kernel, pad_left, channels,
+             freq_kernel);
   }
   if (dw) {
     PWG_REQUIRE(x, PWG_ERR_NULL, "stretch_conv_backward: x needed for dw");
-    zero_fill(dw, kernel, (hipStream_t)stream);
+    const size_t need = pwg_stretch_conv_backward_workspace_floats(kernel, freq_kernel);
+    PWG_REQUIRE(workspace && workspace_floats >= need, PWG_ERR_WORKSPACE,
+                "stretch_conv_backward: workspace of %zu floats needed, %zu given", need, workspace_floats);
     const long n = rows * (long)t_in * scale;
-    hipLaunchKernelGGL(stretch_conv_bwd_weight_kernel, dim3(grid_for(n, 256, 512)), dim3(256), 0, (hipStream_t)stream,
-                       dy, x, dw, (long)rows, t_in, scale, kernel, pad_left);
+    const int nb = grid_for(n, 256, PWG_STRETCH_CONV_WGRAD_BLOCKS);
+    hipLaunchKernelGGL(stretch_conv_bwd_weight_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, x, workspace,
+                       (long)rows, t_in, scale, kernel, pad_left, channels, freq_kernel);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(kernel * freq_kernel), dim3(256), 0, (hipStream_t)stream, workspace, dw,
+                       nb);
     PWG_CHECK_LAUNCH("stretch_conv_bwd_weight");
   }
   return PWG_OK;

@@ -1,0 +1,177 @@
+// pqmf.hip -- pseudo-QMF filterbank as two HBM-bound polyphase kernels (no matrix unit: 63 taps x K sub-bands is
+// ~63 FMAs per sample against 8 B of traffic per sample; the launch is bounded by HBM, not by arithmetic).
+//
+// Reference (parallel_wavegan/layers/pqmf.py:120-149): analysis = pad(taps/2) -> full-rate FIR 1 -> K channels ->
+// one-hot stride-K "pick" convolution (output floor(T / K) samples per band, ANY T); synthesis = one-hot zero-stuffing
+// transposed convolution (x K) -> pad(taps/2) -> FIR K -> 1.  Only the kept samples are computed here:
+//   down:  y[b][k][i] = sum_j  h[k][j]              * x[b][i K + j - pad]            (analysis; adjoint of `up`)
+//   up:    x[b][t]    = sum_k sum_i g[k][t + pad - i K] * y[b][k][i]                 (synthesis; adjoint of `down`)
+// The time window of a workgroup is staged in LDS in POLYPHASE order (plane r holds the samples with index = r mod K),
+// so that the 63 reads of a lane are consecutive across the wave (no bank conflicts); the filter taps are read
+// through wave-uniform (scalar) loads.  Backward passes reuse the two kernels with the roles of the filters swapped.
+#include "common.h"
+
+namespace pwg {
+
+constexpr int PQMF_TI = 256;   // outputs per sub-band (down) / input positions q (up) per workgroup
+constexpr int PQMF_MAXL = 256;  // filter length limit (taps + 1)
+
+// grid (ceil(n_out / TI), B); block 256.  LDS: K planes of (TI + ceil(L / K)) floats.
+template <int K>
+__global__ __launch_bounds__(256) void pqmf_down_kernel(const float* __restrict__ x, const float* __restrict__ h,
+                                                        float* __restrict__ y, int t_in, int n_out, int len, int pad) {
+  extern __shared__ float lds[];
+  const int qmax = (len + K - 1) / K;  // polyphase taps per plane
+  const int pl = PQMF_TI + qmax;       // plane length
+  const int i0 = blockIdx.x * PQMF_TI;
+  const long b = blockIdx.y;
+  const float* xb = x + b * (long)t_in;
+  // window of x: u = i0 K - pad ... (covers a in [0, pl) of every plane: u = t0 + a K + r)
+  const int t0 = i0 * K - pad;
+  for (int idx = threadIdx.x; idx < pl * K; idx += 256) {
+    const int t = t0 + idx;
+    const int a = idx / K, r = idx - a * K;
+    lds[r * pl + a] = (t >= 0 && t < t_in) ? xb[t] : 0.f;
+  }
+  __syncthreads();
+  float acc[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) acc[k] = 0.f;
+  const int i = threadIdx.x;
+  for (int q = 0; q < qmax; ++q) {
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+      const int j = q * K + r;  // wave-uniform
+      if (j < len) {
+        const float xv = lds[r * pl + i + q];
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = fmaf(h[k * len + j], xv, acc[k]);
+      }
+    }
+  }
+  if (i0 + i < n_out) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) y[(b * K + k) * (long)n_out + i0 + i] = acc[k];
+  }
+}
+
+// grid (ceil(ceil(t_out / K) / TI), B); block 256.  Thread q produces x[qK .. qK + K).
+// d = i - q runs over [dlo, dhi] = [ceil((pad - L + 1) / K), floor((K - 1 + pad) / K)];  tap m = r + pad - d K.
+template <int K>
+__global__ __launch_bounds__(256) void pqmf_up_kernel(const float* __restrict__ y, const float* __restrict__ g,
+                                                      float* __restrict__ x, int n_in, int t_out, int len, int pad,
+                                                      int dlo, int dhi) {
+  extern __shared__ float lds[];
+  const int span = dhi - dlo + 1;
+  const int pl = PQMF_TI + span;  // per-band window: i in [q0 + dlo, q0 + TI + dhi)
+  const int q0 = blockIdx.x * PQMF_TI;
+  const long b = blockIdx.y;
+  for (int idx = threadIdx.x; idx < pl * K; idx += 256) {
+    const int k = idx / pl, a = idx - k * pl;
+    const int i = q0 + dlo + a;
+    lds[idx] = (i >= 0 && i < n_in) ? y[(b * K + k) * (long)n_in + i] : 0.f;
+  }
+  __syncthreads();
+  float acc[K];
+#pragma unroll
+  for (int r = 0; r < K; ++r) acc[r] = 0.f;
+  const int q = threadIdx.x;
+  for (int k = 0; k < K; ++k) {
+    const float* gk = g + k * len;
+    for (int a = 0; a < span; ++a) {
+      const int d = dlo + a;
+      const float yv = lds[k * pl + q + a];
+#pragma unroll
+      for (int r = 0; r < K; ++r) {
+        const int m = r + pad - d * K;  // wave-uniform
+        if (m >= 0 && m < len) acc[r] = fmaf(gk[m], yv, acc[r]);
+      }
+    }
+  }
+  __syncthreads();  // the y window is dead: reuse the LDS to turn K strided stores per lane into coalesced ones
+#pragma unroll
+  for (int r = 0; r < K; ++r) lds[q * K + r] = acc[r];
+  __syncthreads();
+  float* xb = x + b * (long)t_out;
+  const int tbase = q0 * K;
+  for (int idx = threadIdx.x; idx < PQMF_TI * K; idx += 256) {
+    const int t = tbase + idx;
+    if (t < t_out) xb[t] = lds[idx];
+  }
+}
+
+template <int K>
+static int launch_down(const float* x, const float* h, float* y, int batch, int t_in, int n_out, int len, int pad,
+                       hipStream_t s) {
+  const int qmax = (len + K - 1) / K;
+  const size_t lds = sizeof(float) * (size_t)K * (PQMF_TI + qmax);
+  hipLaunchKernelGGL(pqmf_down_kernel<K>, dim3(ceil_div(n_out, PQMF_TI), batch), dim3(256), lds, s, x, h, y, t_in, n_out,
+                     len, pad);
+  PWG_CHECK_LAUNCH("pqmf_down_kernel");
+  return PWG_OK;
+}
+template <int K>
+static int launch_up(const float* y, const float* g, float* x, int batch, int n_in, int t_out, int len, int pad,
+                     hipStream_t s) {
+  // floor division towards -inf for the (negative) lower bound
+  const int lo_num = pad - len + 1;
+  const int dlo = lo_num >= 0 ? (lo_num + K - 1) / K : -((-lo_num) / K);
+  const int dhi = (K - 1 + pad) / K;
+  const int span = dhi - dlo + 1;
+  const size_t win = (size_t)K * (PQMF_TI + span), outs = (size_t)K * PQMF_TI;
+  const size_t lds = sizeof(float) * (win > outs ? win : outs);
+  const int nq = ceil_div(t_out, K);
+  hipLaunchKernelGGL(pqmf_up_kernel<K>, dim3(ceil_div(nq, PQMF_TI), batch), dim3(256), lds, s, y, g, x, n_in, t_out, len,
+                     pad, dlo, dhi);
+  PWG_CHECK_LAUNCH("pqmf_up_kernel");
+  return PWG_OK;
+}
+
+}  // namespace pwg
+
+using namespace pwg;
+
+#define PQMF_DISPATCH(fn, ...)                 \
+  switch (subbands) {                          \
+    case 1: return fn<1>(__VA_ARGS__);         \
+    case 2: return fn<2>(__VA_ARGS__);         \
+    case 3: return fn<3>(__VA_ARGS__);         \
+    case 4: return fn<4>(__VA_ARGS__);         \
+    case 5: return fn<5>(__VA_ARGS__);         \
+    case 6: return fn<6>(__VA_ARGS__);         \
+    case 7: return fn<7>(__VA_ARGS__);         \
+    default: return fn<8>(__VA_ARGS__);        \
+  }
+
+static int pqmf_check(const char* what, const void* a, const void* f, const void* o, int32_t batch, int64_t t, int64_t n,
+                      int32_t subbands, int32_t len, int32_t pad) {
+  PWG_REQUIRE(a && f && o, PWG_ERR_NULL, "%s: NULL pointer", what);
+  PWG_REQUIRE(batch > 0 && batch <= 65535 && t > 0 && n > 0 && t < (1LL << 31) && n * subbands < (1LL << 31),
+              PWG_ERR_BAD_SHAPE, "%s: bad geometry (B=%d T=%lld n=%lld)", what, batch, (long long)t, (long long)n);
+  PWG_REQUIRE(subbands >= 1 && subbands <= 8, PWG_ERR_UNSUPPORTED, "%s: 1 <= subbands <= 8 (got %d)", what, subbands);
+  PWG_REQUIRE(len >= 1 && len <= PQMF_MAXL && pad >= 0 && pad < len, PWG_ERR_BAD_SHAPE,
+              "%s: filter length %d (<= %d) / pad %d", what, len, PQMF_MAXL, pad);
+  return PWG_OK;
+}
+
+extern "C" int pwg_pqmf_down(const float* x, const float* h, float* y, int32_t batch, int64_t t_in, int64_t n_out,
+                             int32_t subbands, int32_t len, int32_t pad, void* stream) {
+  const int rc = pqmf_check("pqmf_down", x, h, y, batch, t_in, n_out, subbands, len, pad);
+  if (rc != PWG_OK) return rc;
+  // every output needs i K - pad <= T - 1 + pad at its LAST tap at most: i K + (len - 1) - pad may pass the end (zero
+  // padding), but an output whose FIRST tap is past the end would be a caller error
+  PWG_REQUIRE((n_out - 1) * subbands - pad < t_in, PWG_ERR_BAD_SHAPE, "pqmf_down: n_out %lld reaches past T %lld",
+              (long long)n_out, (long long)t_in);
+  ProfScope prof((hipStream_t)stream, "pqmf_down_kernel", 2.0 * batch * (double)n_out * subbands * len,
+                 4.0 * batch * ((double)t_in + (double)n_out * subbands));
+  PQMF_DISPATCH(launch_down, x, h, y, batch, (int)t_in, (int)n_out, len, pad, (hipStream_t)stream);
+}
+
+extern "C" int pwg_pqmf_up(const float* y, const float* g, float* x, int32_t batch, int64_t n_in, int64_t t_out,
+                           int32_t subbands, int32_t len, int32_t pad, void* stream) {
+  const int rc = pqmf_check("pqmf_up", y, g, x, batch, t_out, n_in, subbands, len, pad);
+  if (rc != PWG_OK) return rc;
+  ProfScope prof((hipStream_t)stream, "pqmf_up_kernel", 2.0 * batch * (double)t_out * len,
+                 4.0 * batch * ((double)t_out + (double)n_in * subbands));
+  PQMF_DISPATCH(launch_up, y, g, x, batch, (int)n_in, (int)t_out, len, pad, (hipStream_t)stream);
+}

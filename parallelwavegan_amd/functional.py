@@ -72,7 +72,7 @@ class SpectralNormFn(torch.autograd.Function):
         rows = w_orig.shape[0]
         cols = w_orig.numel() // rows
         dwo = torch.empty_like(w_orig)
-        scratch = torch.empty(1, device=dw.device, dtype=torch.float32)
+        scratch = torch.empty(_lib.SPECTRAL_NORM_SCRATCH_FLOATS, device=dw.device, dtype=torch.float32)
         _lib.check(_L().pwg_spectral_norm_backward(_ptr(dw), _ptr(w_orig), _ptr(u), _ptr(v), _ptr(sigma), _ptr(dwo),
                                                    _ptr(scratch), rows, cols, _stream()), "spectral_norm_backward")
         return dwo, None, None, None, None
@@ -650,36 +650,107 @@ class GateFn(torch.autograd.Function):
 
 
 class StretchConvFn(torch.autograd.Function):
-    """Nearest stretch by ``scale`` along time + (1, 2*scale+1) smoothing conv; x (B, C, T), w (k,).
-    ``pad_left`` = scale (centred, default) or 2*scale (causal)."""
+    """Nearest stretch by ``scale`` along time + (F, 2*scale+1) smoothing conv over (mel channel, time); x (B, C, T),
+    w (..., F, k) with F = freq_axis_kernel_size (1 in the shipped recipes).  ``pad_left`` = scale (centred, default)
+    or 2*scale (causal).  ``act`` (None / "leaky_relu" / "relu" / "tanh"): the stage's optional nonlinearity, applied in
+    the kernel's epilogue; its gradient mask is taken from the stage output."""
 
     @staticmethod
-    def forward(ctx, x, w, scale, pad_left=None):
+    def forward(ctx, x, w, scale, pad_left=None, act=None, slope=0.0):
         x = _c(x)
         ctx.w_shape = tuple(w.shape)
+        k = w.shape[-1]
+        fk = w.numel() // k
         w = _c(w.reshape(-1))
         _require_device(x, w)
         t_in = x.shape[-1]
         rows = x.numel() // t_in
+        channels = x.shape[-2] if x.dim() >= 2 else 1
         y = torch.empty(x.shape[:-1] + (t_in * scale,), device=x.device, dtype=torch.float32)
-        pad_left = (w.numel() - 1) // 2 if pad_left is None else int(pad_left)
-        _lib.check(_L().pwg_stretch_conv_forward(_ptr(x), _ptr(w), _ptr(y), rows, t_in, scale, w.numel(), pad_left,
-                                                 _stream()), "stretch_conv_forward")
-        ctx.save_for_backward(x, w)
-        ctx.scale, ctx.pad_left = scale, pad_left
+        pad_left = (k - 1) // 2 if pad_left is None else int(pad_left)
+        _lib.check(_L().pwg_stretch_conv_forward(_ptr(x), _ptr(w), _ptr(y), rows, t_in, scale, k, pad_left, channels, fk,
+                                                 ops.ACT[act], float(slope), _stream()), "stretch_conv_forward")
+        if act is None:
+            ctx.save_for_backward(x, w)
+        else:
+            ctx.save_for_backward(x, w, y)
+        ctx.scale, ctx.pad_left, ctx.geom, ctx.act = scale, pad_left, (k, fk, channels), (act, float(slope))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        x, w = ctx.saved_tensors[:2]
         dy = _c(dy)
+        if ctx.act[0] is not None:
+            y, g = ctx.saved_tensors[2], torch.empty_like(dy)
+            _lib.check(_L().pwg_act_backward(_ptr(dy), _ptr(y), _ptr(g), dy.numel(), ops.ACT[ctx.act[0]], ctx.act[1], 1.0,
+                                             _stream()), "act_backward")
+            dy = g
+        k, fk, channels = ctx.geom
         t_in = x.shape[-1]
         rows = x.numel() // t_in
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        ws, ws_n = None, 0
+        if dw is not None:
+            ws_n = int(_L().pwg_stretch_conv_backward_workspace_floats(k, fk))
+            ws = torch.empty(ws_n, device=x.device, dtype=torch.float32)
         _lib.check(_L().pwg_stretch_conv_backward(_ptr(dy), _ptr(x), _ptr(w), _ptr(dx), _ptr(dw), rows, t_in, ctx.scale,
-                                                  w.numel(), ctx.pad_left, _stream()), "stretch_conv_backward")
-        return dx, (None if dw is None else dw.reshape(ctx.w_shape)), None, None
+                                                  k, ctx.pad_left, channels, fk, _ptr(ws), ws_n, _stream()),
+                   "stretch_conv_backward")
+        return dx, (None if dw is None else dw.reshape(ctx.w_shape)), None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# pseudo-QMF filterbank: two polyphase kernels, each the adjoint of the other (csrc/pqmf.hip)
+# ---------------------------------------------------------------------------------------------
+def _pqmf_down(x, h, n_out, pad):
+    b, t = x.shape[0], x.shape[-1]
+    k, length = h.shape
+    y = torch.empty(b, k, n_out, device=x.device, dtype=torch.float32)
+    _lib.check(_L().pwg_pqmf_down(_ptr(x), _ptr(h), _ptr(y), b, t, n_out, k, length, pad, _stream()), "pqmf_down")
+    return y
+
+
+def _pqmf_up(y, g, t_out, pad):
+    b, k, n = y.shape
+    x = torch.empty(b, 1, t_out, device=y.device, dtype=torch.float32)
+    _lib.check(_L().pwg_pqmf_up(_ptr(y), _ptr(g), _ptr(x), b, n, t_out, k, g.shape[1], pad, _stream()), "pqmf_up")
+    return x
+
+
+class PQMFDownFn(torch.autograd.Function):
+    """y[b, k, i] = sum_j h[k, j] x[b, 0, i K + j - pad]; x (B, 1, T), h (K, L) a buffer (no filter gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, h, n_out, pad):
+        x, h = _c(x), _c(h)
+        _require_device(x, h)
+        ctx.save_for_backward(h)
+        ctx.t, ctx.pad = x.shape[-1], pad
+        return _pqmf_down(x, h, n_out, pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (h,) = ctx.saved_tensors
+        return _pqmf_up(_c(dy), h, ctx.t, ctx.pad), None, None, None
+
+
+class PQMFUpFn(torch.autograd.Function):
+    """x[b, 0, t] = sum_k sum_i g[k, t + pad - i K] y[b, k, i]; y (B, K, n), g (K, L) a buffer."""
+
+    @staticmethod
+    def forward(ctx, y, g, t_out, pad):
+        y, g = _c(y), _c(g)
+        _require_device(y, g)
+        ctx.save_for_backward(g)
+        ctx.n, ctx.pad = y.shape[-1], pad
+        return _pqmf_up(y, g, t_out, pad)
+
+    @staticmethod
+    def backward(ctx, dx):
+        (g,) = ctx.saved_tensors
+        return _pqmf_down(_c(dx), g, ctx.n, ctx.pad), None, None, None
 
 
 # ---------------------------------------------------------------------------------------------

@@ -3,11 +3,12 @@
 The reference runs analysis as a full-rate 63-tap FIR (1 -> K channels) followed by a one-hot
 stride-K "pick" convolution, and synthesis as a one-hot zero-stuffing transposed convolution
 followed by a K -> 1 FIR (layers/pqmf.py:120-149), i.e. it computes K x the samples it keeps.
-Here each direction is ONE polyphase launch of the convolution kernel:
-  analysis  = conv1d(x, h_analysis, stride=K, padding=taps/2)
-  synthesis = conv_transpose1d(x, K * flip(h_synthesis), stride=K, padding=taps/2, output_padding=K-1)
-which produce exactly the kept samples.  Filter design follows the same published formulas
-(Kaiser-windowed sinc prototype, cosine modulation).
+Here each direction is ONE launch of a dedicated HBM-bound polyphase kernel (csrc/pqmf.hip, K <= 8):
+  analysis : y[b, k, i] = sum_j h_analysis[k, j] x[b, i K + j - taps/2],   i < floor(T / K)  (any T, as the reference)
+  synthesis: x[b, t]    = sum_k sum_i K h_synthesis[k, taps/2 + i K - t] y[b, k, i]
+which produce exactly the kept samples; each kernel is the other's adjoint, so the backward passes are the same two
+launches.  More than 8 sub-bands run the general convolution kernel in the same polyphase form.  Filter design follows
+the same published formulas (Kaiser-windowed sinc prototype, cosine modulation).
 """
 import numpy as np
 import torch
@@ -55,11 +56,18 @@ class PQMF(torch.nn.Module):
                     transposed=transposed, output_padding=self.subbands - 1, width=1, pad_mode="zero")
 
     def analysis(self, x):
-        """(B, 1, T) -> (B, subbands, T // subbands)."""
-        if x.shape[-1] % self.subbands:
-            raise ValueError("PQMF.analysis: length must be a multiple of the number of sub-bands")
-        return Fn.FusedConvFn.apply(x, self.analysis_filter, None, None, None, self._geom(False), self._fused, None)
+        """(B, 1, T) -> (B, subbands, T // subbands); T need not be a multiple of the number of sub-bands (the
+        reference filters at full rate and keeps samples 0, K, 2K, ... that have a full stride: pqmf.py:120-131)."""
+        n_out = x.shape[-1] // self.subbands
+        if n_out < 1:
+            raise ValueError("PQMF.analysis: the signal is shorter than one sub-band sample")
+        if self.subbands <= 8:
+            return Fn.PQMFDownFn.apply(x, self.analysis_filter[:, 0], n_out, self.taps // 2)
+        y = Fn.FusedConvFn.apply(x, self.analysis_filter, None, None, None, self._geom(False), self._fused, None)
+        return y if y.shape[-1] == n_out else y[..., :n_out].contiguous()
 
     def synthesis(self, x):
         """(B, subbands, T // subbands) -> (B, 1, T)."""
+        if self.subbands <= 8:
+            return Fn.PQMFUpFn.apply(x, self._synthesis_weight[:, 0], x.shape[-1] * self.subbands, self.taps // 2)
         return Fn.FusedConvFn.apply(x, self._synthesis_weight, None, None, None, self._geom(True), self._fused, None)

@@ -17,8 +17,12 @@ class MelSpectrogram(torch.nn.Module):
     def __init__(self, fs=22050, fft_size=1024, hop_size=256, win_length=None, window="hann", num_mels=80, fmin=80,
                  fmax=7600, center=True, normalized=False, onesided=True, eps=1e-10, log_base=10.0):
         super().__init__()
-        if not center or normalized or not onesided:
-            raise NotImplementedError("only center=True, normalized=False, onesided=True (the reference defaults)")
+        if not onesided:
+            # the reference accepts the flag but its own forward cannot run with it: torch.stft then returns n_fft
+            # bins and the matmul with the (n_fft // 2 + 1, num_mels) filterbank fails (losses/mel_loss.py:99-106)
+            raise ValueError("MelSpectrogram(onesided=False): the mel filterbank covers n_fft // 2 + 1 bins "
+                             "(the reference's forward raises a shape error for this option as well)")
+        self.center, self.normalized, self.onesided = bool(center), bool(normalized), True
         self.fft_size = fft_size
         self.win_length = fft_size if win_length is None else win_length
         self.hop_size = hop_size
@@ -30,6 +34,13 @@ class MelSpectrogram(torch.nn.Module):
         fmax = fs / 2 if fmax is None else fmax
         melmat = slaney_mel_basis(fs, fft_size, num_mels, fmin, fmax)  # (mels, bins)
         self.register_buffer("melmat", torch.from_numpy(melmat.T.copy()).float())  # (bins, mels) as the reference
+        stft_eps = eps
+        if self.normalized:
+            # torch.stft(normalized=True) scales the spectrum by n_fft ** -0.5 BEFORE the reference clamps the power:
+            # sqrt(max(P / n, eps)) = sqrt(max(P, eps * n)) / sqrt(n) -- clamp at eps * n, fold 1 / sqrt(n) into the
+            # filterbank the kernels use (the ``melmat`` buffer keeps the reference's values)
+            stft_eps = eps * fft_size
+            melmat = melmat / math.sqrt(fft_size)
         self.register_buffer("mel_weight", torch.from_numpy(melmat[:, :, None].copy()).float(), persistent=False)
         self.log_base = log_base
         if log_base is None:
@@ -40,7 +51,7 @@ class MelSpectrogram(torch.nn.Module):
             self.log_div = math.log(10.0)
         else:
             raise ValueError(f"log_base: {log_base} is not supported.")
-        self.stft_magnitude = STFTMagnitude(fft_size, hop_size, self.win_length, window, eps=eps)
+        self.stft_magnitude = STFTMagnitude(fft_size, hop_size, self.win_length, window, eps=stft_eps, center=self.center)
         # filterbank images of the fused pair-loss kernel (csrc/stft_loss.hip): zero padded to whole 32 x 32 tiles
         bins = melmat.shape[1]
         bins_pad, mels_pad = 32 * ((bins + 31) // 32), 32 * ((num_mels + 31) // 32)
@@ -75,8 +86,10 @@ class MelSpectrogramLoss(torch.nn.Module):
     fused = True  # one fused launch for both signals (csrc/stft_loss.hip); False: the op-by-op chain
 
     def forward(self, y_hat, y):
-        if self.fused and not (torch.is_grad_enabled() and y.requires_grad):
-            ms = self.mel_spectrogram
+        ms = self.mel_spectrogram
+        # the fused pair kernels implement the recipes' form (centred frames, clamp at eps); other STFT options take
+        # the op-by-op chain of the same kernels
+        if self.fused and ms.center and not ms.normalized and not (torch.is_grad_enabled() and y.requires_grad):
             if y_hat.dim() == 3:
                 y_hat = y_hat.reshape(-1, y_hat.size(2))
                 y = y.reshape(-1, y.size(2))

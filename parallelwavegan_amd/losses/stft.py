@@ -36,11 +36,12 @@ def _window(name, win_length):
 class STFTMagnitude(torch.nn.Module):
     """|STFT| with the clamp of the reference losses; output (B, bins, frames)."""
 
-    def __init__(self, fft_size, hop_size, win_length=None, window="hann", eps=1e-7):
+    def __init__(self, fft_size, hop_size, win_length=None, window="hann", eps=1e-7, center=True):
         super().__init__()
         win_length = fft_size if win_length is None else win_length
         assert win_length <= fft_size
         self.fft_size, self.hop_size, self.win_length, self.eps = fft_size, hop_size, win_length, eps
+        self.center = bool(center)  # False: frames start at n * hop of the un-padded signal (torch.stft(center=False))
         self.bins = fft_size // 2 + 1
         self.taps = int(math.ceil(win_length / hop_size))
         off = (fft_size - win_length) // 2  # torch pads the window to n_fft, centred
@@ -77,14 +78,24 @@ class STFTMagnitude(torch.nn.Module):
 
     def frames(self, t):
         # torch.stft(center=True): the signal is padded by n_fft // 2 on both sides (odd n_fft loses one)
+        if not self.center:
+            if t < self.fft_size:
+                raise ValueError(f"STFT(center=False): signal of {t} samples is shorter than n_fft = {self.fft_size}")
+            return 1 + (t - self.fft_size) // self.hop_size
         return 1 + (t + 2 * (self.fft_size // 2) - self.fft_size) // self.hop_size
+
+    @property
+    def fold_pad(self):
+        """Left shift of the folded signal: the reflected n_fft // 2 samples of center=True minus the offset of a
+        window shorter than n_fft (negative without centring: the first windowed sample is x[frame_offset])."""
+        return (self.fft_size // 2 if self.center else 0) - self.frame_offset
 
     def spectrum(self, x):
         """x: (B, T) -> (B, 2*bins, frames) [real rows | imaginary rows]."""
         b, t = x.shape
         n_frames = self.frames(t)
         n_cols = n_frames + self.taps - 1
-        folded = Fn.FrameFoldFn.apply(x, self.fft_size // 2 - self.frame_offset, self.hop_size, n_cols)
+        folded = Fn.FrameFoldFn.apply(x, self.fold_pad, self.hop_size, n_cols)
         return Fn.FusedConvFn.apply(folded, self.basis, None, None, None, self._geom, self._fused, None)
 
     def forward(self, x):
@@ -97,7 +108,7 @@ class STFTMagnitude(torch.nn.Module):
         mean |log|Y| - log|X||] over (B, bins, frames); differentiable w.r.t. ``x`` (``y`` is a constant).
         Power-of-two FFT sizes (256 .. 2048) go through the FFT kernel, every other size (the sub-band losses' 171 /
         384 / 683) through the dense windowed DFT on MFMA."""
-        if self.use_fft and x.shape[-1] > self.fft_size // 2 and self._fft_tables(x.device) is not None:
+        if self.use_fft and self.center and x.shape[-1] > self.fft_size // 2 and self._fft_tables(x.device) is not None:
             return StftFftPairFn.apply(x, y.detach(), self)
         return StftPairSumsFn.apply(x, y.detach(), self)
 

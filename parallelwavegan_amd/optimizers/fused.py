@@ -31,7 +31,7 @@ def _capturing():
 def _reserve(pool, rows):
     """Eager steps keep one pinned (rows, 6) int64 buffer in ``pool`` for the next hipGraph capture."""
     if not pool or pool[-1].shape[0] < rows:
-        pool.append(torch.zeros((rows, 6), dtype=torch.int64).pin_memory())
+        pool.append(torch.zeros((rows, 6), dtype=torch.int64, device="cpu").pin_memory())
 
 
 def _take_reserved(pool, rows):
@@ -169,7 +169,7 @@ class _FusedBase(torch.optim.Optimizer):
             d = self._slot(gi, dev)
             h = self._hyper(group, steps.pop())
             # fresh pinned staging per step (see _table): a pending upload is never overwritten by a later step
-            pin = torch.tensor(h + [float(self.grad_scale)], dtype=torch.float32).pin_memory()
+            pin = torch.tensor(h + [float(self.grad_scale)], dtype=torch.float32, device="cpu").pin_memory()
             d["hyper_dev"].copy_(pin, non_blocking=True)
 
     @torch.no_grad()

@@ -1,0 +1,60 @@
+"""GPU: ``GraphedInference`` never replays stale weight images (a parameter update without ``reset()``
+used to synthesise with the weights of capture time)."""
+import pytest
+import torch
+
+from parallelwavegan_amd import models, ops
+from parallelwavegan_amd.graphs import GraphedInference
+from tests.util import max_abs
+
+pytestmark = pytest.mark.gpu
+
+
+def _small_hifigan(device):
+    torch.manual_seed(7)
+    g = models.HiFiGANGenerator(in_channels=80, out_channels=1, channels=64, kernel_size=7, upsample_scales=[4, 4],
+                                upsample_kernel_sizes=[8, 8], resblock_kernel_sizes=[3, 7],
+                                resblock_dilations=[[1, 3], [1, 3]])
+    return g.to(device).eval()
+
+
+def test_replay_follows_every_kind_of_parameter_update(device):
+    g = _small_hifigan(device)
+    run = GraphedInference(g)
+    c = torch.randn(2, 80, 24, device=device)
+    with torch.no_grad():
+        y0 = run(c).clone()
+        graph0 = run._graphs[next(iter(run._graphs))][0]
+        y0b = run(c).clone()
+        assert run._graphs[next(iter(run._graphs))][0] is graph0, "an unchanged model must replay, not capture again"
+        assert torch.equal(y0, y0b) and max_abs(y0, g(c)) == 0.0
+
+        # 1. in-place update through torch (bumps the version counter)
+        p = g.output_conv[1].weight_v if hasattr(g.output_conv[1], "weight_v") else next(g.parameters())
+        p.mul_(1.5)
+        y1 = run(c).clone()
+        assert run._graphs[next(iter(run._graphs))][0] is not graph0
+        assert max_abs(y1, g(c)) == 0.0 and not torch.equal(y1, y0)
+
+        # 2. update through raw pointers, as the fused optimizers do (no version bump; the engine's own epoch)
+        graph1 = run._graphs[next(iter(run._graphs))][0]
+        q = g.input_conv.bias
+        torch.add(q.detach(), 0.25, out=torch.empty_like(q)).clone()  # (an unrelated op must not invalidate anything)
+        assert run(c) is not None and run._graphs[next(iter(run._graphs))][0] is graph1
+        q.data.add_(0.25)  # .data hides the update from the version counter of ``q``
+        ops.bump_params([q])
+        y2 = run(c).clone()
+        assert run._graphs[next(iter(run._graphs))][0] is not graph1
+        assert max_abs(y2, g(c)) == 0.0 and not torch.equal(y2, y1)
+
+        # 3. load_state_dict / remove_weight_norm
+        sd = {k: v.clone() for k, v in g.state_dict().items()}
+        for k in sd:
+            if k.endswith("weight_g"):
+                sd[k] = sd[k] * 0.9
+        g.load_state_dict(sd)
+        y3 = run(c).clone()
+        assert max_abs(y3, g(c)) == 0.0 and not torch.equal(y3, y2)
+        g.remove_weight_norm()
+        y4 = run(c).clone()
+        assert max_abs(y4, g(c)) == 0.0 and max_abs(y4, y3) <= 1e-5
