@@ -239,10 +239,12 @@ class Trainer(object):
                 inputs = [p for p in gparams if p.requires_grad]
                 if inputs:
                     torch.autograd.backward(starts, seeds, inputs=inputs, retain_graph=gi < last)
+                reducer.zero_missing(gi)  # (recorded in this group's graph segment while capturing)
                 yield (key, gi)
         else:
             loss.backward()
             if reducer is not None:
+                reducer.zero_missing()
                 yield (key, None)
         if reducer is not None:
             opt.grad_scale = 1.0 / reducer.world

@@ -655,69 +655,77 @@ static WgPlan wgrad_plan(int co_g, int ci_g, int groups, int k, int stride, int 
   static const int env_tt = getenv("PWG_WG_TT") ? atoi(getenv("PWG_WG_TT")) : 0;
   static const int env_res = getenv("PWG_WG_RES") ? atoi(getenv("PWG_WG_RES")) : 0;
   p.small = co_g <= 32 || ci_g <= 32 || env_small;
-  if (p.small) {
-    const int per_wave = ceil_div(k, 4);
-    // at most 4 accumulators per wave: with 6 or 11 (k = 41: all taps in one workgroup) the kernel drops
-    // to one wave per SIMD and runs 1.5x slower than three tap groups of 16 taps (tools/bench_wgrad.py)
-    p.tg = per_wave <= 1 ? 1 : per_wave <= 2 ? 2 : per_wave <= 3 ? 3 : 4;
-    p.taps_block = 4 * p.tg;
-  } else {
-    // Taps per workgroup (tools/bench_wgrad.py sweep).  A tap group costs its MFMAs -- TG accumulators,
-    // padded taps included, slower per MFMA when the registers allow only 2 workgroups per CU (TG >= 6)
-    // -- plus the staging of its X tile, which is `stride` times wider for strided convolutions.  More
-    // groups also mean fewer reduction slices per group (fewer slabs).  k = 11 -> 4 groups of 3;
-    // k = 7 -> 7; k = 5 -> 5; k = 41 stride 4 -> 6 groups of 7.
-    float best = 1e30f;
-    p.tg = 1;
-    for (int tg = 1; tg <= 7; ++tg) {  // ties go to the smaller group
-      // far-apart taps (period 11 flattened: dilation 11) widen the shared X tile; past 80 KB only one
-      // workgroup fits a CU, which costs more than re-staging the tile for a second tap group
-      int xs;
-      const size_t lds = wgrad_lds(false, false, tg, 32, stride, dil, width, k, &xs);
-      const float per_mfma = tg <= 3 ? 1.0f : tg <= 5 ? 1.05f : 1.25f;
-      const float cost = ceil_div(k, tg) * (tg * per_mfma + 0.5f * stride) * (lds > 80 * 1024 ? 1.5f : 1.0f);
-      if (cost < best) {
-        best = cost;
-        p.tg = tg;
-      }
-    }
-    if (env_tg > 0) p.tg = env_tg < 7 ? env_tg : 7;
-    p.taps_block = p.tg;
-  }
-  const int bt = p.small ? 32 : 64;
-  // Many far-apart taps (e.g. k = 41 with dilation 5) can exceed the LDS even with per-tap windows:
-  // fall back to fewer taps per workgroup (more tap groups) until the tiles fit.
-  static const int small_tgs[] = {4, 3, 2, 1};
-  for (;;) {
-    const int ntaps_max = k < p.taps_block ? k : p.taps_block;
-    p.win = stride == 1 && width == 1 && (ntaps_max - 1) * dil > 96;  // taps far apart: per-tap windows
-    // longest chunk whose double-buffered tiles keep two workgroups per CU (<= 80 KB), at most ~n_cols
-    p.tt = 32;
-    for (int tt = p.small ? 128 : 32; tt >= 32; tt >>= 1) {
-      int xs;
-      if (tt > 32 && tt > n_cols) continue;
-      if (env_tt > 0 && tt > env_tt && tt > 32) continue;
-      if (wgrad_lds(p.small, p.win, p.taps_block, tt, stride, dil, width, k, &xs) <= 80 * 1024) {
-        p.tt = tt;
-        break;
-      }
-    }
-    p.lds = wgrad_lds(p.small, p.win, p.taps_block, p.tt, stride, dil, width, k, &p.xs_stride);
-    if (p.lds <= 160 * 1024 || p.tg == 1) break;
+  // (second pass: a 64 x 64 tile whose X rows are too long for the LDS even with one tap per workgroup -- a
+  // ConvTranspose1d with stride 11, as StyleMelGAN's noise upsampler has: 31 * 11 + 1 samples per row and chunk --
+  // falls back to the 32 x 32 tile, half the rows per tile)
+  for (int pass = 0; pass < 2; ++pass) {
     if (p.small) {
-      int next = 1;
-      for (int v : small_tgs)
-        if (v < p.tg) {
-          next = v;
-          break;
-        }
-      p.tg = next;
+      const int per_wave = ceil_div(k, 4);
+      // at most 4 accumulators per wave: with 6 or 11 (k = 41: all taps in one workgroup) the kernel drops
+      // to one wave per SIMD and runs 1.5x slower than three tap groups of 16 taps (tools/bench_wgrad.py)
+      p.tg = per_wave <= 1 ? 1 : per_wave <= 2 ? 2 : per_wave <= 3 ? 3 : 4;
       p.taps_block = 4 * p.tg;
     } else {
-      p.tg -= 1;
+      // Taps per workgroup (tools/bench_wgrad.py sweep).  A tap group costs its MFMAs -- TG accumulators,
+      // padded taps included, slower per MFMA when the registers allow only 2 workgroups per CU (TG >= 6)
+      // -- plus the staging of its X tile, which is `stride` times wider for strided convolutions.  More
+      // groups also mean fewer reduction slices per group (fewer slabs).  k = 11 -> 4 groups of 3;
+      // k = 7 -> 7; k = 5 -> 5; k = 41 stride 4 -> 6 groups of 7.
+      float best = 1e30f;
+      p.tg = 1;
+      for (int tg = 1; tg <= 7; ++tg) {  // ties go to the smaller group
+        // far-apart taps (period 11 flattened: dilation 11) widen the shared X tile; past 80 KB only one
+        // workgroup fits a CU, which costs more than re-staging the tile for a second tap group
+        int xs;
+        const size_t lds = wgrad_lds(false, false, tg, 32, stride, dil, width, k, &xs);
+        const float per_mfma = tg <= 3 ? 1.0f : tg <= 5 ? 1.05f : 1.25f;
+        const float cost = ceil_div(k, tg) * (tg * per_mfma + 0.5f * stride) * (lds > 80 * 1024 ? 1.5f : 1.0f);
+        if (cost < best) {
+          best = cost;
+          p.tg = tg;
+        }
+      }
+      if (env_tg > 0) p.tg = env_tg < 7 ? env_tg : 7;
       p.taps_block = p.tg;
     }
+    const int bt = p.small ? 32 : 64;
+    // Many far-apart taps (e.g. k = 41 with dilation 5) can exceed the LDS even with per-tap windows:
+    // fall back to fewer taps per workgroup (more tap groups) until the tiles fit.
+    static const int small_tgs[] = {4, 3, 2, 1};
+    for (;;) {
+      const int ntaps_max = k < p.taps_block ? k : p.taps_block;
+      p.win = stride == 1 && width == 1 && (ntaps_max - 1) * dil > 96;  // taps far apart: per-tap windows
+      // longest chunk whose double-buffered tiles keep two workgroups per CU (<= 80 KB), at most ~n_cols
+      p.tt = 32;
+      for (int tt = p.small ? 128 : 32; tt >= 32; tt >>= 1) {
+        int xs;
+        if (tt > 32 && tt > n_cols) continue;
+        if (env_tt > 0 && tt > env_tt && tt > 32) continue;
+        if (wgrad_lds(p.small, p.win, p.taps_block, tt, stride, dil, width, k, &xs) <= 80 * 1024) {
+          p.tt = tt;
+          break;
+        }
+      }
+      p.lds = wgrad_lds(p.small, p.win, p.taps_block, p.tt, stride, dil, width, k, &p.xs_stride);
+      if (p.lds <= 160 * 1024 || p.tg == 1) break;
+      if (p.small) {
+        int next = 1;
+        for (int v : small_tgs)
+          if (v < p.tg) {
+            next = v;
+            break;
+          }
+        p.tg = next;
+        p.taps_block = 4 * p.tg;
+      } else {
+        p.tg -= 1;
+        p.taps_block = p.tg;
+      }
+    }
+    if (p.lds <= 160 * 1024 || p.small) break;
+    p.small = true;
   }
+  const int bt = p.small ? 32 : 64;
   p.chunks_per_item = ceil_div(n_cols, p.tt);
   p.chunks_total = p.chunks_per_item * batch;
   p.tap_groups = ceil_div(k, p.taps_block);

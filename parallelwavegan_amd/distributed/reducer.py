@@ -47,6 +47,13 @@ def partition_modules(modules, n_groups):
     return [[p for m in reversed(g) for p in reversed(list(m.parameters()))] for g in groups]
 
 
+def _drop_slots(table, keys, owner_ref):
+    for k in keys:
+        e = table.get(k)
+        if e is not None and e[1] is owner_ref:
+            del table[k]
+
+
 class _Bucket:
     def __init__(self, params, device, group):
         self.params = params
@@ -57,6 +64,7 @@ class _Bucket:
             self.offsets[p] = n
             n += p.numel()
         self.flat = torch.zeros(n, device=device, dtype=torch.float32)
+        self.zeroed = False
         self.views = {p: self.flat[o:o + p.numel()].view_as(p) for p, o in self.offsets.items()}
         self.pending = len(params)
         self.work = None
@@ -100,12 +108,22 @@ class GradReducer:
         # backward pass (``epoch``).  PWG_DDP_DIRECT=0: every gradient goes through a hook copy as in round 3.
         self.direct_slots = os.environ.get("PWG_DDP_DIRECT", "1") == "1"
         self.epoch = 0
+        self._filled, self._replaying = set(), False
+        self.zero_fills = 0  # slots zeroed because no gradient arrived (tests / bench)
         self.copies = 0  # hook copies since construction (bench / tests: how many gradients did NOT arrive in place)
         from .. import ops
 
+        import weakref
+
+        me = weakref.ref(self)
+        keys = []
         for p in params:
             if p.is_cuda:
-                ops.GRAD_SLOTS[p.data_ptr()] = [self.flat_grads[p], self, -1]
+                ops.GRAD_SLOTS[p.data_ptr()] = [self.flat_grads[p], me, -1]
+                keys.append(p.data_ptr())
+        # a reducer that is dropped without remove() (a Trainer going out of scope) takes its entries -- and with them
+        # the strong references to its buckets -- out of the process-wide table
+        weakref.finalize(self, _drop_slots, ops.GRAD_SLOTS, keys, me)
         self.defer = False  # True: hooks only fill the buckets (hipGraph capture / replay); the caller exchanges
         self.skip_comm = False  # measurement aid: run the step without its collectives (bench: exposed time)
         # test aid: issue the collectives even in a world of one (exercises RCCL init, its stream semantics and
@@ -121,15 +139,37 @@ class GradReducer:
                 dist.broadcast(t.data, src, group=self.group)
 
     def prepare(self):
-        """Call before each backward whose gradients are to be exchanged."""
+        """Call before each backward whose gradients are to be exchanged.  The buckets are NOT zero-filled (283 MB per
+        discriminator step until round 4): every gradient that arrives overwrites its slot (the first weight-gradient
+        launch of a pass writes it, the hook copy overwrites it), and the slots of parameters that received none are
+        zeroed individually before the bucket goes out (:meth:`zero_missing`)."""
         for b in self.buckets:
             b.pending = sum(1 for p in b.params if p.requires_grad)
             b.work = None
             b.launched = False
             b.events = []
-            b.flat.zero_()  # parameters that receive no gradient this step contribute exactly 0
+            b.zeroed = False
+        self._filled = set()
+        self._replaying = False
         self._next = 0
         self.epoch += 1  # every slot may be claimed once in the coming backward pass
+
+    def zero_missing(self, gi=None):
+        """Zero the slots of the parameters (of exchange group ``gi``, default all) whose gradient has not arrived:
+        they contribute exactly 0 to the sum, as a parameter without a gradient does under DDP.  The trainer calls it
+        after the backward pass of a group -- inside the captured graph segment in hipGraph mode, so that a replay
+        re-zeroes the same slots --; buckets that complete earlier (overlapped launch from a hook) are handled by
+        :meth:`_all_reduce`.  Returns the number of slots zeroed."""
+        n = 0
+        for b in self.buckets:
+            if (gi is None or b.group == gi) and not b.zeroed:
+                for p in b.params:
+                    if id(p) not in self._filled:
+                        b.views[p].zero_()
+                        n += 1
+                b.zeroed = True
+        self.zero_fills += n
+        return n
 
     def begin_replay(self):
         """Host bookkeeping of :meth:`prepare` for a step whose kernels (incl. the bucket zero-fill and
@@ -138,6 +178,8 @@ class GradReducer:
             b.pending = 0
             b.work = None
             b.launched = False
+            b.zeroed = True  # the captured segment re-zeroes the slots that were empty at capture time
+        self._replaying = True
         self._next = 0
 
     def _hook(self, p):
@@ -151,6 +193,9 @@ class GradReducer:
         elif p.grad.data_ptr() != b.views[p].data_ptr():  # (else: the kernel wrote the slot itself, see direct_slots)
             b.views[p].copy_(p.grad)
             self.copies += 1
+            self._filled.add(id(p))
+        else:
+            self._filled.add(id(p))
         p.grad = None  # the bucket slot now owns this gradient
         if not self.defer and b.flat.is_cuda:
             # autograd runs this hook on the stream of the node that produced the gradient; with the
@@ -165,6 +210,12 @@ class GradReducer:
 
     def _all_reduce(self, b):
         b.launched = True
+        if not b.zeroed and not self.defer:
+            for p in b.params:  # (ordered after the producers of this bucket's other slots: see the event waits below)
+                if id(p) not in self._filled:
+                    b.views[p].zero_()
+                    self.zero_fills += 1
+            b.zeroed = True
         if b.events:
             cur = torch.cuda.current_stream(b.flat.device)
             for ev in b.events:
@@ -221,5 +272,5 @@ class GradReducer:
             h.remove()
         for p in self.params:
             e = ops.GRAD_SLOTS.get(p.data_ptr()) if p.is_cuda else None
-            if e is not None and e[1] is self:
+            if e is not None and e[1]() is self:
                 del ops.GRAD_SLOTS[p.data_ptr()]

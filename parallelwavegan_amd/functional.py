@@ -87,13 +87,19 @@ class PreparedWeights:
     keeps one instance per parameter epoch, so every forward / backward of that epoch -- e.g. D(y) and
     D(G(c)) of a discriminator phase -- shares a single scale + pack + pack launch sequence."""
 
-    __slots__ = ("key", "w", "scale", "_fwd", "_fwd_desc", "_bwd", "_res", "_stale")
+    __slots__ = ("key", "w", "_scale", "_fwd", "_fwd_desc", "_bwd", "_res", "_stale")
 
     def __init__(self, key, w, scale, fwd=None, fwd_desc=None):
         """``fwd``: the packed forward image, or None with ``fwd_desc`` (any descriptor of the layer) to build it
         on first use -- layers that only run inside a fused multi-layer kernel never need it."""
-        self.key, self.w, self.scale, self._fwd, self._fwd_desc, self._bwd, self._res = key, w, scale, fwd, fwd_desc, None, None
+        self.key, self.w, self._scale, self._fwd, self._fwd_desc, self._bwd, self._res = key, w, scale, fwd, fwd_desc, None, None
         self._stale = False  # set by weight_bank.WeightBank when it overwrites the (shared, persistent) images
+
+    @property
+    def scale(self):
+        """Weight-norm row scale g / |v| (None without weight norm); a bank-owned buffer like the images: checked."""
+        self._check()
+        return self._scale
 
     def _check(self):
         if self._stale:
@@ -106,21 +112,22 @@ class PreparedWeights:
         self._check()
         if self._fwd is None:
             with torch.no_grad():
-                self._fwd = ops.pack_weight(self._fwd_desc, self.w, self.scale)
+                self._fwd = ops.pack_weight(self._fwd_desc, self.w, self._scale)
         return self._fwd
 
     def res(self):
         """MFMA A-operand image for the one-launch residual unit (csrc/resunit.hip), built on first use."""
+        self._check()
         if self._res is None:
             with torch.no_grad():
-                self._res = ops.resunit_pack_weight(self.w, self.scale)
+                self._res = ops.resunit_pack_weight(self.w, self._scale)
         return self._res
 
     def bwd(self, desc):
         self._check()
         if self._bwd is None:
             with torch.no_grad():
-                self._bwd = ops.pack_weight_bwd(desc, self.w, self.scale)
+                self._bwd = ops.pack_weight_bwd(desc, self.w, self._scale)
         return self._bwd
 
 

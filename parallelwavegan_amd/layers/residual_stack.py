@@ -98,7 +98,7 @@ class ResidualStack(torch.nn.Module):
         ch = conv0.in_channels
         if any(cv.in_channels != ch or cv.out_channels != ch for cv in (conv0, conv1, skip)) or c.shape[1] != ch:
             return False
-        if not c.is_contiguous() or c.data_ptr() % 16:  # (the x tile is staged with 16-B LDS-DMA pieces)
+        if not c.is_contiguous():  # (rows are staged with 16-B LDS-DMA pieces; 4-B source alignment is enough)
             return False
         return ops.resstack_supported(ch, c.shape[2], conv0.dilation)
 

@@ -35,12 +35,16 @@ def bump_params(params):
         p._pwg_epoch = getattr(p, "_pwg_epoch", 0) + 1
 
 
-# Data-parallel gradient slots (distributed.GradReducer): parameter storage address -> [bucket view, owner, claim
-# epoch].  A weight-gradient launch whose layer's parameter has a free slot writes its result straight into the
-# bucket: autograd's AccumulateGrad adopts the returned alias as ``p.grad`` without a copy and the reducer's hook finds
-# nothing left to copy.  A slot is claimed once per backward pass (the owner's epoch); later contributions of the same
-# pass -- the discriminator phase differentiates D(y) and D(G(c)) in one pass -- go to ordinary tensors and autograd
-# adds them up as before.
+# Data-parallel gradient slots (distributed.GradReducer): parameter storage address -> [bucket view, weak reference to
+# the owner, claim epoch] (the owner drops its entries in remove() and, through weakref.finalize, when it is collected).
+# Contract: like ``.grad`` itself, a slot ACCUMULATES every contribution between two ``prepare()`` calls -- a second
+# backward() over a retained graph adds to it, as AccumulateGrad would -- and a node writes its parameters' slots
+# whenever it runs, so the ``inputs=``-restricted backward calls of one pass must cover disjoint sub-networks (the
+# trainer's exchange groups are the independent sub-discriminators).
+# A weight-gradient launch whose layer's parameter has a free slot writes its result straight into the bucket:
+# autograd's AccumulateGrad adopts the returned alias as ``p.grad`` without a copy and the reducer's hook finds nothing
+# left to copy.  A slot is claimed once per backward pass (the owner's epoch); later contributions of the same pass --
+# the discriminator phase differentiates D(y) and D(G(c)) in one pass -- are added into the slot by their own node.
 GRAD_SLOTS = {}
 
 
@@ -54,16 +58,19 @@ def claim_grad_slots(keys_shapes):
     entries = []
     for key, shape in keys_shapes:
         e = GRAD_SLOTS.get(key)
-        if e is None or not e[1].enabled or not e[1].direct_slots or e[0].numel() != _numel(shape):
+        owner = e[1]() if e is not None else None  # (weak: a dropped reducer must not be kept alive by this table)
+        if e is not None and owner is None:
+            del GRAD_SLOTS[key]
+        if owner is None or not owner.enabled or not owner.direct_slots or e[0].numel() != _numel(shape):
             return None, False
-        entries.append((e, shape))
-    states = {e[2] == e[1].epoch for e, _ in entries}
+        entries.append((e, shape, owner))
+    states = {e[2] == owner.epoch for e, _, owner in entries}
     if len(states) != 1:  # (cannot happen while a layer's parameters live in one reducer; stay on the copying path)
         return None, False
     later = states.pop()
-    for e, _ in entries:
-        e[2] = e[1].epoch
-    return [e[0].view(shape) for e, shape in entries], later
+    for e, _, owner in entries:
+        e[2] = owner.epoch
+    return [e[0].view(shape) for e, shape, _ in entries], later
 
 
 def _numel(shape):

@@ -142,3 +142,29 @@ def build_from_config(config, device="cpu", only=None):
                 optimizer=optimizer[k], **config[f"{k}_scheduler_params"])
             for k in ("generator", "discriminator")}
     return model, criterion, optimizer, scheduler
+
+
+def download_pretrained_model(tag_or_url, download_dir=None):
+    """Path of the checkpoint of a pretrained model that is ALREADY in the local cache the reference's downloader fills
+    (``~/.cache/parallel_wavegan/<tag>/checkpoint*.pkl``, /root/reference/parallel_wavegan/utils/utils.py:363-421).
+    Fetching from Google Drive is the reference's distribution plumbing, outside the accelerated path:
+    a tag that is not cached raises instead of going to the network."""
+    import fnmatch
+    import re
+
+    if download_dir is None:
+        download_dir = os.path.expanduser("~/.cache/parallel_wavegan")
+    tag = tag_or_url
+    if "drive.google.com" in tag_or_url:
+        ids = re.compile(r"/[-\w]{25,}").findall(tag_or_url)
+        if not ids:
+            raise ValueError("Unknown URL format. Please use google drive for the model.")
+        tag = ids[0][1:]
+    root = os.path.join(download_dir, tag)
+    found = []
+    for base, _, names in os.walk(root):
+        found += [os.path.join(base, n) for n in names if fnmatch.fnmatch(n, "checkpoint*.pkl")]
+    if not found:
+        raise FileNotFoundError(f"pretrained model {tag_or_url!r} is not in the local cache ({root}); download it with the "
+                                "reference package's `download_pretrained_model` (this engine does not access the network)")
+    return sorted(found)[0]

@@ -116,3 +116,86 @@ def test_grad_reducer_world_size_2():
         assert none_left and zero_ok and nb >= 2
         assert local_only > 1e-4        # before exchange_all the buckets hold this rank's gradients only
         assert err_deferred <= 1e-6, err_deferred
+
+
+def _worker8(rank, world, port, out):
+    """World of 8 (the node size the multi-GPU bench runs at): ranks execute the step in DIFFERENT ways -- even ranks
+    eagerly with overlapped hook launches, odd ranks group by group in deferred (hipGraph) mode; rank 3's last layer
+    gets no gradient at all, rank 5 produces its gradients in reversed group order -- and must still issue the same
+    collective sequence (no hang) and end with the average of the per-rank gradients."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from parallelwavegan_amd.distributed import GradReducer, partition_modules
+
+    torch.manual_seed(0)
+    subs = [torch.nn.Sequential(torch.nn.Linear(6, 12), torch.nn.Tanh(), torch.nn.Linear(12, 2)) for _ in range(3)]
+    model = torch.nn.ModuleList(subs)
+    params = list(model.parameters())
+    groups = partition_modules(list(model), 3)
+    red = GradReducer(params, bucket_bytes=200, groups=groups)
+    red.broadcast_parameters(params)
+    n_buckets = len(red.buckets)
+    assert [b.group for b in red.buckets] == sorted(b.group for b in red.buckets) and n_buckets >= 3
+    g = torch.Generator().manual_seed(7)
+    x_all = torch.randn(world, 4, 6, generator=g)
+
+    def loss_of(r, skip_last):
+        terms = [m(x_all[r]).pow(2).mean() for i, m in enumerate(model) if not (skip_last and i == 2)]
+        return sum(terms)
+
+    # reference: mean over ranks of each rank's own gradient (rank 3 contributes zero for sub-network 2)
+    want = [torch.zeros_like(p) for p in params]
+    for r in range(world):
+        gr = torch.autograd.grad(loss_of(r, r == 3), params, allow_unused=True)
+        for w, t in zip(want, gr):
+            if t is not None:
+                w += t / world
+    errs = []
+    for step in range(2):  # twice: the second step must not see the first step's gradients in un-refilled slots
+        loss = loss_of(rank, rank == 3)
+        if rank % 2 == 0:
+            red.prepare()
+            loss.backward()
+            red.zero_missing()
+            red.finish()
+        else:
+            red.defer = True
+            red.prepare()
+            order = list(range(len(red.groups)))
+            if rank == 5:
+                order.reverse()  # gradients become available in another order; the collectives must not
+            for n, gi in enumerate(order):
+                inputs = [p for p in red.groups[gi] if p.requires_grad]
+                torch.autograd.backward(loss, inputs=inputs, retain_graph=n < len(order) - 1)
+                red.zero_missing(gi)
+            red.finish()
+            red.defer = False
+            red.begin_replay()
+            for gi in range(len(red.groups)):
+                red.exchange_group(gi)
+            red.wait_all()
+        scale = 1.0 / world
+        errs.append(max((red.flat_grads[p] * scale - w).abs().max().item() for p, w in zip(params, want)))
+    out[rank] = (max(errs), n_buckets, red.zero_fills)
+    red.remove()
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_world_size_8_mixed_execution_orders():
+    mp.set_start_method("spawn", force=True)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = _free_port()
+    world = 8
+    procs = [mp.Process(target=_worker8, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0, "a rank hung or died: collective sequences differ between ranks"
+    for r in range(world):
+        err, nb, zero_fills = out[r]
+        assert err <= 1e-6, (r, err)
+        # only rank 3 has empty slots (the 4 parameters of sub-network 2, two steps); nobody zero-fills whole buckets
+        assert zero_fills == (8 if r == 3 else 0), (r, zero_fills)

@@ -47,6 +47,36 @@ def test_resstack_kernel_matches_aten(C, B, T, d, with_bias, with_scale, device)
     assert eh <= 2e-6 and ey <= 3e-6, (eh, ey)
 
 
+@pytest.mark.parametrize("C,T,d", [(48, 512, 3), (96, 256, 9), (192, 128, 27)])
+def test_resstack_kernels_on_a_base_that_is_only_4_byte_aligned(C, T, d, device):
+    """the forward demanded a 16-B aligned x while the data-gradient kernel issued the same 16-B LDS-DMA at
+    8-B aligned offsets.  The instruction is legal at 4-byte source alignment (tools/probes/glds_x4.hip): both kernels
+    give bit-identical results on the same values placed 4, 8 and 12 bytes past a 16-B boundary."""
+    torch.manual_seed(C + d)
+    slope, B = 0.2, 2
+    w1 = torch.randn(C, C, 3, device=device) / (3 * C) ** 0.5
+    w2 = torch.randn(C, C, 1, device=device) / C ** 0.5
+    ws = torch.randn(C, C, 1, device=device) / C ** 0.5
+    b1 = torch.randn(C, device=device)
+    img = ops.resstack_pack_weight(w1, None, w2, None, ws, None)
+    imgb = ops.resstack_pack_weight_bwd(w1, None, w2, None, ws, None)
+    n = B * C * T
+    base_x, base_dy = torch.randn(n + 8, device=device), torch.randn(n + 8, device=device)
+    outs = []
+    for shift in (0, 1, 2, 3):
+        x = torch.empty(n + 8, device=device)[shift:shift + n].view(B, C, T)
+        dy = torch.empty(n + 8, device=device)[shift:shift + n].view(B, C, T)
+        x.copy_(base_x[:n].view(B, C, T))
+        dy.copy_(base_dy[:n].view(B, C, T))
+        assert x.data_ptr() % 16 == 4 * shift
+        with poison_lds():
+            y, h = ops.resstack_forward(x, img, d, slope, b1, None, None, save_h=True)
+            dh, dxp = ops.resstack_backward_data(dy, h, x, imgb, d, slope)
+        outs.append((y.clone(), h.clone(), dh.clone(), dxp.clone()))
+    for o in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
+
+
 def test_resstack_unsupported_geometries():
     assert not ops.resstack_supported(64, 1024, 3)
     assert not ops.resstack_supported(96, 1022, 3)  # T % 4

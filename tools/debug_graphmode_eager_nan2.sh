@@ -1,0 +1,7 @@
+#!/bin/bash
+cd "$(dirname "$0")/.."
+for rep in 1 2 3 4 5 6 7 8; do
+  timeout 300 python tools/debug_graphmode_eager_nan2.py 2>&1 | grep -A40 "^RESULT" > /tmp/nan2.txt
+  head -1 /tmp/nan2.txt
+  if ! grep -q "^RESULT 0 " /tmp/nan2.txt; then cat /tmp/nan2.txt; break; fi
+done
