@@ -76,6 +76,10 @@ class Trainer(object):
             for m in self.model.values():  # independent sub-networks become parallel graph branches
                 if hasattr(m, "branch_streams"):
                     m.branch_streams = True
+            if torch.device(device).type == "cuda":
+                from .. import streams
+
+                streams.reserve(torch.device(device))  # (created before any capture)
             # parameters of the sub-networks receive their gradients on the branch streams by design (the joins
             # are explicit events, streams.py); torch >= 2.9 warns about that once per process
             quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)

@@ -744,23 +744,31 @@ __global__ __launch_bounds__(256) void conv1d_small_cout_kernel(const float* __r
 // ---------------------------------------------------------------------------
 constexpr int SI_TILE = 1024;
 constexpr int SI_MAXK = 16;
+// grid (time tiles, items, channel groups): the output channels are cut into gridDim.z groups so that a launch with
+// few (item, tile) pairs still fills the chip -- HiFi-GAN's scale discriminators at the training batch are 16 items x
+// 8 tiles = 128 workgroups each walking 128 channels (round 4: 126 us = 0.5 TB/s; the write of y is the whole job).
+// VEC: every thread owns 4 CONSECUTIVE columns and stores them as one 16-B piece (t_out % 4 == 0, y 16-B aligned);
+// else the columns of a thread are 256 apart (4-B stores, each wave instruction one contiguous 256-B run).
+template <bool VEC>
 __global__ __launch_bounds__(256) void conv1d_small_cin_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                                const float* __restrict__ bias, float* __restrict__ y,
-                                                               int cin_pad, int m_pad, int cout, int t_in, int t_out,
+                                                               int cin_pad, int m_pad, int cout, int cg, int t_in, int t_out,
                                                                int k, int dil, int pad, int pre_act, float pre_slope,
                                                                int post_act, float post_slope, float out_mul) {
   extern __shared__ float sm[];
-  float* ws = sm;              // [cout][k]
-  float* bs = sm + cout * k;   // [cout]
-  float* xs = bs + cout;       // [SI_TILE + halo]
+  float* ws = sm;            // [cg][k]
+  float* bs = sm + cg * k;   // [cg]
+  float* xs = bs + cg;       // [SI_TILE + halo]
   const int b = blockIdx.y;
   const int t0 = blockIdx.x * SI_TILE;
+  const int c0 = blockIdx.z * cg;
+  const int nc = min(cg, cout - c0);
   const int L = SI_TILE + (k - 1) * dil;
-  for (int i = threadIdx.x; i < cout * k; i += 256) {  // from the packed image [tap][ci][m], ci = 0
+  for (int i = threadIdx.x; i < nc * k; i += 256) {  // from the packed image [tap][ci][m], ci = 0
     const int tap = i % k, c = i / k;
-    ws[i] = wp[(long)tap * cin_pad * m_pad + c];
+    ws[i] = wp[(long)tap * cin_pad * m_pad + c0 + c];
   }
-  for (int i = threadIdx.x; i < cout; i += 256) bs[i] = bias ? bias[i] : 0.f;
+  for (int i = threadIdx.x; i < nc; i += 256) bs[i] = bias ? bias[c0 + i] : 0.f;
   const float* xb = x + (long)b * t_in;
   for (int i = threadIdx.x; i < L; i += 256) {
     const int f = t0 - pad + i;
@@ -772,13 +780,16 @@ __global__ __launch_bounds__(256) void conv1d_small_cin_kernel(const float* __re
     xs[i] = v;
   }
   __syncthreads();
+  // local column of output o of this thread
+  const int col0 = VEC ? 4 * (int)threadIdx.x : (int)threadIdx.x;
+  constexpr int CSTEP = VEC ? 1 : 256;
   float xv[4][SI_MAXK];
 #pragma unroll
   for (int o = 0; o < 4; ++o)
 #pragma unroll
-    for (int tap = 0; tap < SI_MAXK; ++tap) xv[o][tap] = tap < k ? xs[threadIdx.x + 256 * o + tap * dil] : 0.f;
-  float* yb = y + (long)b * cout * t_out;
-  for (int c = 0; c < cout; ++c) {
+    for (int tap = 0; tap < SI_MAXK; ++tap) xv[o][tap] = tap < k ? xs[col0 + CSTEP * o + tap * dil] : 0.f;
+  float* yb = y + ((long)b * cout + c0) * t_out;
+  for (int c = 0; c < nc; ++c) {
     const float bv = bs[c];
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -789,13 +800,21 @@ __global__ __launch_bounds__(256) void conv1d_small_cin_kernel(const float* __re
         for (int o = 0; o < 4; ++o) acc[o] = __builtin_fmaf(wv, xv[o][tap], acc[o]);
       }
     }
+    float r[4];
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
-      const int t = t0 + threadIdx.x + 256 * o;
-      if (t < t_out) {
-        float v = acc[o] + bv;
-        if (out_mul != 1.0f) v *= out_mul;
-        yb[(long)c * t_out + t] = apply_act(v, post_act, post_slope);
+      float v = acc[o] + bv;
+      if (out_mul != 1.0f) v *= out_mul;
+      r[o] = apply_act(v, post_act, post_slope);
+    }
+    if (VEC) {
+      const int t = t0 + col0;
+      if (t < t_out) *reinterpret_cast<float4*>(yb + (long)c * t_out + t) = make_float4(r[0], r[1], r[2], r[3]);
+    } else {
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const int t = t0 + col0 + 256 * o;
+        if (t < t_out) yb[(long)c * t_out + t] = r[o];
       }
     }
   }
@@ -1588,14 +1607,23 @@ extern "C" int pwg_conv1d_forward(const pwg_conv1d_desc* d_in, const float* x, c
     ConvArgs chk;
     rc = fill_args(d, g, x, w_packed, bias, add1, add2, y, &chk);
     if (rc != PWG_OK) return rc;
-    const size_t lds = ((size_t)d->c_out * (d->kernel + 1) + SI_TILE + (d->kernel - 1) * d->dilation) * sizeof(float);
+    // channel groups: at least ~1024 workgroups per launch (4 per CU), never fewer than 8 channels per group
+    const int pairs = ceil_div(d->t_out, SI_TILE) * d->batch;
+    int ngroups = ceil_div(1024, pairs);
+    if (ngroups > d->c_out / 8) ngroups = d->c_out / 8;
+    if (ngroups < 1) ngroups = 1;
+    const int cg = ceil_div(d->c_out, ngroups);
+    ngroups = ceil_div(d->c_out, cg);
+    const size_t lds = ((size_t)cg * (d->kernel + 1) + SI_TILE + (d->kernel - 1) * d->dilation) * sizeof(float);
     PWG_REQUIRE(lds <= 64 * 1024, PWG_ERR_UNSUPPORTED, "conv1d (single input channel): %zu B of LDS", lds);
     const double out_elems = (double)d->batch * d->c_out * d->t_out;
+    const bool vec = d->t_out % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15u) == 0;
     ProfScope prof((hipStream_t)stream, "conv1d_small_cin_kernel", 2.0 * out_elems * d->kernel,
                    4.0 * ((double)d->batch * d->t_in + out_elems));
-    hipLaunchKernelGGL(conv1d_small_cin_kernel, dim3(ceil_div(d->t_out, SI_TILE), d->batch), dim3(256), lds,
-                       (hipStream_t)stream, x, w_packed, bias, y, g.cin_pad, g.m_pad, d->c_out, d->t_in, d->t_out, d->kernel,
-                       d->dilation, d->pad_left, d->pre_act, d->pre_slope, d->post_act, d->post_slope, d->out_mul);
+    hipLaunchKernelGGL(vec ? conv1d_small_cin_kernel<true> : conv1d_small_cin_kernel<false>,
+                       dim3(ceil_div(d->t_out, SI_TILE), d->batch, ngroups), dim3(256), lds, (hipStream_t)stream, x, w_packed,
+                       bias, y, g.cin_pad, g.m_pad, d->c_out, cg, d->t_in, d->t_out, d->kernel, d->dilation, d->pad_left,
+                       d->pre_act, d->pre_slope, d->post_act, d->post_slope, d->out_mul);
     PWG_CHECK_LAUNCH("conv1d_small_cin");
     return PWG_OK;
   }

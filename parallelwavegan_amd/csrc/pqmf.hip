@@ -7,63 +7,82 @@
 //   down:  y[b][k][i] = sum_j  h[k][j]              * x[b][i K + j - pad]            (analysis; adjoint of `up`)
 //   up:    x[b][t]    = sum_k sum_i g[k][t + pad - i K] * y[b][k][i]                 (synthesis; adjoint of `down`)
 // The time window of a workgroup is staged in LDS in POLYPHASE order (plane r holds the samples with index = r mod K),
-// so that the 63 reads of a lane are consecutive across the wave (no bank conflicts); the filter taps are read
-// through wave-uniform (scalar) loads.  Backward passes reuse the two kernels with the roles of the filters swapped.
+// so that the 63 reads of a lane are consecutive across the wave (no bank conflicts); the filter taps sit in LDS too,
+// transposed so that the K taps a step needs are one broadcast read, and every lane owns 4 outputs per sub-band: one
+// tap read feeds 4 K FMAs.  Backward passes reuse the two kernels with the roles of the filters swapped.
 #include "common.h"
 
 namespace pwg {
 
-constexpr int PQMF_TI = 256;   // outputs per sub-band (down) / input positions q (up) per workgroup
-constexpr int PQMF_MAXL = 256;  // filter length limit (taps + 1)
+constexpr int PQMF_NI = 4;                 // outputs (down) / input positions (up) per lane: a filter tap read from LDS
+constexpr int PQMF_TI = 256 * PQMF_NI;     //   feeds NI x K FMAs (round-5 first version: one scalar load per FMA, 0.9 TB/s)
+constexpr int PQMF_MAXL = 256;             // filter length limit (taps + 1)
 
-// grid (ceil(n_out / TI), B); block 256.  LDS: K planes of (TI + ceil(L / K)) floats.
+// grid (ceil(n_out / TI), B); block 256; lane `tid` owns outputs i0 + tid + 256 n, n < NI (consecutive lanes read
+// consecutive LDS words).  LDS: K planes of (TI + qmax) samples, then the filter transposed to [j][k] (K taps of one j
+// contiguous: one broadcast read), zero past the last tap.
 template <int K>
 __global__ __launch_bounds__(256) void pqmf_down_kernel(const float* __restrict__ x, const float* __restrict__ h,
                                                         float* __restrict__ y, int t_in, int n_out, int len, int pad) {
-  extern __shared__ float lds[];
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   const int qmax = (len + K - 1) / K;  // polyphase taps per plane
   const int pl = PQMF_TI + qmax;       // plane length
+  float* ht = lds + K * pl;            // [qmax * K][K]
   const int i0 = blockIdx.x * PQMF_TI;
   const long b = blockIdx.y;
   const float* xb = x + b * (long)t_in;
-  // window of x: u = i0 K - pad ... (covers a in [0, pl) of every plane: u = t0 + a K + r)
-  const int t0 = i0 * K - pad;
+  const int t0 = i0 * K - pad;  // window sample u = t0 + a K + r lives at plane r, position a
   for (int idx = threadIdx.x; idx < pl * K; idx += 256) {
     const int t = t0 + idx;
     const int a = idx / K, r = idx - a * K;
     lds[r * pl + a] = (t >= 0 && t < t_in) ? xb[t] : 0.f;
   }
+  for (int idx = threadIdx.x; idx < qmax * K * K; idx += 256) {
+    const int j = idx / K, k = idx - j * K;
+    ht[idx] = j < len ? h[k * len + j] : 0.f;
+  }
   __syncthreads();
-  float acc[K];
+  float acc[PQMF_NI][K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) acc[k] = 0.f;
+  for (int n = 0; n < PQMF_NI; ++n)
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[n][k] = 0.f;
   const int i = threadIdx.x;
   for (int q = 0; q < qmax; ++q) {
 #pragma unroll
     for (int r = 0; r < K; ++r) {
-      const int j = q * K + r;  // wave-uniform
-      if (j < len) {
-        const float xv = lds[r * pl + i + q];
+      float hv[K], xv[PQMF_NI];
 #pragma unroll
-        for (int k = 0; k < K; ++k) acc[k] = fmaf(h[k * len + j], xv, acc[k]);
-      }
+      for (int k = 0; k < K; ++k) hv[k] = ht[(q * K + r) * K + k];
+#pragma unroll
+      for (int n = 0; n < PQMF_NI; ++n) xv[n] = lds[r * pl + i + 256 * n + q];
+#pragma unroll
+      for (int n = 0; n < PQMF_NI; ++n)
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[n][k] = fmaf(hv[k], xv[n], acc[n][k]);
     }
   }
-  if (i0 + i < n_out) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) y[(b * K + k) * (long)n_out + i0 + i] = acc[k];
+  for (int n = 0; n < PQMF_NI; ++n) {
+    const int io = i0 + i + 256 * n;
+    if (io < n_out) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) y[(b * K + k) * (long)n_out + io] = acc[n][k];
+    }
   }
 }
 
-// grid (ceil(ceil(t_out / K) / TI), B); block 256.  Thread q produces x[qK .. qK + K).
-// d = i - q runs over [dlo, dhi] = [ceil((pad - L + 1) / K), floor((K - 1 + pad) / K)];  tap m = r + pad - d K.
+// grid (ceil(ceil(t_out / K) / TI), B); block 256.  Lane `tid` owns the positions q0 + tid + 256 n and produces
+// x[qK .. qK + K) of each.  d = i - q runs over [dlo, dhi] = [ceil((pad - L + 1) / K), floor((K - 1 + pad) / K)];
+// the taps g[k][r + pad - d K] are laid out in LDS as [k][d - dlo][r], zero where the index leaves the filter.
 template <int K>
 __global__ __launch_bounds__(256) void pqmf_up_kernel(const float* __restrict__ y, const float* __restrict__ g,
                                                       float* __restrict__ x, int n_in, int t_out, int len, int pad,
                                                       int dlo, int dhi) {
-  extern __shared__ float lds[];
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   const int span = dhi - dlo + 1;
   const int pl = PQMF_TI + span;  // per-band window: i in [q0 + dlo, q0 + TI + dhi)
+  float* ct = lds + K * pl;       // [K][span][K]
   const int q0 = blockIdx.x * PQMF_TI;
   const long b = blockIdx.y;
   for (int idx = threadIdx.x; idx < pl * K; idx += 256) {
@@ -71,31 +90,41 @@ __global__ __launch_bounds__(256) void pqmf_up_kernel(const float* __restrict__ 
     const int i = q0 + dlo + a;
     lds[idx] = (i >= 0 && i < n_in) ? y[(b * K + k) * (long)n_in + i] : 0.f;
   }
+  for (int idx = threadIdx.x; idx < K * span * K; idx += 256) {
+    const int r = idx % K, a = (idx / K) % span, k = idx / (K * span);
+    const int m = r + pad - (dlo + a) * K;
+    ct[idx] = (m >= 0 && m < len) ? g[k * len + m] : 0.f;
+  }
   __syncthreads();
-  float acc[K];
+  float acc[PQMF_NI][K];
 #pragma unroll
-  for (int r = 0; r < K; ++r) acc[r] = 0.f;
+  for (int n = 0; n < PQMF_NI; ++n)
+#pragma unroll
+    for (int r = 0; r < K; ++r) acc[n][r] = 0.f;
   const int q = threadIdx.x;
   for (int k = 0; k < K; ++k) {
-    const float* gk = g + k * len;
     for (int a = 0; a < span; ++a) {
-      const int d = dlo + a;
-      const float yv = lds[k * pl + q + a];
+      float cv[K], yv[PQMF_NI];
 #pragma unroll
-      for (int r = 0; r < K; ++r) {
-        const int m = r + pad - d * K;  // wave-uniform
-        if (m >= 0 && m < len) acc[r] = fmaf(gk[m], yv, acc[r]);
-      }
+      for (int r = 0; r < K; ++r) cv[r] = ct[(k * span + a) * K + r];
+#pragma unroll
+      for (int n = 0; n < PQMF_NI; ++n) yv[n] = lds[k * pl + q + 256 * n + a];
+#pragma unroll
+      for (int n = 0; n < PQMF_NI; ++n)
+#pragma unroll
+        for (int r = 0; r < K; ++r) acc[n][r] = fmaf(cv[r], yv[n], acc[n][r]);
     }
   }
-  __syncthreads();  // the y window is dead: reuse the LDS to turn K strided stores per lane into coalesced ones
+  __syncthreads();  // the y window is dead: reuse it to turn K strided stores per lane into coalesced ones
 #pragma unroll
-  for (int r = 0; r < K; ++r) lds[q * K + r] = acc[r];
+  for (int n = 0; n < PQMF_NI; ++n)
+#pragma unroll
+    for (int r = 0; r < K; ++r) lds[(q + 256 * n) * K + r] = acc[n][r];
   __syncthreads();
   float* xb = x + b * (long)t_out;
-  const int tbase = q0 * K;
+  const long tbase = (long)q0 * K;
   for (int idx = threadIdx.x; idx < PQMF_TI * K; idx += 256) {
-    const int t = tbase + idx;
+    const long t = tbase + idx;
     if (t < t_out) xb[t] = lds[idx];
   }
 }
@@ -104,7 +133,7 @@ template <int K>
 static int launch_down(const float* x, const float* h, float* y, int batch, int t_in, int n_out, int len, int pad,
                        hipStream_t s) {
   const int qmax = (len + K - 1) / K;
-  const size_t lds = sizeof(float) * (size_t)K * (PQMF_TI + qmax);
+  const size_t lds = sizeof(float) * ((size_t)K * (PQMF_TI + qmax) + (size_t)qmax * K * K);
   hipLaunchKernelGGL(pqmf_down_kernel<K>, dim3(ceil_div(n_out, PQMF_TI), batch), dim3(256), lds, s, x, h, y, t_in, n_out,
                      len, pad);
   PWG_CHECK_LAUNCH("pqmf_down_kernel");
@@ -118,8 +147,7 @@ static int launch_up(const float* y, const float* g, float* x, int batch, int n_
   const int dlo = lo_num >= 0 ? (lo_num + K - 1) / K : -((-lo_num) / K);
   const int dhi = (K - 1 + pad) / K;
   const int span = dhi - dlo + 1;
-  const size_t win = (size_t)K * (PQMF_TI + span), outs = (size_t)K * PQMF_TI;
-  const size_t lds = sizeof(float) * (win > outs ? win : outs);
+  const size_t lds = sizeof(float) * ((size_t)K * (PQMF_TI + span) + (size_t)K * span * K);  // (window >= K * TI outputs)
   const int nq = ceil_div(t_out, K);
   hipLaunchKernelGGL(pqmf_up_kernel<K>, dim3(ceil_div(nq, PQMF_TI), batch), dim3(256), lds, s, y, g, x, n_in, t_out, len,
                      pad, dlo, dhi);

@@ -45,6 +45,10 @@ class GraphedInference:
 
     def _capture(self, inputs):
         static_in = [t.clone() for t in inputs]
+        if isinstance(self.model, torch.nn.Module) and any(getattr(m, "branch_streams", False) for m in self.model.modules()):
+            from . import streams
+
+            streams.reserve(static_in[0].device)  # branches fork only inside the capture: create their streams first
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():

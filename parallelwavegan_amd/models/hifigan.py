@@ -15,7 +15,7 @@ from ..layers.activation import FusedActivation, PreActivated, deferrable
 from ..layers.causal_conv import CausalConv1d, CausalConvTranspose1d
 from ..layers.conv import Conv1d, Conv2d, ConvTranspose1d
 from ..layers.pooling import get_pooling
-from ..streams import run_branches, run_branches_chained
+from ..streams import fork_now, run_branches, run_branches_chained
 from ..layers.residual_block import HiFiGANResidualBlock as ResidualBlock
 
 
@@ -92,7 +92,8 @@ class HiFiGANGenerator(torch.nn.Module):
         for i in range(self.num_upsamples):
             act, up = self.upsamples[i][0], self.upsamples[i][1]
             c = up(c, pre_act=act.kind, pre_slope=act.slope)
-            if self.branch_streams and nb >= 2 and c.numel() >= self.chain_min_elems and not c.requires_grad and not (
+            fork = self.branch_streams and c.is_cuda and fork_now()  # (side streams only while capturing: streams.py)
+            if fork and nb >= 2 and c.numel() >= self.chain_min_elems and not c.requires_grad and not (
                     torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
                 # inference: the MRF blocks as parallel branches whose LAST kernels are chained -- branch j's last
                 # kernel waits for branch j-1 and adds its result in the epilogue (the reference's running sum
@@ -102,7 +103,7 @@ class HiFiGANGenerator(torch.nn.Module):
                                                                      out_div=float(nb) if j == nb - 1 else 1.0))
                      for j in range(nb)], c.device)
                 continue
-            if self.branch_streams and 2 <= nb <= 3:
+            if fork and 2 <= nb <= 3:
                 # training: the MRF blocks as parallel branches; combined by one small kernel in the same order
                 # ((b0 + b1) + b2) / nb as the reference's running sum
                 outs = run_branches([(lambda j=j, c=c: self.blocks[i * nb + j](c)) for j in range(nb)], c.device, True)

@@ -18,6 +18,29 @@ _POOL = {}
 MAX_SIDE_STREAMS = int(os.environ.get("PWG_MAX_SIDE_STREAMS", "8"))
 
 
+# Fork only while the stream is being captured into a hipGraph (default), or also in eager execution
+# (PWG_EAGER_BRANCH_STREAMS=1).  Inside a capture the side streams are bookkeeping: they become dependency edges of
+# the graph and the replay involves no stream scheduling at all.  Eagerly, the same fork runs 8 HIP streams over the
+# device's hardware queues -- and round 5's strict graph == eager test caught that mode producing, about once in four
+# fresh processes under NaN-poisoned allocations, a whole feature map of a HiFi-GAN scale discriminator that a LATER
+# consumer on the joined stream read as NaN although the next layer on the producing stream had read finite values
+# (tools/debug_graphmode_eager_nan2.py, profiles/r05_eager_branch_streams_nan.txt).  Every cross-stream hand-over in
+# this file is event-ordered and record_stream'ed, the captured form of the same program replays bit-identically, and
+# the eager fork bought nothing a warm-up step needs; so eager steps (graph warm-up, the data-parallel fallback) run
+# their branches one after the other on the caller's stream.
+EAGER_FORK = os.environ.get("PWG_EAGER_BRANCH_STREAMS", "0") == "1"
+
+
+def fork_now(device=None):
+    """Should independent branches be forked onto side streams right now?"""
+    return EAGER_FORK or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())
+
+
+def reserve(device, n=None):
+    """Create the side streams ahead of a capture (stream creation is not a capturable operation)."""
+    return _streams(device, MAX_SIDE_STREAMS if n is None else n)
+
+
 def _streams(device, n):
     key = (device.index if device.index is not None else torch.cuda.current_device())
     pool = _POOL.setdefault(key, [])
@@ -38,7 +61,7 @@ def _record(obj, stream):
 
 def run_branches(branches, device, enabled=True):
     """branches: list of zero-argument callables -> list of their results."""
-    if not enabled or len(branches) < 2 or device.type != "cuda":
+    if not enabled or len(branches) < 2 or device.type != "cuda" or not fork_now():
         return [fn() for fn in branches]
     cur = torch.cuda.current_stream(device)
     side = _streams(device, len(branches))

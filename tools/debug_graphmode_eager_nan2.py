@@ -13,6 +13,7 @@ from tests.util import poison_empty, poison_lds  # noqa: E402
 dev = torch.device("cuda:0")
 gold = load_golden("c3_train_full")
 flags = []  # (label, device bool tensor)
+detail = []
 with poison_lds(), poison_empty():
     tr, batch, model, opt = _build("c3", gold, dev, use_hip_graph=True, graph_warmup_steps=100)
     disc = model["discriminator"]
@@ -24,8 +25,14 @@ with poison_lds(), poison_empty():
         calls[0] += 1
         flags.append((f"step {tr.steps} D-call {calls[0]} input", torch.isfinite(x).all()))
         for i, maps in enumerate(out):
-            for j, m in enumerate(maps):
+            for j, m in enumerate(maps or []):
                 flags.append((f"step {tr.steps} D-call {calls[0]} produced disc {i} map {j} {tuple(m.shape)}", torch.isfinite(m).all()))
+                if j == 0 and i in (0, 1, 2):  # where inside the map are the non-finite values? (no host sync)
+                    bad = ~torch.isfinite(m.reshape(-1))
+                    b8 = bad.to(torch.int8)
+                    detail.append((f"step {tr.steps} D-call {calls[0]} disc {i} map 0 ptr {m.data_ptr():#x} numel {m.numel()}",
+                                   bad.sum(), torch.argmax(b8), m.numel() - 1 - torch.argmax(b8.flip(0)),
+                                   bad.reshape(m.shape[0], -1).sum(dim=1), bad.reshape(-1, m.shape[-1]).sum(dim=1)[:256]))
         return out
 
     disc.forward = fwd
@@ -45,5 +52,10 @@ with poison_lds(), poison_empty():
     torch.cuda.synchronize()
 bad = [lab for lab, f in flags if not bool(f.item())]
 print(f"RESULT {len(bad)} non-finite of {len(flags)} checks")
-for lab in bad[:40]:
+for lab in bad[:12]:
     print("  ", lab)
+for lab, n, first, last, per_item, per_row in detail:
+    if int(n.item()):
+        print("DETAIL", lab, "non-finite", int(n.item()), "first flat index", int(first.item()), "last", int(last.item()))
+        print("   per batch item:", per_item.tolist())
+        print("   per (item, channel) row, first 256 rows:", per_row.tolist())
