@@ -18,6 +18,24 @@ constexpr int PQMF_NI = 4;                 // outputs (down) / input positions (
 constexpr int PQMF_TI = 256 * PQMF_NI;     //   feeds NI x K FMAs (round-5 first version: one scalar load per FMA, 0.9 TB/s)
 constexpr int PQMF_MAXL = 256;             // filter length limit (taps + 1)
 
+// 63 taps x K bands per K samples is 63 FMAs per 8 bytes of traffic: at 6.3 TB/s the launch needs ~50 TFMA/s, more than
+// the 39 T scalar-fp32 FMAs/s of the vector units -- the accumulators of two bands ride in one v_pk_fma_f32.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int K>
+__device__ __forceinline__ void pqmf_fma_row(float (&acc)[K], const float (&c)[K], float v) {
+  constexpr int P = K / 2;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    f32x2 a = {acc[2 * p], acc[2 * p + 1]};
+    const f32x2 cc = {c[2 * p], c[2 * p + 1]};
+    const f32x2 vv = {v, v};
+    a = __builtin_elementwise_fma(cc, vv, a);
+    acc[2 * p] = a.x;
+    acc[2 * p + 1] = a.y;
+  }
+  if (K & 1) acc[K - 1] = fmaf(c[K - 1], v, acc[K - 1]);
+}
+
 // grid (ceil(n_out / TI), B); block 256; lane `tid` owns outputs i0 + tid + 256 n, n < NI (consecutive lanes read
 // consecutive LDS words).  LDS: K planes of (TI + qmax) samples, then the filter transposed to [j][k] (K taps of one j
 // contiguous: one broadcast read), zero past the last tap.
@@ -57,9 +75,7 @@ __global__ __launch_bounds__(256) void pqmf_down_kernel(const float* __restrict_
 #pragma unroll
       for (int n = 0; n < PQMF_NI; ++n) xv[n] = lds[r * pl + i + 256 * n + q];
 #pragma unroll
-      for (int n = 0; n < PQMF_NI; ++n)
-#pragma unroll
-        for (int k = 0; k < K; ++k) acc[n][k] = fmaf(hv[k], xv[n], acc[n][k]);
+      for (int n = 0; n < PQMF_NI; ++n) pqmf_fma_row<K>(acc[n], hv, xv[n]);
     }
   }
 #pragma unroll
@@ -110,9 +126,7 @@ __global__ __launch_bounds__(256) void pqmf_up_kernel(const float* __restrict__ 
 #pragma unroll
       for (int n = 0; n < PQMF_NI; ++n) yv[n] = lds[k * pl + q + 256 * n + a];
 #pragma unroll
-      for (int n = 0; n < PQMF_NI; ++n)
-#pragma unroll
-        for (int r = 0; r < K; ++r) acc[n][r] = fmaf(cv[r], yv[n], acc[n][r]);
+      for (int n = 0; n < PQMF_NI; ++n) pqmf_fma_row<K>(acc[n], cv, yv[n]);
     }
   }
   __syncthreads();  // the y window is dead: reuse it to turn K strided stores per lane into coalesced ones

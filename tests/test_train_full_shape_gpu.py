@@ -149,12 +149,13 @@ def _worst(ha, hb):
     return out
 
 
-# plain-eager vs replay: DIFFERENT launch plans on purpose (the graph mode runs the sub-networks as parallel branches
-# and tells the planner so -- conv_concurrency_hint 0.5: fewer split-K slices, other tile shapes -- i.e. another
-# summation order), so the two trajectories separate by the reference's own chaos: Adam / RAdam turn rounding noise of
-# near-zero gradients into +-lr steps.  Per configuration, ~3x the largest deviation seen in repeated runs
-# (tools/flake_graph_vs_eager.py; C4: lr 1e-3, 3.05 % at step 5)
-LATE_TOL = {"c2": 3e-2, "c3": 3e-2, "c4": 1e-1, "c5": 3e-2}
+# plain-eager vs replay: for HiFi-GAN (C3 / C5) DIFFERENT launch plans on purpose -- the graph mode runs the
+# sub-discriminators as parallel branches and tells the planner so (conv_concurrency_hint 0.5: fewer split-K slices,
+# other tile shapes), i.e. another summation order; C2 / C4 have no branches, their plans are the same and so are the
+# values.  Until round 4 the three fp32-atomic reductions made Adam / RAdam amplify last-bit noise into percent-level
+# drift by step 5 (bar 1e-1); with ordered reductions the two trajectories stay within 1.3e-5 of each other over all
+# six steps (profiles/r05_graph_eq_eager.txt), so one bar of 2e-4 holds for every step.
+PLAIN_TOL = {"c2": 0.0, "c3": 2e-4, "c4": 0.0, "c5": 2e-4}
 
 
 @pytest.mark.parametrize("tag", ["c2", "c3", "c4", "c5"])
@@ -167,7 +168,7 @@ def test_graph_replay_at_the_baseline_batch_shape_follows_eager(device, tag):
     Since round 5 no kernel of the step uses floating-point atomics, so A and B -- same kernels, same plans, same
     inputs -- must agree BIT FOR BIT on every loss of all six steps (a loose bar cannot catch a
     stale pointer or a missed node), and so must a second run of A (run-to-run determinism).  B against C keeps a
-    per-configuration chaos bar."""
+    bar of 2e-4 on every step where the launch plans differ (C3 / C5) and equality where they do not (C2 / C4)."""
     gold = load_golden(f"{tag}_train_full")
     eager_plans, n0 = _six_steps(tag, gold, device, use_hip_graph=True, graph_warmup_steps=100)
     replay, n1 = _six_steps(tag, gold, device, use_hip_graph=True, graph_warmup_steps=2)
@@ -183,5 +184,4 @@ def test_graph_replay_at_the_baseline_batch_shape_follows_eager(device, tag):
     assert all(w == 0.0 for w, _ in w_run), (tag, "two eager runs differ", w_run)
     assert all(w == 0.0 for w, _ in w_cap), (tag, "replay differs from eager launches of the same plans", w_cap)
     for i, (w, k) in enumerate(w_plain):
-        tol = 2e-4 if i < (1 if tag == "c4" else 3) else LATE_TOL[tag]
-        assert w <= tol, (tag, i, k, w)
+        assert w <= PLAIN_TOL[tag], (tag, i, k, w)
