@@ -50,10 +50,21 @@ __global__ __launch_bounds__(256) void pqmf_down_kernel(const float* __restrict_
   const long b = blockIdx.y;
   const float* xb = x + b * (long)t_in;
   const int t0 = i0 * K - pad;  // window sample u = t0 + a K + r lives at plane r, position a
-  for (int idx = threadIdx.x; idx < pl * K; idx += 256) {
-    const int t = t0 + idx;
-    const int a = idx / K, r = idx - a * K;
-    lds[r * pl + a] = (t >= 0 && t < t_in) ? xb[t] : 0.f;
+  // (eight independent loads in flight per lane: the trip count is a run-time value, so the compiler would otherwise
+  // wait for every load before issuing the next one)
+  for (int base = threadIdx.x; base < pl * K; base += 256 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = t0 + base + 256 * u;
+      v[u] = (base + 256 * u < pl * K && t >= 0 && t < t_in) ? xb[t] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + 256 * u;
+      const int a = idx / K, r = idx - a * K;
+      if (idx < pl * K) lds[r * pl + a] = v[u];
+    }
   }
   for (int idx = threadIdx.x; idx < qmax * K * K; idx += 256) {
     const int j = idx / K, k = idx - j * K;
@@ -101,10 +112,18 @@ __global__ __launch_bounds__(256) void pqmf_up_kernel(const float* __restrict__ 
   float* ct = lds + K * pl;       // [K][span][K]
   const int q0 = blockIdx.x * PQMF_TI;
   const long b = blockIdx.y;
-  for (int idx = threadIdx.x; idx < pl * K; idx += 256) {
-    const int k = idx / pl, a = idx - k * pl;
-    const int i = q0 + dlo + a;
-    lds[idx] = (i >= 0 && i < n_in) ? y[(b * K + k) * (long)n_in + i] : 0.f;
+  for (int base = threadIdx.x; base < pl * K; base += 256 * 8) {  // (eight loads in flight per lane, as in `down`)
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + 256 * u;
+      const int k = idx / pl, a = idx - k * pl;
+      const int i = q0 + dlo + a;
+      v[u] = (idx < pl * K && i >= 0 && i < n_in) ? y[(b * K + k) * (long)n_in + i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (base + 256 * u < pl * K) lds[base + 256 * u] = v[u];
   }
   for (int idx = threadIdx.x; idx < K * span * K; idx += 256) {
     const int r = idx % K, a = (idx / K) % span, k = idx / (K * span);
