@@ -158,3 +158,44 @@ def test_load_model_reproduces_reference_golden(tmp_path, device):
         assert max_abs(model(c.to(device)), gold["y"]) <= WAVE_TOL
         model.remove_weight_norm()
         assert max_abs(model.inference(c[0].transpose(0, 1).numpy()), gold["y_inference"]) <= WAVE_TOL
+
+
+def test_download_pretrained_model_resolves_the_local_cache_only(tmp_path):
+    """`parallel_wavegan.utils.download_pretrained_model` (utils/utils.py:363-421 of the reference) is distribution
+    plumbing: the drop-in resolves a tag / Google-Drive URL that is ALREADY in the cache directory the reference's
+    downloader fills and raises, instead of going to the network, for anything else."""
+    from parallelwavegan_amd.utils import download_pretrained_model
+
+    tag = "ljspeech_hifigan.v1"
+    with pytest.raises(FileNotFoundError):
+        download_pretrained_model(tag, download_dir=str(tmp_path))
+    d = tmp_path / tag
+    d.mkdir()
+    (d / "config.yml").write_text("generator_type: HiFiGANGenerator\n")
+    (d / "checkpoint-2500000steps.pkl").write_bytes(b"x")
+    assert download_pretrained_model(tag, download_dir=str(tmp_path)) == str(d / "checkpoint-2500000steps.pkl")
+    url = "https://drive.google.com/file/d/10GYvB_mIKzXzSjD67tSnBhknZRoBjsNb/view?usp=sharing"
+    with pytest.raises(FileNotFoundError):
+        download_pretrained_model(url, download_dir=str(tmp_path))
+    d2 = tmp_path / "10GYvB_mIKzXzSjD67tSnBhknZRoBjsNb"
+    d2.mkdir()
+    (d2 / "checkpoint-400000steps.pkl").write_bytes(b"x")
+    assert download_pretrained_model(url, download_dir=str(tmp_path)).endswith("checkpoint-400000steps.pkl")
+    with pytest.raises(ValueError):
+        download_pretrained_model("https://drive.google.com/short", download_dir=str(tmp_path))
+
+
+def test_prepared_weights_refuse_every_bank_owned_buffer_once_stale():
+    """`.scale` and `.res()` of a holder whose buffers a later WeightBank.ensure() overwrote used to be
+    served silently (only `.fwd` / `.bwd()` were guarded)."""
+    import torch
+
+    from parallelwavegan_amd.functional import PreparedWeights
+
+    w, scale = torch.zeros(4, 2, 3), torch.ones(4)
+    pw = PreparedWeights(("k",), w, scale, fwd=torch.zeros(8))
+    assert pw.scale is scale and pw.fwd is not None
+    pw._stale = True
+    for access in (lambda: pw.scale, lambda: pw.fwd, lambda: pw.res(), lambda: pw.bwd(None)):
+        with pytest.raises(RuntimeError, match="overwritten by a later WeightBank.ensure"):
+            access()

@@ -58,3 +58,36 @@ def test_replay_follows_every_kind_of_parameter_update(device):
         g.remove_weight_norm()
         y4 = run(c).clone()
         assert max_abs(y4, g(c)) == 0.0 and max_abs(y4, y3) <= 1e-5
+
+
+def test_branches_fork_onto_side_streams_only_inside_a_capture(device):
+    """streams.fork_now (round 5): eager execution runs independent branches in order on the caller's
+    stream; inside a hipGraph capture they are forked (and become parallel branches of the graph).  Results are the same
+    either way."""
+    from parallelwavegan_amd import streams
+
+    cur = torch.cuda.current_stream(device)
+    seen = []
+
+    def branch(k):
+        def fn():
+            seen.append(torch.cuda.current_stream(device).cuda_stream)
+            return torch.full((4,), float(k), device=device) * 2.0
+        return fn
+
+    outs = streams.run_branches([branch(k) for k in range(3)], device, True)
+    assert seen == [cur.cuda_stream] * 3 and [o[0].item() for o in outs] == [0.0, 2.0, 4.0]
+    streams.reserve(device)
+    seen.clear()
+    side = torch.cuda.Stream()
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            origin = torch.cuda.current_stream(device).cuda_stream
+            outs = streams.run_branches([branch(k) for k in range(3)], device, True)
+    cur.wait_stream(side)
+    g.replay()
+    torch.cuda.synchronize()
+    assert len(set(seen)) == 3 and origin not in seen, "three branches, three side streams, none the capturing stream"
+    assert [o[0].item() for o in outs] == [0.0, 2.0, 4.0]
