@@ -282,6 +282,8 @@ def bench_train(args, tag, dev, rank, world, dist, steps, warmup, detail=True):
             "exchanged_MB_per_step": {k: round(r.bytes / 1e6, 1) for k, r in tr.reducers.items()},
             "exchange_groups": {k: len(r.groups) for k, r in tr.reducers.items()},
             "buckets": {k: len(r.buckets) for k, r in tr.reducers.items()},
+            "hook_copies_total": {k: r.copies for k, r in tr.reducers.items()},
+            "slots_zeroed_total": {k: r.zero_fills for k, r in tr.reducers.items()},
             "ms_per_step_without_collectives": t_nocomm / steps * 1e3,
             "ms_per_step_without_exchange_of": {k: v / steps * 1e3 for k, v in t_without.items()},
             "rccl": rccl_log_summary(),

@@ -109,6 +109,7 @@ class GradReducer:
         self.direct_slots = os.environ.get("PWG_DDP_DIRECT", "1") == "1"
         self.epoch = 0
         self._filled, self._replaying = set(), False
+        self.zero_buckets = os.environ.get("PWG_DDP_ZERO_BUCKETS", "0") == "1"
         self.zero_fills = 0  # slots zeroed because no gradient arrived (tests / bench)
         self.copies = 0  # hook copies since construction (bench / tests: how many gradients did NOT arrive in place)
         from .. import ops
@@ -149,6 +150,9 @@ class GradReducer:
             b.launched = False
             b.events = []
             b.zeroed = False
+            if self.zero_buckets:  # (PWG_DDP_ZERO_BUCKETS=1: the round-4 behaviour, for A/B measurements)
+                b.flat.zero_()
+                b.zeroed = True
         self._filled = set()
         self._replaying = False
         self._next = 0
