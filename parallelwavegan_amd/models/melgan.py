@@ -17,6 +17,8 @@ def _convs(module):
     return [m for m in module.modules() if isinstance(m, (Conv1d, ConvTranspose1d))]
 
 
+from ..streams import run_branches  # noqa: E402
+
 class _MelGANNormMixin:
     def remove_weight_norm(self):
         for m in _convs(self):
@@ -216,7 +218,18 @@ class MelGANMultiScaleDiscriminator(torch.nn.Module, _MelGANNormMixin):
             self.apply_weight_norm()
         self.reset_parameters()
 
+    branch_streams = False  # set True by the trainer's hipGraph mode: the scales become parallel branches of the graph
+
     def forward(self, x):
+        if self.branch_streams:
+            # the pooled inputs first (cheap, sequential; the trailing pooling of the reference's loop, whose result is
+            # never used, is dropped), then the scale discriminators as independent branches (streams.run_branches
+            # forks only while the stream is being captured)
+            xs = []
+            for _ in self.discriminators:
+                xs.append(x)
+                x = self.pooling(x)
+            return run_branches([(lambda f=f, xi=xi: f(xi)) for f, xi in zip(self.discriminators, xs)], xs[0].device, True)
         outs = []
         for f in self.discriminators:
             outs.append(f(x))
