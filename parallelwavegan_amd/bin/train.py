@@ -89,7 +89,10 @@ class Trainer(object):
                 # the branches share the chip: a launch need not fill it alone (fewer, more efficient tiles and
                 # fewer weight-gradient slabs; measured +2.7 % on the HiFi-GAN V1 step).  Applied around every
                 # step (the hint is process-wide), see _train_step
-                self._concurrency_hint = float(os.environ.get("PWG_CONCURRENCY_HINT", config.get("conv_concurrency_hint", 0.5)))
+                # (a model may state its own default: MelGAN's three scale branches plan for the whole chip)
+                hints = [getattr(m, "branch_concurrency_hint", 0.5) for m in self.model.values() if hasattr(m, "branch_streams")]
+                self._concurrency_hint = float(os.environ.get("PWG_CONCURRENCY_HINT",
+                                                              config.get("conv_concurrency_hint", min(hints))))
         # discriminators whose feature maps stay in pre-activation form inside a training step (HiFi-GAN MPD / MSD,
         # MelGAN): needs a feature-matching loss that applies the activation itself (this package's; a foreign
         # criterion gets the ordinary post-activation maps)

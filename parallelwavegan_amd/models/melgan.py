@@ -219,6 +219,10 @@ class MelGANMultiScaleDiscriminator(torch.nn.Module, _MelGANNormMixin):
         self.reset_parameters()
 
     branch_streams = False  # set True by the trainer's hipGraph mode: the scales become parallel branches of the graph
+    # three branches do not fill the chip the way HiFi-GAN's eight do: the planners keep assuming a launch has it to itself
+    # (measured on the captured C4 step, same box, two rounds each: serial 27.93 ms, branches with hint 0.5 27.85, with
+    # hint 1.0 27.56)
+    branch_concurrency_hint = 1.0
 
     def forward(self, x):
         if self.branch_streams:
