@@ -13,7 +13,7 @@ _POOL = {}
 
 # At most this many side streams: more branches than that share streams round-robin (branches on one stream run in
 # program order).  The device exposes 4 hardware queues to a process by default; measured on the HiFi-GAN V1 step
-# (tools/exp_queues.sh, profiles/r04_queues_and_streams.txt): 8 or 16 queues make the captured step 35 % SLOWER (the
+# (tools/experiments/exp_queues.sh, profiles/r04_queues_and_streams.txt): 8 or 16 queues make the captured step 35 % SLOWER (the
 # concurrent MFMA kernels evict each other's tiles), one stream is 22 % slower than the default.
 MAX_SIDE_STREAMS = int(os.environ.get("PWG_MAX_SIDE_STREAMS", "8"))
 
@@ -24,7 +24,7 @@ MAX_SIDE_STREAMS = int(os.environ.get("PWG_MAX_SIDE_STREAMS", "8"))
 # device's hardware queues -- and round 5's strict graph == eager test caught that mode producing, about once in four
 # fresh processes under NaN-poisoned allocations, a whole feature map of a HiFi-GAN scale discriminator that a LATER
 # consumer on the joined stream read as NaN although the next layer on the producing stream had read finite values
-# (tools/debug_graphmode_eager_nan2.py, profiles/r05_eager_branch_streams_nan.txt).  Every cross-stream hand-over in
+# (tools/experiments/debug_graphmode_eager_nan2.py, profiles/r05_eager_branch_streams_nan.txt).  Every cross-stream hand-over in
 # this file is event-ordered and record_stream'ed, the captured form of the same program replays bit-identically, and
 # the eager fork bought nothing a warm-up step needs; so eager steps (graph warm-up, the data-parallel fallback) run
 # their branches one after the other on the caller's stream.

@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tests.test_train_full_shape_gpu import _build, load_golden  # noqa: E402
 from tests.util import poison_empty, poison_lds  # noqa: E402
 
