@@ -54,7 +54,20 @@ LOOSE = {("c4", "train/fake_loss"): 7e-4}
 # spectral-convergence accumulation (see SC_TOL above); its discriminator is at 6e-4.
 MOM_TOL = {"c2": 2e-4, "c3": 1e-3, "c5": 1e-3, "c4": 3e-3}
 UPD_TOL = {"c2": 3e-4, "c3": 8e-4, "c5": 8e-4, "c4": 8e-3}  # measured 4.6e-5 / 1.1e-4 / 1.5e-4 / 4.3e-3 (C4: as above)
+# Round 5 ("a 0.5 % wgrad error in C4's generator would pass"): C4's wide bars now apply to ONE tensor, the
+# generator's first convolution `melgan.1.weight_v` (2.65e-3 / 4.16e-3 away: it sits right behind the spectral losses,
+# whose fp32 accumulation in the reference is what it inherits); every other generator tensor is within 9.0e-4 /
+# 1.1e-3 and every discriminator tensor within 6.7e-4 / 6.0e-4 of the reference, and is held to ~2x that.
+TENSOR_TOL = {"c4": {"generator": {"default": (2e-3, 2.5e-3), "melgan.1.weight_v": (3e-3, 8e-3)},
+                     "discriminator": {"default": (1.5e-3, 1.5e-3)}}}
 
+
+def _bars(tag, key, names, which):
+    """Per-tensor bars (which = 0: first-moment norms, 1: <update, moment>)."""
+    per = TENSOR_TOL.get(tag, {}).get(key)
+    if per is None:
+        return np.full(len(names), (MOM_TOL, UPD_TOL)[which][tag])
+    return np.array([per.get(n, per["default"])[which] for n in names])
 
 def _build(tag, gold, dev, **overrides):
     with open(os.path.join(ROOT, "tests", "fixtures", "conf", CONF[tag] + ".yaml")) as f:
@@ -114,14 +127,20 @@ def test_one_step_at_the_baseline_batch_shape_matches_the_reference(device, tag)
         got, want = np.array([norms[n] for n in gn]), gold[f"momnorm/{key}"]
         assert np.isfinite(got).all(), (tag, key)
         rel = np.abs(got - want) / (np.abs(want) + 1e-3 * np.abs(want).max())
-        print(f"[full-shape {tag}] {key}: worst first-moment norm {gn[int(rel.argmax())]} rel {rel.max():.2e}")
-        assert rel.max() <= MOM_TOL[tag], (tag, key, gn[int(rel.argmax())], rel.max())
+        top = np.argsort(-rel)[:4]
+        print(f"[full-shape {tag}] {key}: worst first-moment norm {gn[int(rel.argmax())]} rel {rel.max():.2e}"
+              f"  (next: {', '.join('%s %.1e' % (gn[int(i)], rel[int(i)]) for i in top[1:])})")
+        over = rel > _bars(tag, key, gn, 0)
+        assert not over.any(), (tag, key, [(gn[int(i)], float(rel[int(i)])) for i in np.nonzero(over)[0]])
         dots = {names[p]: float(((p.detach() - p0[key][names[p]]).double() * s["exp_avg"].double()).sum())
                 for p, s in opt[key].state.items()}
         got, want = np.array([dots[n] for n in gn]), gold[f"upddot/{key}"]
         rel = np.abs(got - want) / (np.abs(want) + 1e-3 * np.abs(want).max())
-        print(f"[full-shape {tag}] {key}: worst <update, moment> {gn[int(rel.argmax())]} rel {rel.max():.2e}")
-        assert rel.max() <= UPD_TOL[tag], (tag, key, "upddot", gn[int(rel.argmax())], rel.max())
+        top = np.argsort(-rel)[:4]
+        print(f"[full-shape {tag}] {key}: worst <update, moment> {gn[int(rel.argmax())]} rel {rel.max():.2e}"
+              f"  (next: {', '.join('%s %.1e' % (gn[int(i)], rel[int(i)]) for i in top[1:])})")
+        over = rel > _bars(tag, key, gn, 1)
+        assert not over.any(), (tag, key, "upddot", [(gn[int(i)], float(rel[int(i)])) for i in np.nonzero(over)[0]])
 
 
 def _six_steps(tag, gold, device, **cfg):
