@@ -47,6 +47,13 @@ class ResidualStack(torch.nn.Module):
                 Conv1d(channels, channels, 1, bias=bias),
             )
         self.skip_layer = Conv1d(channels, channels, 1, bias=bias)
+        if (self.fuse_unit and not use_causal_conv and kernel_size == 3 and channels in (48, 96, 192) and dilation <= 27
+                and padm.mode == "reflect" and self.stack[0].kind == "leaky_relu" and 0.0 < self.stack[0].slope < 1.0):
+            # the geometries the one-launch unit covers (csrc/resstack.hip): the unit packs its own image of the three
+            # weights, so the weight bank prepares only their row scales; a call the unit turns down at run time
+            # (T % 4 != 0, a non-contiguous input) packs the layers' images lazily
+            for cv in self.unit_convs():
+                cv.bank_images = False
 
     def unit_convs(self):
         """(dilated convolution, 1x1 convolution, skip 1x1) of the non-causal form."""
