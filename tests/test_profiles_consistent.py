@@ -61,3 +61,36 @@ def test_round4_traffic_summary_is_derived_from_the_committed_raw_counters(tmp_p
     assert abs(old["calibration"]["fetch_factor_used"] - 2.0) < 1e-3 and abs(old["calibration"]["write_factor_used"] - 1.0) < 1e-3
     assert old["kernel"] == "conv1d_mfma_dma_kernel" and old["launches_per_forward"] == 47.0
     assert old["kernels"]["conv1d_mfma_dma_kernel"]["traffic_over_algorithmic"] < 1.3
+
+
+def test_round5_traffic_summary_kernel_trace_and_bench_line_agree(tmp_path):
+    """Round 5 (tools/evidence_round5.sh): (i) the traffic summary bench.py cites first is reproducible from the committed
+    raw counter sums and the detail record of the same profiling run; (ii) the committed stdout line of the round cites
+    exactly that number; (iii) the conv family's average launch duration in the rocprofv3 kernel trace agrees with the
+    HIP-event figure `roofline.avg_launch_us` of the same command (the contract's cross-check) within 2 %."""
+    import csv
+
+    out = tmp_path / "traffic.json"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_round5_summary.py"),
+                           os.path.join(ROOT, "profiles", "r05_pmc_hbm_raw.json"),
+                           os.path.join(ROOT, "profiles", "r05_infer_bench_detail.json"), str(out)],
+                          stdout=subprocess.DEVNULL)
+    new = json.load(open(out))
+    old = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_hbm_traffic.json")))
+    for fam in ("conv1d_mfma_dma_kernel", "resunit_kernel"):
+        for key in ("hbm_bytes_per_launch", "algorithmic_bytes_per_launch"):
+            assert abs(new["kernels"][fam][key] - old["kernels"][fam][key]) <= 1e-9 * old["kernels"][fam][key]
+    assert abs(old["calibration"]["fetch_factor_used"] - 2.0) < 1e-3 and abs(old["calibration"]["write_factor_used"] - 1.0) < 1e-3
+    assert old["kernel"] == "conv1d_mfma_dma_kernel" and old["launches_per_forward"] == 47.0
+    assert old["kernels"]["conv1d_mfma_dma_kernel"]["traffic_over_algorithmic"] < 1.3
+    line = json.load(open(os.path.join(ROOT, "profiles", "r05_zz_bench_line.json")))
+    assert line["roofline"]["traffic_source"] == "profiles/r05_pmc_hbm_traffic.json"
+    assert abs(line["roofline"]["traffic"] - old["hbm_bytes_per_launch"]) <= 1.0
+    assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-3
+    # kernel trace of the inference-only command vs the event timing of the same run
+    with open(os.path.join(ROOT, "profiles", "r05_infer_kernel_stats.csv")) as f:
+        rows = [r for r in csv.reader(l for l in f if not l.startswith("#"))]
+    fam = next(r for r in rows if r[0].startswith("FAMILY pwg::conv1d_mfma_dma_kernel"))
+    trace_avg_us = float(fam[3])
+    ev = json.load(open(os.path.join(ROOT, "profiles", "r05_infer_bench_detail.json")))["roofline"]["avg_launch_us"]
+    assert int(fam[1]) == 470 and abs(trace_avg_us - ev) <= 0.02 * trace_avg_us, (trace_avg_us, ev)
