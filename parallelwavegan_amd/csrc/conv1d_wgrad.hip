@@ -734,7 +734,12 @@ static WgPlan wgrad_plan(int co_g, int ci_g, int groups, int k, int stride, int 
   // with the same amount of work; at least 256 columns of reduction per workgroup
   // (with concurrent launches -- the parallel sub-discriminator branches of a captured step -- two resident
   // workgroups per CU per launch are enough, and every slice saved is a slab less to write and reduce)
-  const int res_default = (!p.small && p.tg >= 6) ? 2 : (concurrency_hint() < 1.f ? 2 : 3);
+  // (round 5: the strided (k,1) layers of the period discriminators stage an X tile `stride` x `width`-rows wide per
+  // chunk -- 114 KB of LDS at 512 -> 1024, one workgroup per CU anyway --: fewer, longer slices win there even
+  // stand-alone (tools/bench_wgrad.py, PWG_WG_RES=1 against 3: 128 -> 512 stride 3: 97.8 -> 66.9 us, 512 -> 1024:
+  // 212 -> 195 us))
+  const int res_default = (stride > 1 && width > 1) ? 1
+                          : (!p.small && p.tg >= 6) ? 2 : (concurrency_hint() < 1.f ? 2 : 3);
   const int resident = 256 * (env_res > 0 ? env_res : res_default);
   int splits = resident / (p.tiles * p.tap_groups);
   const int min_chunks = 256 / p.tt > 1 ? 256 / p.tt : 1;
