@@ -90,7 +90,12 @@ class Trainer(object):
                 # fewer weight-gradient slabs; measured +2.7 % on the HiFi-GAN V1 step).  Applied around every
                 # step (the hint is process-wide), see _train_step
                 # (a model may state its own default: MelGAN's three scale branches plan for the whole chip)
-                hints = [getattr(m, "branch_concurrency_hint", 0.5) for m in self.model.values() if hasattr(m, "branch_streams")]
+                # Round 5: the default is 1.0 again.  The matrix kernels of a captured step run one after the other (their
+                # serial times add up to the step, profiles/r05_c3_time_by_category.txt), so each should plan for the whole
+                # chip: same-box A/B, three alternating runs: C3 52.21 -> 51.65 ms, C5 48.75 -> 47.95 ms; stand-alone
+                # the period discriminators' 512 / 1024-channel layers are 14 - 17 % faster under hint 1.0
+                # (tools/bench_dshapes.py).  Round 3's 0.5 predates the split-K fill rule and the per-shape slice counts.
+                hints = [getattr(m, "branch_concurrency_hint", 1.0) for m in self.model.values() if hasattr(m, "branch_streams")]
                 self._concurrency_hint = float(os.environ.get("PWG_CONCURRENCY_HINT",
                                                               config.get("conv_concurrency_hint", min(hints))))
         # discriminators whose feature maps stay in pre-activation form inside a training step (HiFi-GAN MPD / MSD,
