@@ -87,6 +87,13 @@ def run_branches_chained(branches, device):
     of every branch still runs concurrently.  Returns the last branch's result on the caller's stream."""
     cur = torch.cuda.current_stream(device)
     side = _streams(device, len(branches))
+    if len(set(side)) < len(branches):
+        # fewer side streams than branches (PWG_MAX_SIDE_STREAMS < 3): two chained branches would share a stream and the
+        # capture of that pattern crashes inside hipGraphInstantiate -- run the chain in order on the caller's stream
+        res = None
+        for fn in branches:
+            res = fn(lambda r=res: r)
+        return res
     fork = torch.cuda.Event()
     fork.record(cur)
     prev = None  # (completion event, result) of the previous branch
