@@ -645,7 +645,9 @@ typedef struct pwg_opt_chunk {
   int32_t pad_;
 } pwg_opt_chunk;
 /* `step` is the 1-based step count AFTER increment, as torch uses it for bias correction;
- * gradients are multiplied by grad_scale first (1/world_size after a sum all-reduce).   */
+ * gradients are multiplied by grad_scale first (1/world_size after a sum all-reduce).
+ * pwg_adam_step*: weight_decay > 0 is torch.optim.Adam's L2 form (g += wd * p); weight_decay < 0 selects
+ * torch.optim.AdamW's DECOUPLED decay of magnitude |weight_decay| (p *= 1 - lr * |wd| before the update).   */
 int pwg_adam_step(const void* chunks, int32_t n_chunks, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int32_t step, float grad_scale, void* stream);
 int pwg_radam_step(const void* chunks, int32_t n_chunks, float lr, float beta1, float beta2, float eps,

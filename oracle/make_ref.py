@@ -45,6 +45,15 @@ def stage(force=False):
                 if n.endswith(".py"):
                     p = os.path.join(base, n)
                     files[os.path.relpath(p, SRC_ROOT)] = _sha(p)
+    # the recipes' training configurations (egs/*/*/conf/*.yaml): what a user of the reference would hand to
+    # build_from_config; tests/test_reference_recipes_gpu.py runs one small training step of every one of them
+    egs = os.path.join(SRC_ROOT, "egs")
+    for base, _, names in os.walk(egs):
+        if os.path.basename(base) == "conf":
+            for n in sorted(names):
+                if n.endswith(".yaml"):
+                    p = os.path.join(base, n)
+                    files[os.path.relpath(p, SRC_ROOT)] = _sha(p)
     if not force and os.path.exists(manifest_path):
         with open(manifest_path) as f:
             old = json.load(f)
@@ -52,6 +61,7 @@ def stage(force=False):
             return old
     shutil.rmtree(dst, ignore_errors=True)
     shutil.rmtree(os.path.join(DST_ROOT, "test"), ignore_errors=True)
+    shutil.rmtree(os.path.join(DST_ROOT, "egs"), ignore_errors=True)
     for rel in files:
         out = os.path.join(DST_ROOT, rel)
         os.makedirs(os.path.dirname(out), exist_ok=True)

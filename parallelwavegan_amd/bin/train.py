@@ -258,6 +258,27 @@ class Trainer(object):
             if reducer is not None:
                 reducer.zero_missing()
                 yield (key, None)
+        fused = self._is_fused(opt)
+        if not fused:
+            # an optimizer of torch's own (any `*_optimizer_type` the reference resolves from torch.optim: SGD, NAdam
+            # ...): it reads `.grad` and knows nothing of bucket slots or a folded averaging factor (torch's Adam
+            # family even asserts that an attribute called `grad_scale` is unset); the update itself is then ATen's
+            scale = 1.0
+            if reducer is not None:
+                scale = 1.0 / reducer.world
+                for p in params:
+                    p.grad = reducer.flat_grads[p].clone()
+            pairs = [(p, p.grad) for p in params if p.grad is not None]
+            if scale != 1.0:
+                for _, g in pairs:
+                    g.mul_(scale)
+            max_norm = cfg.get(f"{key}_grad_norm", -1)
+            if max_norm > 0:
+                clip_grad_norm_(pairs, max_norm)
+            opt.step()
+            if not self._capturing:
+                self.scheduler[key].step()
+            return
         if reducer is not None:
             opt.grad_scale = 1.0 / reducer.world
             opt.flat_grads = reducer.flat_grads
@@ -278,9 +299,17 @@ class Trainer(object):
             self.scheduler[key].step()
 
     # ------------------------------------------------------------------ hipGraph mode
+    @staticmethod
+    def _is_fused(opt):
+        from ..optimizers.fused import _FusedBase
+
+        return isinstance(opt, _FusedBase)
+
     def _graph_ok(self):
         cfg = self.config
         return (cfg.get("use_hip_graph", False)
+                # the captured step replays the fused optimizers' device-scalar launches; torch's own optimizers run eagerly
+                and all(self._is_fused(o) for o in self.optimizer.values())
                 # models that take host-side random decisions per call (StyleMelGAN's random windows)
                 and all(getattr(self._module(k), "hip_graph_safe", True) for k in ("generator", "discriminator")))
 

@@ -163,7 +163,10 @@ __global__ void adam_multi_kernel(const OptChunk* chunks, float lr, float b1, fl
   for (int i = threadIdx.x; i < c.n; i += blockDim.x) {
     float p = c.p[i];
     float g = c.g[i] * grad_scale;
-    if (wd != 0.f) g += wd * p;
+    // wd > 0: torch.optim.Adam's L2 form (g += wd p);  wd < 0: torch.optim.AdamW's decoupled decay of |wd|
+    // (p *= 1 - lr |wd| before the update, no gradient term)
+    if (wd > 0.f) g += wd * p;
+    else if (wd < 0.f) p *= (1.f + lr * wd);
     const float m = b1 * c.m[i] + (1.f - b1) * g;
     const float v = b2 * c.v[i] + (1.f - b2) * g * g;
     c.m[i] = m;
@@ -208,12 +211,13 @@ __global__ void radam_multi_kernel(const OptChunk* chunks, float lr, float b1, f
 //   RAdam: step_size as radam.py:63-86 (includes lr), aux = 1 if rectified (N_sma >= 5) else 0
 __global__ void adam_multi_dev_kernel(const OptChunk* chunks, const float* hyper) {
   const OptChunk c = chunks[blockIdx.x];
-  const float b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], step = hyper[5],
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], step = hyper[5],
               sqrt_bias_c2 = hyper[6], grad_scale = hyper[7];
   for (int i = threadIdx.x; i < c.n; i += blockDim.x) {
     float p = c.p[i];
     float g = c.g[i] * grad_scale;
-    if (wd != 0.f) g += wd * p;
+    if (wd > 0.f) g += wd * p;                // Adam: L2
+    else if (wd < 0.f) p *= (1.f + lr * wd);  // AdamW: decoupled decay of |wd| (see adam_multi_kernel)
     const float m = b1 * c.m[i] + (1.f - b1) * g;
     const float v = b2 * c.v[i] + (1.f - b2) * g * g;
     c.m[i] = m;

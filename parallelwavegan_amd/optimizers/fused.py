@@ -222,6 +222,20 @@ class Adam(_FusedBase):
                 lr / (1.0 - b1 ** t), math.sqrt(1.0 - b2 ** t)]
 
 
+class AdamW(Adam):
+    """``torch.optim.AdamW`` semantics (decoupled weight decay ``p *= 1 - lr * wd`` before the Adam update; default
+    ``weight_decay`` 1e-2 as torch's) on the same launch: the kernel takes the decay with a negative sign
+    (include/pwg_kernels.h).  Two of the reference's recipes (egs/yesno/voc1/conf/*.v1.debug.yaml) name it."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False, **unused):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad)
+
+    def _hyper(self, group, t):
+        h = super()._hyper(group, t)
+        h[4] = -abs(h[4])
+        return h
+
+
 class RAdam(_FusedBase):
     """Rectified Adam with the update rule of the reference's ``optimizers/radam.py:27-99``."""
 

@@ -125,3 +125,42 @@ def test_two_training_steps_match_the_reference_trainer(family, device):
     # is rounding noise on the entries of small tensors whose gradient is ~0; the losses, first moments and <update, moment>
     # above are held to 2e-4 / 3e-3 / 5e-3)
     _run_and_compare(tr, batches, gold, model, opt, 0.1, final_rtol=1e-2)
+
+
+def test_trainer_steps_an_optimizer_of_torchs_own(device):
+    """``*_optimizer_type`` may name anything ``torch.optim`` has (parallel_wavegan/optimizers/__init__.py re-exports
+    it): such an optimizer runs eagerly from ``.grad`` -- never captured, never handed the fused optimizers' folded
+    averaging factor (torch's Adam family asserts that an attribute called ``grad_scale`` is unset)."""
+    g = models.MelGANGenerator(in_channels=80, channels=64, upsample_scales=[4, 4, 2, 2], stack_kernel_size=3, stacks=1)
+    d = models.ParallelWaveGANDiscriminator(layers=4, conv_channels=16)
+    gen = torch.Generator().manual_seed(3)
+    c = torch.randn(2, 80, 16, generator=gen).to(device)
+    with torch.no_grad():
+        t = g.to(device)(c).shape[-1]
+    y = (0.3 * torch.randn(2, 1, t, generator=gen)).to(device)
+    model = {"generator": g.to(device), "discriminator": d.to(device)}
+    criterion = {"gen_adv": losses.GeneratorAdversarialLoss(), "dis_adv": losses.DiscriminatorAdversarialLoss(),
+                 "stft": losses.MultiResolutionSTFTLoss(fft_sizes=[256, 512], hop_sizes=[32, 64], win_lengths=[128, 256]).to(device)}
+    opt = {"generator": torch.optim.NAdam(model["generator"].parameters(), lr=5e-4),
+           "discriminator": torch.optim.SGD(model["discriminator"].parameters(), lr=1e-3, momentum=0.9)}
+    sched = {k: optimizers.lr_scheduler.StepLR(opt[k], step_size=10 ** 6, gamma=0.5) for k in model}
+    config = dict(generator_type="MelGANGenerator", generator_params={"out_channels": 1}, use_stft_loss=True,
+                  use_subband_stft_loss=False, use_mel_loss=False, use_feat_match_loss=False, lambda_aux=1.0,
+                  lambda_adv=1.0, generator_grad_norm=10.0, discriminator_grad_norm=-1,
+                  generator_train_start_steps=0, discriminator_train_start_steps=0, train_max_steps=100,
+                  save_interval_steps=10 ** 9, eval_interval_steps=10 ** 9, log_interval_steps=10 ** 9,
+                  distributed=False, rank=0, outdir=tempfile.mkdtemp(), progress=False, use_hip_graph=True,
+                  graph_warmup_steps=1)
+    batch = ((c,), y)
+    tr = Trainer(steps=1, epochs=0, data_loader={"train": [batch], "dev": [batch]}, sampler={"train": None, "dev": None},
+                 model=model, criterion=criterion, optimizer=opt, scheduler=sched, config=config, device=device)
+    tr.tqdm = None
+    before = {k: [p.detach().clone() for p in m.parameters()] for k, m in model.items()}
+    for _ in range(4):
+        tr._train_step(batch)
+    tr._flush_pending()
+    assert not tr._graphs  # use_hip_graph is ignored for optimizers the capture cannot replay
+    assert all(np.isfinite(v) for v in tr.total_train_loss.values()), dict(tr.total_train_loss)
+    for k, m in model.items():
+        assert any(not torch.equal(a, b) for a, b in zip(before[k], m.parameters())), k
+    assert opt["generator"].state and opt["discriminator"].state

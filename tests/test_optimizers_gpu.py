@@ -63,3 +63,27 @@ def test_clip_grad_norm_matches_torch(device):
     assert abs(out[0].item() - total.item()) <= 1e-5 * total.item()
     for pc, pd in zip(cpu, dev):
         assert (pc.grad - pd.grad.cpu()).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize("kw", [dict(lr=2e-4, betas=(0.8, 0.99), weight_decay=0.0), dict(lr=1e-3, weight_decay=0.05),
+                                dict(lr=1e-3, amsgrad=True)])
+def test_fused_adamw_matches_torch_adamw(kw, device):
+    """`generator_optimizer_type: AdamW` (egs/yesno/voc1/conf/*.v1.debug.yaml of the reference): decoupled weight decay,
+    torch's default 1e-2, same state-dict layout."""
+    cpu, dev, g = _params(4, device)
+    ref = torch.optim.AdamW(cpu, **kw)
+    opt = optimizers.AdamW(dev, **kw)
+    for step in range(5):
+        for pc, pd in zip(cpu, dev):
+            grad = torch.randn(pc.shape, generator=g) * (10.0 if step == 2 else 0.1)
+            pc.grad = grad.clone()
+            pd.grad = grad.to(device)
+        ref.step()
+        opt.step()
+    for pc, pd in zip(cpu, dev):
+        assert (pc.detach() - pd.detach().cpu()).abs().max().item() <= 2e-6 * (1 + pc.detach().abs().max().item())
+    sd, sr = opt.state_dict(), ref.state_dict()
+    assert sd["state"].keys() == sr["state"].keys()
+    for k in sr["state"]:
+        assert set(sd["state"][k]) == set(sr["state"][k])
+    assert opt.param_groups[0]["weight_decay"] == ref.param_groups[0]["weight_decay"]
