@@ -209,6 +209,21 @@ int pwg_conv1d_forward_cfg(const pwg_conv1d_desc* d, const float* x, const float
                            const float* bias, const float* add1, const float* add2, float* y,
                            int32_t tile_config, int32_t use_dma, void* stream);
 
+/* Diagnostics (host only, no launch, no device needed): the plan pwg_conv1d_forward derives for a descriptor.
+ * has_addends: 1 if add1 / add2 will be passed.  out[8]:
+ *   out[0] kernel family: 0 = MFMA implicit-GEMM kernel, 1 = grouped 16x16x4 kernel, 2 = single-input-channel
+ *          streaming kernel, 3 = few-output-channel streaming kernel (out[1..7] are 0 unless out[0] == 0)
+ *   out[1] tile configuration, out[2] reduction slices (the workspace query is sized for them), out[3] 1 = LDS-DMA path
+ *   out[4] logical tile order inside an XCD's run of workgroups: 0 = the row blocks of a column tile together (they
+ *          share the x window in that XCD's L2), 1 = the items of a (row block, reduction slice) together (they share
+ *          the weight chunk: the 512 / 1024-channel discriminator layers with 9 .. 128 columns per item)
+ *   out[5..7] grid (column tiles, row blocks x groups, items x slices).
+ * pwg_debug_conv_tile_of_workgroup evaluates, on the host, the kernel's own dispatch-id -> logical-tile map
+ * (out[3] = column tile, row block index, item * ksplit + slice): tests walk it to show it is a bijection.        */
+int pwg_conv1d_plan(const pwg_conv1d_desc* d, int32_t has_addends, int32_t* out);
+int pwg_debug_conv_tile_of_workgroup(int32_t grid_x, int32_t grid_y, int32_t grid_z, int32_t row_blocks,
+                                     int32_t ksplit, int32_t item_major, int32_t workgroup, int32_t* out);
+
 /* ------------------------------------------------------------------------- */
 /* One HiFi-GAN MRF residual unit as ONE launch (inference; channels 32 / 64)  */
 /*                                                                            */

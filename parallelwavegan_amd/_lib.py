@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libpwgkernels.so")
 
 PWG_ACT_NONE, PWG_ACT_LEAKY_RELU, PWG_ACT_TANH, PWG_ACT_RELU = 0, 1, 2, 3
 PWG_PAD_ZERO, PWG_PAD_REFLECT, PWG_PAD_REPLICATE = 0, 1, 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 SPECTRAL_NORM_SCRATCH_FLOATS = 257  # PWG_SPECTRAL_NORM_SCRATCH_FLOATS (include/pwg_kernels.h)
 
 
@@ -147,6 +147,8 @@ SIGNATURES = {
                                                      ctypes.c_size_t, _vp]),
     "pwg_conv1d_num_tile_configs": (ctypes.c_int, []),
     "pwg_conv1d_forward_cfg": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "pwg_conv1d_plan": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _i32, ctypes.POINTER(_i32)]),
+    "pwg_debug_conv_tile_of_workgroup": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, ctypes.POINTER(_i32)]),
     "pwg_resunit_supported": (ctypes.c_int, [ctypes.POINTER(ResUnitDesc)]),
     "pwg_resunit_profitable": (ctypes.c_int, [ctypes.POINTER(ResUnitDesc)]),
     "pwg_resunit_packed_weight_floats": (ctypes.c_size_t, [_i32, _i32]),

@@ -71,6 +71,8 @@ struct ConvArgs {
   float* partial;
   long slab_elems;
   int epi_vec;  // 1: y / add1 / add2 / mask are 16-B aligned with y_cstride % 4 == 0 -> LDS-transposed 16-B epilogue
+  int item_major;  // logical tile order inside an XCD's run: 0 = row blocks of a column tile together (x window shared),
+                   // 1 = the items of a (row block, reduction slice) together (weight chunk shared); choose_tile_order
 };
 
 template <int WM, int WN, int WAVES_M, int WAVES_N, int CK>
@@ -249,6 +251,47 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv1d_mfma_kernel(Con
 // ---------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+// XCD-aware tile order: dispatch id -> logical tile (bx = column tile, by = group * mtiles + row block,
+// bz = item * ksplit + reduction slice).  The dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs,
+// each with its own 4 MB L2.  In grid order the row blocks of one column tile -- which stage the SAME x window -- sit
+// gridDim.x ids apart, on different XCDs, and each pulls that window from HBM.  The remap hands every XCD one
+// contiguous run of logical tiles, ordered
+//   item_major = 0: row block fastest, then column tile, group, (item, slice): the row blocks of a column tile (and
+//     the neighbouring column tiles, which share the halo) are resident on one XCD at the same time and meet in its L2;
+//   item_major = 1: item fastest, then column tile, row block, group, slice -- for weight-heavy launches (few columns
+//     per item under a long reduction: the 512 / 1024-channel discriminator layers at T = 9 .. 128), where the operand
+//     worth sharing is the WEIGHT chunk: the workgroups that walk the same (row block, slice) of the weight image, one
+//     per item and column tile, form one run on one XCD, so each XCD streams its 1/8 of the image from HBM instead of
+//     all of it (choose_tile_order decides).
+// A bijection for any grid size, so results do not depend on the dispatch assumption (tests/test_tile_order.py walks
+// it on the host through pwg_debug_conv_tile_of_workgroup).
+__host__ __device__ __forceinline__ void tile_of_workgroup(unsigned lin, unsigned gx, unsigned gy, unsigned gz,
+                                                            unsigned mtiles, unsigned ksplit, int item_major, int& bx,
+                                                            int& by, int& bz) {
+  const unsigned total = gx * gy * gz;
+  const unsigned per = total >> 3, rem = total & 7, xcd = lin & 7, seq = lin >> 3;
+  lin = xcd < rem ? xcd * (per + 1) + seq : rem * (per + 1) + (xcd - rem) * per + seq;
+  const unsigned ngroups = gy / mtiles;
+  if (item_major) {
+    const unsigned nb = gz / ksplit;
+    const unsigned item = lin % nb;
+    lin /= nb;
+    bx = lin % gx;
+    lin /= gx;
+    const unsigned mi = lin % mtiles;
+    lin /= mtiles;
+    by = (lin % ngroups) * mtiles + mi;
+    bz = item * ksplit + lin / ngroups;
+  } else {
+    const unsigned mi = lin % mtiles;
+    lin /= mtiles;
+    bx = lin % gx;
+    lin /= gx;
+    by = (lin % ngroups) * mtiles + mi;
+    bz = lin / ngroups;
+  }
+}
+
 // FAST = true: stride 1, width 1, halo (k-1)*dil <= 64.  The x-tile row stride is the compile-time
 //   constant BN + 64, so every LDS operand address is (one VGPR base per tap) + immediate and the
 //   two column sub-tiles of a wave come from one ds_read2_b32; the pre-activation is
@@ -278,28 +321,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WM * WN >= 8 ? 1 : (WM * W
   const int l31 = lane & 31;
   const int lhi = lane >> 5;
 
-  // XCD-aware tile order.  The dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs, each with its
-  // own 4 MB L2.  In grid order the row blocks of one column tile -- which stage the SAME x window -- sit gridDim.x ids
-  // apart, on different XCDs, and each pulls that window from HBM.  The remap hands every XCD one contiguous run of
-  // logical tiles ordered row-block fastest, then column tile: the row blocks of a column tile (and the neighbouring
-  // column tiles, which share the halo) are resident on one XCD at the same time and meet in its L2.  A bijection for
-  // any grid size, so results do not depend on the dispatch assumption.  (PWG_DBG bit 16 = grid order, for the A/B.)
+  // XCD-aware tile order (tile_of_workgroup above; PWG_DBG bit 16 = grid order, for the A/B)
   const int mtiles = (a.m_g + BM - 1) / BM;
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if (!(a.dbg & 16)) {
-    const unsigned gx = gridDim.x, gy = gridDim.y;
-    const unsigned total = gx * gy * gridDim.z;
-    unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-    const unsigned per = total >> 3, rem = total & 7, xcd = lin & 7, seq = lin >> 3;
-    lin = xcd < rem ? xcd * (per + 1) + seq : rem * (per + 1) + (xcd - rem) * per + seq;
-    const unsigned mi = lin % mtiles;
-    lin /= mtiles;
-    bx = lin % gx;
-    lin /= gx;
-    const unsigned ngroups = gy / mtiles;
-    by = (lin % ngroups) * mtiles + mi;
-    bz = lin / ngroups;
-  }
+  if (!(a.dbg & 16))
+    tile_of_workgroup(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x, gridDim.y, gridDim.z,
+                      (unsigned)mtiles, (unsigned)a.ksplit, a.item_major, bx, by, bz);
   const int n0 = bx * BN;
   const int g = by / mtiles;
   const int m0 = (by % mtiles) * BM;
@@ -1151,6 +1178,41 @@ static size_t scratch_bytes_needed(size_t buf_bytes, size_t scr_bytes, int cin_g
   return (buf_bytes >= scr_bytes && ceil_div(cin_g, ck) >= 2) ? 0 : scr_bytes;
 }
 
+// Logical tile order of a launch (ConvArgs::item_major, tile_of_workgroup).  What an XCD pulls into its L2 is the set
+// of DISTINCT weight tiles (row block x group x reduction slice: k * Cin_slice * BM floats) and x windows (item x
+// column tile x group x slice: Cin_slice * staged columns) its contiguous run of total / 8 logical tiles touches; the
+// two orders are scored by those bytes and the item-major one is taken when it pulls less than 0.8 x the bytes of the
+// x-window-major one (the order every layer ran with up to round 4 keeps the ties).  Examples at B = 16:
+//   1024 -> 1024 k = 5, T = 32, 128 x 32 tiles, 4 slices:  21.3 MB per XCD -> 3.2 MB  (item-major)
+//   128 -> 128 k = 11, T = 51200 (inference), 64 x 256:    55 MB per XCD vs 109 MB      (x-window-major)
+// PWG_TILE_ORDER=0 / 1 forces one order for A/B runs.
+static int choose_tile_order(const Geometry& g, int width, int t_in, int bm, int bn, int gx, int mtiles, int groups,
+                             int batch, int ksplit) {
+  static const int forced = getenv("PWG_TILE_ORDER") ? atoi(getenv("PWG_TILE_ORDER")) : -1;
+  if (forced == 0 || forced == 1) return forced;
+  if (batch < 2) return 0;
+  const double total = (double)gx * mtiles * groups * batch * ksplit;
+  const double run = total / 8.0 < 1.0 ? 1.0 : total / 8.0;
+  auto cdiv = [](double a, double b) { double q = a / b; double f = (double)(long)q; return f < q ? f + 1.0 : f; };
+  auto dmin = [](double a, double b) { return a < b ? a : b; };
+  const double cin_slice = cdiv((double)g.cin_g, (double)ksplit);
+  const int rows = (width == 1) ? bn : ((bn - 1) / width + 2);
+  double xwin = (double)((rows - 1) * g.stride + (g.k_phase - 1) * g.dil + 1) * width;
+  xwin = dmin(xwin, (double)t_in * width);
+  const double wt = 4.0 * g.k_phase * cin_slice * bm;
+  const double xt = 4.0 * cin_slice * xwin;
+  const double gs = (double)groups * ksplit;
+  // x-window-major: row block, column tile, group, slice, item
+  const double w0 = dmin(run, mtiles) * dmin(gs, cdiv(run, (double)mtiles * gx));
+  const double x0 = cdiv(run, mtiles);
+  // item-major: item, column tile, row block, group, slice
+  const double ig = (double)batch * gx;
+  const double w1 = cdiv(run, ig);
+  const double x1 = dmin(run, ig) * dmin(gs, cdiv(run, ig * mtiles));
+  const double bytes0 = w0 * wt + x0 * xt, bytes1 = w1 * wt + x1 * xt;
+  return bytes1 < 0.8 * bytes0 ? 1 : 0;
+}
+
 template <int WM, int WN, int WAVES_M, int WAVES_N, int CK, bool DMA>
 static int launch_conv(const ConvArgs& a0, const Geometry& g, int batch, int groups, hipStream_t stream) {
   constexpr int BM = 32 * WM * WAVES_M;
@@ -1192,6 +1254,7 @@ static int launch_conv(const ConvArgs& a0, const Geometry& g, int batch, int gro
   if (!DMA) a.ksplit = 1;  // (the register-staged kernel has no split-K)
   dim3 grid(ceil_div(g.n_cols, BN), ceil_div(g.m_g, BM) * groups, batch * a.ksplit);
   dim3 block(64 * WAVES_M * WAVES_N);
+  a.item_major = DMA ? choose_tile_order(g, W, a.t_in, BM, BN, (int)grid.x, ceil_div(g.m_g, BM), groups, batch, a.ksplit) : 0;
   // algorithmic work of this launch: 2*taps*Cin_g MACs per real output element, and one read of
   // x / one write of y / one read of each fused addend / one read of the packed weights
   const double out_elems = (double)batch * groups * g.cout_g * a.t_out * a.width;
@@ -1204,9 +1267,10 @@ static int launch_conv(const ConvArgs& a0, const Geometry& g, int batch, int gro
   {
     ProfScope prof(stream,
                    prof_shape_name(DMA ? "conv1d_mfma_dma_kernel" : "conv1d_mfma_kernel",
-                                   "B%d Cin%d M%d(x%dph) Tin%d cols%d k%d s%d d%d g%d W%d tile%dx%dx%d split%d%s", batch,
+                                   "B%d Cin%d M%d(x%dph) Tin%d cols%d k%d s%d d%d g%d W%d tile%dx%dx%d split%d%s%s", batch,
                                    g.cin_g * groups, g.cout_g * groups, g.phases, a.t_in, g.n_cols, g.k_phase, g.stride,
-                                   g.dil, groups, a.width, BM, BN, CK, a.ksplit, a.mask_src ? " dgrad" : ""),
+                                   g.dil, groups, a.width, BM, BN, CK, a.ksplit, a.item_major ? " im" : "",
+                                   a.mask_src ? " dgrad" : ""),
                    flops, bytes);
     hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
   }
@@ -1488,6 +1552,7 @@ static int fill_args(const pwg_conv1d_desc* d, const Geometry& g, const float* x
   a.dbg = dbg;
   a.ksplit = 1;
   a.epi_vec = 0;
+  a.item_major = 0;
   a.partial = nullptr;
   a.slab_elems = (long)d->batch * d->c_out * d->t_out * d->width;
   *out = a;
@@ -1530,6 +1595,23 @@ extern "C" int pwg_conv1d_pack_weight(const pwg_conv1d_desc* d, const float* w, 
   hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   PWG_CHECK_LAUNCH("pack_weight");
   return PWG_OK;
+}
+
+// which launches of pwg_conv1d_forward leave the MFMA kernel (flattened descriptors): the streaming VALU kernels for a
+// single input channel (conv1d_small_cin_kernel) and for <= 4 output channels over a long sequence
+// (conv1d_small_cout_kernel)
+static bool small_cin_applicable(const pwg_conv1d_desc* d, bool has_addends) {
+  static const bool small_cin_on = !(getenv("PWG_SMALL_CIN") && atoi(getenv("PWG_SMALL_CIN")) == 0);
+  return small_cin_on && !d->transposed && d->groups == 1 && d->c_in == 1 && d->width == 1 && d->stride == 1 &&
+         d->pad_mode == PWG_PAD_ZERO && d->kernel <= SI_MAXK && d->c_out >= 8 && d->c_out <= 256 && !has_addends &&
+         d->out_div == 1.0f && d->t_out >= 2048 &&
+         (d->pre_act == PWG_ACT_NONE || d->pre_act == PWG_ACT_LEAKY_RELU || d->pre_act == PWG_ACT_RELU);
+}
+static bool small_cout_applicable(const pwg_conv1d_desc* d, bool has_addends) {
+  return !d->transposed && d->groups == 1 && d->width == 1 && d->stride == 1 && d->pad_mode == PWG_PAD_ZERO &&
+         d->c_out <= 4 && d->c_out * d->c_in * d->kernel <= SC_MAXW && !has_addends && d->out_div == 1.0f &&
+         d->t_out >= 4096 && (d->kernel - 1) * d->dilation <= 1024 &&
+         (d->pre_act == PWG_ACT_NONE || d->pre_act == PWG_ACT_LEAKY_RELU || d->pre_act == PWG_ACT_RELU);
 }
 
 // tile configuration, staging path and split-K factor of a (flattened) forward-form descriptor
@@ -1599,11 +1681,7 @@ extern "C" int pwg_conv1d_forward(const pwg_conv1d_desc* d_in, const float* x, c
   int rc = make_geometry(d, &g);
   if (rc != PWG_OK) return rc;
   if (gconv_forward_applicable(d, add1, add2)) return gconv_forward(d, x, w_packed, bias, y, (hipStream_t)stream);
-  static const bool small_cin_on = !(getenv("PWG_SMALL_CIN") && atoi(getenv("PWG_SMALL_CIN")) == 0);
-  if (small_cin_on && !d->transposed && d->groups == 1 && d->c_in == 1 && d->width == 1 && d->stride == 1 &&
-      d->pad_mode == PWG_PAD_ZERO && d->kernel <= SI_MAXK && d->c_out >= 8 && d->c_out <= 256 && !add1 && !add2 &&
-      d->out_div == 1.0f && d->t_out >= 2048 &&
-      (d->pre_act == PWG_ACT_NONE || d->pre_act == PWG_ACT_LEAKY_RELU || d->pre_act == PWG_ACT_RELU)) {
+  if (small_cin_applicable(d, add1 || add2)) {
     ConvArgs chk;
     rc = fill_args(d, g, x, w_packed, bias, add1, add2, y, &chk);
     if (rc != PWG_OK) return rc;
@@ -1627,10 +1705,7 @@ extern "C" int pwg_conv1d_forward(const pwg_conv1d_desc* d_in, const float* x, c
     PWG_CHECK_LAUNCH("conv1d_small_cin");
     return PWG_OK;
   }
-  if (!d->transposed && d->groups == 1 && d->width == 1 && d->stride == 1 && d->pad_mode == PWG_PAD_ZERO &&
-      d->c_out <= 4 && d->c_out * d->c_in * d->kernel <= SC_MAXW && !add1 && !add2 && d->out_div == 1.0f &&
-      d->t_out >= 4096 && (d->kernel - 1) * d->dilation <= 1024 &&
-      (d->pre_act == PWG_ACT_NONE || d->pre_act == PWG_ACT_LEAKY_RELU || d->pre_act == PWG_ACT_RELU)) {
+  if (small_cout_applicable(d, add1 || add2)) {
     // (the same argument checks as the MFMA path: fill_args validates pointers and the pre-activation)
     ConvArgs chk;
     rc = fill_args(d, g, x, w_packed, bias, add1, add2, y, &chk);
@@ -1722,6 +1797,56 @@ extern "C" int pwg_conv1d_backward_data(const pwg_conv1d_desc* d, const float* d
 }
 
 extern "C" int pwg_conv1d_num_tile_configs(void) { return kNumCfgs; }
+
+extern "C" int pwg_conv1d_plan(const pwg_conv1d_desc* d_in, int32_t has_addends, int32_t* out) {
+  PWG_REQUIRE(d_in != nullptr && out != nullptr, PWG_ERR_NULL, "conv1d_plan: NULL pointer");
+  const pwg_conv1d_desc flat = flatten_width(*d_in);
+  const pwg_conv1d_desc* d = &flat;
+  Geometry g;
+  int rc = make_geometry(d, &g);
+  if (rc != PWG_OK) return rc;
+  for (int i = 0; i < 8; ++i) out[i] = 0;
+  const float* addend = has_addends ? reinterpret_cast<const float*>(out) : nullptr;  // (only tested against NULL)
+  if (gconv_forward_applicable(d, addend, nullptr)) {
+    out[0] = 1;
+    return PWG_OK;
+  }
+  if (small_cin_applicable(d, has_addends != 0)) {
+    out[0] = 2;
+    return PWG_OK;
+  }
+  if (small_cout_applicable(d, has_addends != 0)) {
+    out[0] = 3;
+    return PWG_OK;
+  }
+  const ConvPlan p = plan_conv(d, g);
+  const TileCfg c = cfg_info(p.id);
+  const int gx = ceil_div(g.n_cols, c.bn), mtiles = ceil_div(g.m_g, c.bm);
+  out[1] = p.id;
+  out[2] = p.dma ? p.ksplit : 1;
+  out[3] = p.dma ? 1 : 0;
+  out[4] = p.dma ? choose_tile_order(g, d->width, d->t_in, c.bm, c.bn, gx, mtiles, d->groups, d->batch, out[2]) : 0;
+  out[5] = gx;
+  out[6] = mtiles * d->groups;
+  out[7] = d->batch * out[2];
+  return PWG_OK;
+}
+
+extern "C" int pwg_debug_conv_tile_of_workgroup(int32_t gx, int32_t gy, int32_t gz, int32_t mtiles, int32_t ksplit,
+                                                int32_t item_major, int32_t workgroup, int32_t* out) {
+  PWG_REQUIRE(out != nullptr, PWG_ERR_NULL, "tile_of_workgroup: NULL pointer");
+  PWG_REQUIRE(gx > 0 && gy > 0 && gz > 0 && mtiles > 0 && ksplit > 0 && gy % mtiles == 0 && gz % ksplit == 0 &&
+                  workgroup >= 0 && (long)workgroup < (long)gx * gy * gz,
+              PWG_ERR_BAD_SHAPE, "tile_of_workgroup: inconsistent grid (%d, %d, %d) mtiles %d ksplit %d id %d", gx, gy,
+              gz, mtiles, ksplit, workgroup);
+  int bx, by, bz;
+  tile_of_workgroup((unsigned)workgroup, (unsigned)gx, (unsigned)gy, (unsigned)gz, (unsigned)mtiles, (unsigned)ksplit,
+                    item_major, bx, by, bz);
+  out[0] = bx;
+  out[1] = by;
+  out[2] = bz;
+  return PWG_OK;
+}
 
 extern "C" float pwg_set_concurrency_hint(float fill_scale) {
   const float was = g_fill_scale;

@@ -445,6 +445,28 @@ def num_tile_configs():
     return _lib.lib().pwg_conv1d_num_tile_configs()
 
 
+PLAN_FAMILIES = ("mfma", "grouped", "single_input_channel", "few_output_channels")
+
+
+def conv1d_plan(desc, has_addends=False):
+    """The launch plan ``pwg_conv1d_forward`` derives for ``desc`` (host only: no launch, no device needed):
+    dict(family, tile_config, ksplit, dma, item_major, grid)."""
+    out = (ctypes.c_int32 * 8)()
+    _lib.check(_lib.lib().pwg_conv1d_plan(ctypes.byref(desc), int(bool(has_addends)), out), "conv1d_plan")
+    return dict(family=PLAN_FAMILIES[out[0]], tile_config=out[1], ksplit=out[2], dma=bool(out[3]),
+                item_major=bool(out[4]), grid=(out[5], out[6], out[7]))
+
+
+def conv_tile_of_workgroup(grid, row_blocks, ksplit, item_major, workgroup):
+    """Host evaluation of the convolution kernel's dispatch-id -> logical-tile map (column tile, row block index,
+    item * ksplit + slice)."""
+    out = (ctypes.c_int32 * 3)()
+    _lib.check(_lib.lib().pwg_debug_conv_tile_of_workgroup(int(grid[0]), int(grid[1]), int(grid[2]), int(row_blocks),
+                                                           int(ksplit), int(bool(item_major)), int(workgroup), out),
+               "conv_tile_of_workgroup")
+    return out[0], out[1], out[2]
+
+
 class profile:
     """Context manager: per-kernel-family HIP-event timing of every launch made through the
     C ABI (``pwg_prof_*``).  ``.results`` -> {kernel: dict(ms, launches, flops, bytes)}."""
