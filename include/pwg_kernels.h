@@ -215,8 +215,9 @@ int pwg_conv1d_forward_cfg(const pwg_conv1d_desc* d, const float* x, const float
  *          streaming kernel, 3 = few-output-channel streaming kernel (out[1..7] are 0 unless out[0] == 0)
  *   out[1] tile configuration, out[2] reduction slices (the workspace query is sized for them), out[3] 1 = LDS-DMA path
  *   out[4] logical tile order inside an XCD's run of workgroups: 0 = the row blocks of a column tile together (they
- *          share the x window in that XCD's L2), 1 = the items of a (row block, reduction slice) together (they share
- *          the weight chunk: the 512 / 1024-channel discriminator layers with 9 .. 128 columns per item)
+ *          share the x window in that XCD's L2; the default), 1 = the items of a (row block, reduction slice) together
+ *          (they share the weight chunk; measured no faster, kept selectable: PWG_TILE_ORDER=1 forces it, =2 lets a
+ *          bytes-per-XCD model choose per launch)
  *   out[5..7] grid (column tiles, row blocks x groups, items x slices).
  * pwg_debug_conv_tile_of_workgroup evaluates, on the host, the kernel's own dispatch-id -> logical-tile map
  * (out[3] = column tile, row block index, item * ksplit + slice): tests walk it to show it is a bijection.        */

@@ -1185,11 +1185,16 @@ static size_t scratch_bytes_needed(size_t buf_bytes, size_t scr_bytes, int cin_g
 // x-window-major one (the order every layer ran with up to round 4 keeps the ties).  Examples at B = 16:
 //   1024 -> 1024 k = 5, T = 32, 128 x 32 tiles, 4 slices:  21.3 MB per XCD -> 3.2 MB  (item-major)
 //   128 -> 128 k = 11, T = 51200 (inference), 64 x 256:    55 MB per XCD vs 109 MB      (x-window-major)
-// PWG_TILE_ORDER=0 / 1 forces one order for A/B runs.
+// MEASURED (profiles/r05_tile_order_ab.txt, tools/bench_tile_order.py): outputs bit-identical, and NO change in time
+// on any of the 29 weight-heavy shapes (1024 -> 1024 k = 5 at T = 9 / 17 / 32: 81 - 86 us either way, warm or with the
+// Infinity Cache flushed) nor on the captured C3 / C5 steps (48.98 vs 49.10 ms, 45.71 vs 45.92 ms: run-to-run spread)
+// -- where the weights come from (HBM, Infinity Cache, the XCD's own L2) does not bound these launches.  The
+// x-window-major order therefore stays the default; PWG_TILE_ORDER=2 applies the model, = 1 forces item-major.
 static int choose_tile_order(const Geometry& g, int width, int t_in, int bm, int bn, int gx, int mtiles, int groups,
                              int batch, int ksplit) {
-  static const int forced = getenv("PWG_TILE_ORDER") ? atoi(getenv("PWG_TILE_ORDER")) : -1;
-  if (forced == 0 || forced == 1) return forced;
+  static const int mode = getenv("PWG_TILE_ORDER") ? atoi(getenv("PWG_TILE_ORDER")) : 0;
+  if (mode == 1) return 1;
+  if (mode != 2) return 0;
   if (batch < 2) return 0;
   const double total = (double)gx * mtiles * groups * batch * ksplit;
   const double run = total / 8.0 < 1.0 ? 1.0 : total / 8.0;

@@ -13,6 +13,7 @@ until a parameter changes.  Training: the effective weight is a differentiable H
 (functional.WeightNormFn / SpectralNormFn) feeding functional.FusedConvFn.
 """
 import math
+import os
 
 import torch
 
@@ -24,6 +25,10 @@ class _ConvNd(torch.nn.Module):
     transposed = False
     width_mode = False  # True for the (k, 1) Conv2d: input is (B, C, H, W)
     explicit_pad_min_elems = 1 << 20  # no-grad forward with reflect / replicate padding: see forward()
+    # Batch folding (forward() / _fold_batch): PWG_FOLD_BATCH=0 / 1 switches it, unset = the measured default
+    fold_batch = {"0": False, "1": True}.get(os.environ.get("PWG_FOLD_BATCH", ""), False)
+    fold_max_cols = 40              # output columns per item up to which a layer is folded
+    fold_min_weight_bytes = 4 << 20  # ... if its weight is at least this large (the launch streams it once per item)
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
                  bias=True, output_padding=0, pad_mode="zero"):
@@ -223,15 +228,41 @@ class _ConvNd(torch.nn.Module):
             return True
         return any(t is not None and t.requires_grad for t in tensors)
 
+    def _fold_batch(self, x, add1, add2, precomputed):
+        """Few columns per item under a large weight (the 1024-channel tail of the scale discriminators at T = 9 .. 32,
+        reference: models/hifigan.py:529-601): every item's workgroups stream the whole weight image for a handful of
+        columns, and the launch takes the same ~80 us at T = 9, 17 and 32 (profiles/r05_tile_order_ab.txt).  A
+        convolution along T treats the items exactly like the independent width columns of the period discriminators'
+        (k, 1) layers, so such a layer runs as ONE item of width B over the activations transposed to (C, T, B):
+        B x fewer passes over the weights, full column tiles, and the weight gradient's reduction chunks are full too.
+        The transposing copies (2 x the activation bytes, a few MB) are the price."""
+        if not self.fold_batch or self.width_mode or self.transposed or x.dim() != 3 or self.pad_mode != "zero":
+            return False
+        if add1 is not None or add2 is not None or precomputed is not None:
+            return False
+        b, t_out = x.shape[0], self.out_length(x.shape[-1])
+        w_bytes = 4 * self.out_channels * (self.in_channels // self.groups) * self.kernel_size
+        return b >= 4 and 0 < t_out <= self.fold_max_cols and w_bytes >= self.fold_min_weight_bytes
+
     def forward(self, x, pre_act=None, pre_slope=0.0, post_act=None, post_slope=0.0, add1=None, add2=None,
                 out_mul=1.0, out_div=1.0, precomputed=None):
         """Fused ``post((conv(pre(x)) + bias + add1 + add2) * out_mul / out_div)``.  ``precomputed`` (autograd path
         only): this layer's output as produced by a multi-layer kernel -- no launch, the node is recorded for backward."""
+        if self._fold_batch(x, add1, add2, precomputed):
+            b, c, t = x.shape
+            xf = x.permute(1, 2, 0).contiguous().view(1, c, t, b)
+            y = self._forward(xf, b, pre_act, pre_slope, post_act, post_slope, None, None, out_mul, out_div, None)
+            return y.reshape(self.out_channels, -1, b).permute(2, 0, 1).contiguous()
+        return self._forward(x, 0, pre_act, pre_slope, post_act, post_slope, add1, add2, out_mul, out_div, precomputed)
+
+    def _forward(self, x, folded, pre_act, pre_slope, post_act, post_slope, add1, add2, out_mul, out_div, precomputed):
+        """``folded``: 0, or the width of a batch-folded input (1, C, T, B) of a layer that is not in width mode."""
         fused = dict(pre_act=pre_act, pre_slope=pre_slope, post_act=post_act, post_slope=post_slope,
                      out_mul=out_mul, out_div=out_div)
+        width_mode = self.width_mode or folded > 0
         if self._needs_grad(x, add1, add2):
             geom = self.geom()
-            if self.width_mode:
+            if width_mode:
                 geom["width"] = x.shape[-1]
             if self.pad_mode != "zero" and (self.padding > 0 or self.padding_right > 0):
                 # the backward kernels implement zero padding: pad explicitly (HIP kernel with its own
@@ -250,7 +281,7 @@ class _ConvNd(torch.nn.Module):
         assert precomputed is None, "precomputed outputs only make sense on the autograd path"
         with torch.no_grad():
             b = x.shape[0]
-            if self.width_mode:
+            if width_mode:
                 h, width = x.shape[2], x.shape[3]
                 desc = self.make_desc(b, h, width=width, **fused)
                 y = ops.conv1d_forward(desc, x.reshape(b, x.shape[1], -1).contiguous(), self.packed_weight(),

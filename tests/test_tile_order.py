@@ -95,23 +95,53 @@ def _plan(batch, c_in, c_out, t_in, kernel, stride=1, dilation=1, groups=1, widt
     return ops.conv1d_plan(d)
 
 
-def test_planner_picks_the_item_major_order_for_weight_heavy_layers_only():
-    # HiFi-GAN scale discriminator tail at B = 16 (reference: models/hifigan.py:529-601): 1024 -> 1024, k = 5
-    for t in (9, 17, 32):
-        p = _plan(16, 1024, 1024, t, 5)
-        assert p["family"] == "mfma" and p["dma"] and p["item_major"], (t, p)
-    # period discriminator, period 5: 1024 -> 1024 (5, 1) over 21 rows of 5 samples (reference: models/hifigan.py:314-341)
-    p = _plan(16, 1024, 1024, 21, 5, width=5)
-    assert p["item_major"], p
-    # ... and its strided 512 -> 1024 layer
-    p = _plan(16, 512, 1024, 61, 5, stride=3, width=5, t_out=21)
-    assert p["item_major"], p
-    # generator layers at the inference batch (B16 x 800 frames): x windows dominate, the order of rounds 1-4 stays
-    for c, t, k in ((128, 51200, 11), (256, 6400, 7), (64, 102400, 3), (512, 800, 7)):
-        p = _plan(16, c, c, t, k)
-        assert p["family"] == "mfma" and not p["item_major"], (c, t, k, p)
-    # one item: nothing to share
-    assert not _plan(1, 1024, 1024, 32, 5)["item_major"]
+_PLANNER_CASES = """
+import json, sys
+from parallelwavegan_amd import ops
+def plan(batch, c_in, c_out, t_in, kernel, stride=1, width=1, t_out=None):
+    pad = (kernel - 1) // 2
+    if t_out is None:
+        t_out = ops.conv_out_length(t_in, kernel, stride, 1, pad, pad)
+    return ops.conv1d_plan(ops.make_conv_desc(batch, c_in, c_out, t_in, t_out, kernel, stride, 1, pad, 1, width=width))
+out = dict(tail=[plan(16, 1024, 1024, t, 5) for t in (9, 17, 32)],
+           mpd=[plan(16, 1024, 1024, 21, 5, width=5), plan(16, 512, 1024, 61, 5, stride=3, width=5, t_out=21)],
+           gen=[plan(16, c, c, t, k) for c, t, k in ((128, 51200, 11), (256, 6400, 7), (64, 102400, 3), (512, 800, 7))],
+           one=[plan(1, 1024, 1024, 32, 5)])
+print(json.dumps(out))
+"""
+
+
+def _planner_cases(order):
+    import json
+
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    env.pop("PWG_TILE_ORDER", None)
+    if order is not None:
+        env["PWG_TILE_ORDER"] = str(order)
+    out = subprocess.run([sys.executable, "-c", _PLANNER_CASES], env=env, capture_output=True, text=True, cwd=ROOT,
+                         timeout=300)
+    assert out.returncode == 0, out.stderr
+    return json.loads(out.stdout.strip().split("\n")[-1])
+
+
+def test_traffic_model_picks_the_item_major_order_for_weight_heavy_layers_only():
+    """PWG_TILE_ORDER=2 (the mode is read once per process: subprocesses): the bytes-per-XCD model takes the item-major
+    order for the scale / period discriminators' 1024-channel layers at B = 16 (reference: models/hifigan.py:314-341,
+    :529-601) and leaves the generator layers of the inference batch (x windows dominate) and single items alone."""
+    r = _planner_cases(2)
+    for p in r["tail"] + r["mpd"]:
+        assert p["family"] == "mfma" and p["dma"] and p["item_major"], p
+    for p in r["gen"] + r["one"]:
+        assert p["family"] == "mfma" and not p["item_major"], p
+
+
+def test_default_and_forced_tile_orders():
+    """Default: the x-window-major order everywhere (the item-major one measured no faster, profiles/r05_tile_order_ab.txt);
+    PWG_TILE_ORDER=1 forces item-major."""
+    for order, want in ((None, False), (0, False), (1, True)):
+        r = _planner_cases(order)
+        for p in r["tail"] + r["mpd"] + r["gen"]:
+            assert p["item_major"] == want, (order, p)
 
 
 def test_plan_reports_the_other_kernel_families():
@@ -132,16 +162,3 @@ def test_plan_grid_matches_the_tile_map_domain():
         assert gz == b * p["ksplit"] and gx >= 1 and gy >= 1
         last = gx * gy * gz - 1
         ops.conv_tile_of_workgroup(p["grid"], gy, p["ksplit"], p["item_major"], last)  # (groups = 1: row blocks = gy)
-
-
-def test_tile_order_environment_override():
-    """PWG_TILE_ORDER = 0 / 1 forces one order (read once per process: A/B runs use two processes)."""
-    code = ("from parallelwavegan_amd import ops\n"
-            "d = ops.make_conv_desc(16, 1024, 1024, 32, 32, 5, 1, 1, 2, 1)\n"
-            "e = ops.make_conv_desc(16, 128, 128, 51200, 51200, 11, 1, 1, 5, 1)\n"
-            "print(int(ops.conv1d_plan(d)['item_major']), int(ops.conv1d_plan(e)['item_major']))\n")
-    for val, want in (("0", "0 0"), ("1", "1 1")):
-        env = dict(os.environ, PWG_TILE_ORDER=val, PYTHONPATH=ROOT)
-        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=ROOT, timeout=300)
-        assert out.returncode == 0, out.stderr
-        assert out.stdout.split("\n")[-2].strip() == want, (val, out.stdout)
