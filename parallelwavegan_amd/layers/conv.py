@@ -25,9 +25,11 @@ class _ConvNd(torch.nn.Module):
     transposed = False
     width_mode = False  # True for the (k, 1) Conv2d: input is (B, C, H, W)
     explicit_pad_min_elems = 1 << 20  # no-grad forward with reflect / replicate padding: see forward()
-    # Batch folding (forward() / _fold_batch): PWG_FOLD_BATCH=0 / 1 switches it, unset = the measured default
-    fold_batch = {"0": False, "1": True}.get(os.environ.get("PWG_FOLD_BATCH", ""), False)
-    fold_max_cols = 40              # output columns per item up to which a layer is folded
+    # Batch folding (forward() / _fold_batch): on by default (C3 49.36 -> 48.29 ms, C5 45.52 -> 44.29 ms per captured
+    # step, C4 / C2 unchanged; 64 or 128 columns per item measured slower: profiles/r05_fold_batch_ab.txt);
+    # PWG_FOLD_BATCH=0 switches it off for A/B runs
+    fold_batch = {"0": False, "1": True}.get(os.environ.get("PWG_FOLD_BATCH", ""), True)
+    fold_max_cols = int(os.environ.get("PWG_FOLD_MAX_COLS", 40))  # output columns per item up to which a layer is folded
     fold_min_weight_bytes = 4 << 20  # ... if its weight is at least this large (the launch streams it once per item)
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
