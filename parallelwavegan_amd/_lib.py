@@ -7,7 +7,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpwgkernels.so")
+# PWG_KERNEL_LIB: another build of the same library (tools/build_variant.py: compile-time kernel variants for same-box
+# A/B runs); the ABI check below applies to it as well
+LIB_PATH = os.environ.get("PWG_KERNEL_LIB") or os.path.join(_HERE, "libpwgkernels.so")
 
 PWG_ACT_NONE, PWG_ACT_LEAKY_RELU, PWG_ACT_TANH, PWG_ACT_RELU = 0, 1, 2, 3
 PWG_PAD_ZERO, PWG_PAD_REFLECT, PWG_PAD_REPLICATE = 0, 1, 2

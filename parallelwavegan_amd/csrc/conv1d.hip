@@ -31,6 +31,11 @@ namespace pwg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef PWG_PRIO
+#define PWG_PRIO 0
+#endif
+constexpr int kPrio = PWG_PRIO;  // s_setprio by phase in conv1d_mfma_dma_kernel (tools/build_variant.py)
+
 struct ConvArgs {
   const float* x;
   const float* wp;
@@ -422,7 +427,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WM * WN >= 8 ? 1 : (WM * W
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (!(a.dbg & 2)) __syncthreads();
     float* buf = smem + (c & 1) * buf_floats;
+    // (wave priority by phase, compile-time experiment PWG_PRIO -- the resident workgroups of a CU are at different
+    // phases.  bit 0: matrix phase raised; bit 1: the DMA issue of the next chunk raised; bit 2: the epilogue raised)
+    if constexpr (kPrio & 2) __builtin_amdgcn_s_setprio(1);
     if (c + 1 < nchunks && !(a.dbg & 1)) issue((c_first + c + 1) * CK, smem + ((c + 1) & 1) * buf_floats);
+    if constexpr (kPrio & 2) __builtin_amdgcn_s_setprio(0);
+    if constexpr (kPrio & 1) __builtin_amdgcn_s_setprio(1);
     const float* xs = buf;
     const float* wl = buf + CK * XS + wave_m * (WM * 32) + l31 + lhi * BM;  // + tap*CK*BM + 2*kk*BM + mi*32
     const float* xl = xs + lhi * XS + (FAST ? wave_n * (WN * 32) + l31 : 0);  // + tap*tap_step + 2*kk*XS + coff
@@ -472,7 +482,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WM * WN >= 8 ? 1 : (WM * W
       mma(a1, b1);
     }
     if (tap < a.k) mma(a0, b0);
+    if constexpr (kPrio & 1) __builtin_amdgcn_s_setprio(0);
   }
+  if constexpr (kPrio & 4) __builtin_amdgcn_s_setprio(1);
 
   if (a.dbg & 4) {
     if (acc[0][0][0] == 12345.678f) a.y[0] = 1.f;
