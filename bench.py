@@ -41,6 +41,13 @@ CORPUS = {"c2": "ljspeech", "c3": "ljspeech", "c4": "ljspeech", "c5": "libritts"
 C3_REFERENCE_GFLOP_PER_ITEM = 4 * 19.65 + 10 * 12.08
 
 
+def _fold_batch_on():
+    """Is batch folding of weight-heavy, few-column layers active (layers/conv.py, PWG_FOLD_BATCH)?"""
+    from parallelwavegan_amd.layers.conv import _ConvNd
+
+    return _ConvNd.fold_batch
+
+
 def load_conf(name):
     import yaml
 
@@ -330,6 +337,7 @@ def bench_train(args, tag, dev, rank, world, dist, steps, warmup, detail=True):
             "scaling": "weak",
             "parallelism": f"dp{world}" if world > 1 else "single",
             "hip_graph": bool(tr._graphs),
+            "fold_batch": bool(_fold_batch_on()),
             "losses_finite": finite,
             "first_nonfinite": first_bad,
             "steps_checked": len(hist),
