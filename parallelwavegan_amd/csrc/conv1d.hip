@@ -699,7 +699,6 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(FinishArgs a) {
 // on the way), every thread accumulates 4 outputs (stride 256: conflict-free LDS reads) x <= 4 channels
 // with plain fp32 FMAs in (ci, tap) order.  HBM-bound: one read of x, one write of y.
 // ---------------------------------------------------------------------------
-constexpr int SC_TILE = 1024;
 constexpr int SC_MAXW = 2048;  // cout * cin * k floats of weights in LDS
 // OPT = outputs per thread (tile = 256 * OPT samples).  Round 4: the launch is a serial walk over the input channels with two
 // barriers each, so few large tiles leave the chip idle -- PWG's last 64 -> 1 layer at B6 x 25600 was 150 workgroups and
@@ -713,7 +712,7 @@ __global__ __launch_bounds__(256) void conv1d_small_cout_kernel(const float* __r
                                                                 float post_slope, float out_mul) {
   extern __shared__ float sm[];
   float* ws = sm;                      // [cout][cin][k]
-  float* xs = sm + cout * cin * k;     // [SC_TILE + halo]
+  float* xs = sm + cout * cin * k;     // [tile + halo], tile = 256 * OPT samples
   const int b = blockIdx.y;
   constexpr int TILE = 256 * OPT;
   const int t0 = blockIdx.x * TILE;

@@ -688,7 +688,6 @@ static WgPlan wgrad_plan(int co_g, int ci_g, int groups, int k, int stride, int 
       if (env_tg > 0) p.tg = env_tg < 7 ? env_tg : 7;
       p.taps_block = p.tg;
     }
-    const int bt = p.small ? 32 : 64;
     // Many far-apart taps (e.g. k = 41 with dilation 5) can exceed the LDS even with per-tap windows:
     // fall back to fewer taps per workgroup (more tap groups) until the tiles fit.
     static const int small_tgs[] = {4, 3, 2, 1};

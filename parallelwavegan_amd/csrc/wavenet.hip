@@ -166,8 +166,6 @@ __global__ __launch_bounds__(256, 2) void wavenet_layer_kernel(WnArgs a) {
   }
 
   // ---- gate in registers; z / g to HBM (training), g to LDS rows 0..63 (every wave is done with the first window)
-  const int n = n0 + cn * 32 + l31;
-  const bool n_ok = n < T;
   __syncthreads();
   float* scr = tile + 2 * WN_R * WN_COLS + wave * (2 * 32 * 36);  // wave-private scratch in the dead rows 128..
   const int trow = lane >> 3, tcol = (lane & 7) * 4;
