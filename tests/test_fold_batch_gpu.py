@@ -97,3 +97,66 @@ def test_fold_rule_leaves_the_other_layers_alone(monkeypatch):
     assert not small._fold_batch(torch.zeros(16, 128, 32), None, None, None)      # small weight
     refl = Conv1d(1024, 1024, 5, padding=2, pad_mode="reflect")
     assert not refl._fold_batch(torch.zeros(16, 1024, 32), None, None, None)      # reflect padding needs width 1
+
+
+# geometries the rule would also fold in other models: dilation, causal (left-only) padding, stride 2 / 3, groups,
+# bias-free layers, post-activation -- run with the weight threshold lowered so that small layers fold
+FUZZ = [
+    # B, Cin, Cout, T, K, stride, dilation, padding, groups, bias, post_act
+    (8, 48, 64, 23, 3, 1, 1, 1, 1, True, None),
+    (4, 64, 64, 40, 7, 1, 3, 9, 1, True, "leaky_relu"),       # dilation 3
+    (6, 32, 96, 31, 5, 2, 1, 2, 1, False, None),              # stride 2, no bias
+    (7, 64, 32, 37, 4, 3, 1, (3, 0), 1, True, None),          # causal padding, stride 3, even kernel
+    (16, 64, 64, 9, 9, 1, 2, 8, 4, True, "tanh"),             # groups 4, dilation 2, T < receptive field
+    (5, 40, 40, 12, 1, 1, 1, 0, 1, True, None),               # 1 x 1
+    (4, 64, 128, 33, 11, 1, 1, (10, 0), 2, True, "leaky_relu"),  # causal, groups 2
+    (9, 16, 16, 1, 3, 1, 1, 1, 1, True, None),                # a single column per item
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Cin,Cout,T,K,stride,dil,pad,groups,bias,post", FUZZ)
+def test_folding_is_exact_for_every_conv1d_geometry(B, Cin, Cout, T, K, stride, dil, pad, groups, bias, post, device,
+                                                    monkeypatch):
+    monkeypatch.setattr(_ConvNd, "fold_min_weight_bytes", 0)
+    torch.manual_seed(B * 31 + T)
+    m = Conv1d(Cin, Cout, K, stride=stride, padding=pad, dilation=dil, groups=groups, bias=bias).to(device)
+    g = torch.Generator().manual_seed(T + K)
+    x_cpu = torch.randn(B, Cin, T, generator=g)
+    fused = dict(pre_act="leaky_relu", pre_slope=0.2)
+    if post is not None:
+        fused.update(post_act=post, post_slope=0.1)
+    runs = {}
+    for fold in (False, True):
+        monkeypatch.setattr(_ConvNd, "fold_batch", fold)
+        assert m._fold_batch(x_cpu, None, None, None) == fold
+        for p in m.parameters():
+            p.grad = None
+        x = x_cpu.to(device).requires_grad_()
+        y = m(x, **fused)
+        if "dy" not in runs:
+            runs["dy"] = torch.randn(y.shape, generator=g)
+        y.backward(runs["dy"].to(device))
+        with torch.no_grad():
+            y_nograd = m(x.detach(), **fused)
+        runs[fold] = dict(y=y.detach(), y_nograd=y_nograd, dx=x.grad.detach(),
+                          **{n: p.grad.detach().clone() for n, p in m.named_parameters()})
+    # oracle: ATen on CPU
+    pl, pr = (pad if isinstance(pad, tuple) else (pad, pad))
+    w = m.weight.detach().cpu().requires_grad_()
+    b = m.bias.detach().cpu().requires_grad_() if bias else None
+    xr = x_cpu.clone().requires_grad_()
+    y_ref = F.conv1d(F.pad(F.leaky_relu(xr, 0.2), (pl, pr)), w, b, stride=stride, dilation=dil, groups=groups)
+    if post == "leaky_relu":
+        y_ref = F.leaky_relu(y_ref, 0.1)
+    elif post == "tanh":
+        y_ref = torch.tanh(y_ref)
+    y_ref.backward(runs["dy"])
+    for fold in (False, True):
+        r = runs[fold]
+        _close(r["y"], y_ref, f"forward (fold={fold})")
+        _close(r["y_nograd"], y_ref, f"no-grad forward (fold={fold})")
+        _close(r["dx"], xr.grad, f"data gradient (fold={fold})")
+        _close(r["weight"], w.grad, f"weight gradient (fold={fold})")
+        if bias:
+            _close(r["bias"], b.grad, f"bias gradient (fold={fold})")
