@@ -438,6 +438,177 @@ def bench_pwg_inference(dev, steps=10, warmup=3, batch=16, frames=400):
     return out
 
 
+class _MultiBandDecode(torch.nn.Module):
+    """What ``MelGANGenerator.inference`` runs for a multi-band model (models/melgan.py:239-257): the generator, then
+    ``pqmf.synthesis`` of its sub-band signals -- as a batched forward so that it can be captured like the others."""
+
+    def __init__(self, g, pqmf):
+        super().__init__()
+        self.g, self.pqmf = g, pqmf
+
+    def forward(self, c):
+        return self.pqmf.synthesis(self.g(c))
+
+
+def bench_mbmelgan_inference(dev, steps=10, warmup=3, batch=16, frames=800):
+    """BASELINE configs[3]'s generator as ``bin/decode.py`` uses it: Multi-band MelGAN.v2 generator + PQMF synthesis
+    (the one model whose published GPU decode figure maps onto a BASELINE config), as a resident batch
+    and at batch 1 (100 / 800 frames), graph replay, with the timed batch's last utterance checked against the oracle."""
+    from parallelwavegan_amd import ops
+    from parallelwavegan_amd.graphs import GraphedInference
+    from parallelwavegan_amd.layers import PQMF
+    from parallelwavegan_amd.models import MelGANGenerator
+
+    conf = load_conf("multi_band_melgan.v2")
+    gp = conf["generator_params"]
+    torch.manual_seed(77)
+    g = MelGANGenerator(**gp)
+    g.remove_weight_norm()
+    model = _MultiBandDecode(g, PQMF(subbands=gp["out_channels"], **conf.get("pqmf_params", {}))).to(dev).eval()
+    hop = conf["hop_size"]
+    out = {}
+    gen = torch.Generator(device="cpu").manual_seed(300)
+    for tag, (b, f, n) in {"batch": (batch, frames, steps), "B1_F100": (1, 100, 20), "B1_F800": (1, 800, 20)}.items():
+        c_host = torch.randn(b, gp["in_channels"], f, generator=gen)
+        c = c_host.to(dev)
+        run = GraphedInference(model)
+        with torch.no_grad():
+            for _ in range(warmup):
+                y = run(c)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                y = run(c)
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        assert torch.isfinite(y).all() and y.shape == (b, 1, f * hop), tuple(y.shape)
+        out[tag] = {"batch": b, "frames": f, "ms": dt * 1e3, "samples_per_s": b * f * hop / dt,
+                    "rtf": dt / (b * f * hop / float(conf["sampling_rate"]))}
+        if tag == "batch":
+            from oracle import torch_cpu
+
+            sd = {k: v.detach().cpu() for k, v in g.state_dict().items()}
+            torch.set_num_threads(min(os.cpu_count() or 1, 32))
+            with torch.no_grad():
+                ref = torch_cpu.pqmf_synthesis(torch_cpu.melgan_generator(sd, c_host[b - 1:], **gp),
+                                               subbands=gp["out_channels"], **conf.get("pqmf_params", {}))
+            err = (y[b - 1:].cpu() - ref).abs().max().item()
+            out[tag]["parity"] = {"max_abs_vs_oracle": err, "utterances_checked": [b - 1], "tolerance": 1e-4,
+                                  "oracle_abs_max": ref.abs().max().item(), "ok": err <= 1e-4}
+            with ops.profile() as prof, torch.no_grad():
+                model(c)
+            fl = sum(v["flops"] for v in prof.results.values())
+            by = sum(v["bytes"] for v in prof.results.values())
+            out[tag]["MFLOP_per_sample_executed"] = fl / (b * f * hop) / 1e6
+            out[tag]["TFLOPs"] = fl / dt / 1e12
+            out[tag]["frac_of_fp32_matrix_peak"] = fl / dt / 1e12 / FP32_MATRIX_PEAK_TFLOPS
+            out[tag]["algorithmic_GBps"] = by / dt / 1e9
+            out[tag]["kernels"] = {k: {"ms": round(v["ms"], 3), "launches": v["launches"],
+                                       "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
+                                       "GBps_algorithmic": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
+                                   for k, v in sorted(prof.results.items(), key=lambda kv: -kv[1]["ms"])}
+        del run
+    out["config"] = ("c4 generator: multi_band_melgan.v2 + PQMF synthesis (MelGANGenerator.inference's work, "
+                     "models/melgan.py:239-257), fp32, weight norm removed, hipGraph replay")
+    del model, g
+    torch.cuda.empty_cache()
+    return out
+
+
+def cpu_baseline_other_generators(budget_s=6.0):
+    """The reference's own ``inference`` on the host cores for the two other generators SURVEY s8d names:
+    Parallel WaveGAN.v1 on a random 80 x 100 mel (BASELINE configs[0]: the test_parallel_wavegan.py:157-198 path, a CPU
+    run by definition) and Multi-band MelGAN.v2 (+ PQMF synthesis) at 100 and 800 frames.  ``kind`` = "reference" when
+    the staged reference package is importable, else "port" (the oracle's restatement)."""
+    from oracle import ref_run, torch_cpu
+
+    cores = os.cpu_count() or 1
+    use_ref = ref_run.available()
+    res = {}
+
+    def best_of(fn, budget):
+        best, n, t_start = float("inf"), 0, time.time()
+        while n < 3 or (time.time() - t_start < budget and n < 200):
+            t0 = time.time()
+            y = fn()
+            best = min(best, time.time() - t0)
+            n += 1
+        return best, n, y
+
+    def fastest_threads(fn):
+        probe = {}
+        for nt in sorted({min(cores, n) for n in (8, 16, 32, 64)}):
+            torch.set_num_threads(nt)
+            fn()
+            probe[nt] = min(_time(fn), _time(fn))
+        nt = min(probe, key=probe.get)
+        torch.set_num_threads(nt)
+        return nt
+
+    def _time(fn):
+        t0 = time.time()
+        fn()
+        return time.time() - t0
+
+    with torch.no_grad():
+        # ---- configs[0]: PWG.v1, c = randn(100 + 2 * acw, 80), the noise passed explicitly as decode.py does not need to
+        conf = load_conf("parallel_wavegan.v1")
+        gp, hop = conf["generator_params"], conf["hop_size"]
+        acw = gp["aux_context_window"]
+        gen = torch.Generator(device="cpu").manual_seed(5)
+        c = torch.randn(100, gp["aux_channels"], generator=gen)  # inference() replicate-pads the context frames itself
+        z = torch.randn(100 * hop, 1, generator=gen)
+        if use_ref:
+            g_ref = ref_run.generator("ParallelWaveGANGenerator", gp)
+            fn = lambda: g_ref.inference(c, x=z)  # noqa: E731  (models/parallel_wavegan.py:229-261)
+        else:
+            from parallelwavegan_amd.models import ParallelWaveGANGenerator
+
+            g0 = ParallelWaveGANGenerator(**gp)
+            g0.remove_weight_norm()
+            sd = {k: v.detach() for k, v in g0.state_dict().items()}
+            cp = torch.nn.functional.pad(c.t().unsqueeze(0), (acw, acw), mode="replicate")
+            fn = lambda: torch_cpu.pwg_generator(sd, z.t().unsqueeze(0), cp, **gp)  # noqa: E731
+        nt = fastest_threads(fn)
+        best, n, y = best_of(fn, budget_s)
+        res["pwg_v1_c0"] = {"value": y.numel() / best, "unit": "samples/s", "best_s": best, "calls": n, "cores": nt,
+                            "kind": "reference" if use_ref else "port",
+                            "sample": "BASELINE configs[0]: ParallelWaveGANGenerator.inference on a random 80 x 100 mel "
+                                      f"(context {acw} frames replicate-padded), B=1, best of {n}, {nt} of {cores} host threads"}
+        # ---- Multi-band MelGAN.v2 + PQMF synthesis
+        conf = load_conf("multi_band_melgan.v2")
+        gp, hop = conf["generator_params"], conf["hop_size"]
+        if use_ref:
+            ref_run.ref_shim.install()
+            from parallel_wavegan.layers import PQMF as RefPQMF
+
+            m_ref = ref_run.generator("MelGANGenerator", gp)
+            m_ref.pqmf = RefPQMF(subbands=gp["out_channels"], **conf.get("pqmf_params", {}))  # as utils.load_model:346-353
+            mk = lambda c_: (lambda: m_ref.inference(c_))  # noqa: E731
+        else:
+            from parallelwavegan_amd.models import MelGANGenerator
+
+            g1 = MelGANGenerator(**gp)
+            g1.remove_weight_norm()
+            sd1 = {k: v.detach() for k, v in g1.state_dict().items()}
+            mk = lambda c_: (lambda: torch_cpu.pqmf_synthesis(  # noqa: E731
+                torch_cpu.melgan_generator(sd1, c_.t().unsqueeze(0), **gp), subbands=gp["out_channels"],
+                **conf.get("pqmf_params", {})))
+        per = {}
+        for frames, budget in ((100, budget_s / 2), (800, budget_s)):
+            c = torch.randn(frames, gp["in_channels"], generator=gen)
+            fn = mk(c)
+            if frames == 100:
+                nt = fastest_threads(fn)
+            best, n, y = best_of(fn, budget)
+            per[frames] = {"samples_per_s": y.numel() / best, "best_s": best, "calls": n}
+        res["mb_melgan_v2"] = {"value": per[800]["samples_per_s"], "unit": "samples/s", "cores": nt,
+                               "kind": "reference" if use_ref else "port", "frames_100": per[100], "frames_800": per[800],
+                               "sample": "MelGANGenerator.inference (generator + PQMF synthesis), B=1 x 800 frames, best of "
+                                         f"{per[800]['calls']}, {nt} of {cores} host threads"}
+    return res
+
+
 RCCL_LOG = {"path": None}
 
 
@@ -529,6 +700,22 @@ def compact_line(out):
         line["cpu_baseline"] = {"value": _r(cb["value"], 1), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
                                 "sample": f"reference HiFiGANGenerator B1 x 800 frames, best of {cb['frames_800']['calls']}"
                                 if cb["kind"] == "reference" else "oracle restatement B1 x 800 frames"}
+        oth = cb.get("others") or {}
+        if "pwg_v1_c0" in oth:  # BASELINE configs[0] (PWG.v1, 80 x 100 mel, CPU) and MB-MelGAN.v2 + PQMF, same host
+            line["cpu_baseline"]["pwg_v1_c0"] = _r(oth["pwg_v1_c0"]["value"], 1)
+            line["cpu_baseline"]["mb_melgan_v2"] = _r(oth["mb_melgan_v2"]["value"], 1)
+    lat = out.get("latency")
+    if lat:  # B = 1 at 100 and 800 frames (ms per utterance, graph replay)
+        line["lat_ms"] = {k.lower().replace("_", ""): _r(v["ms"], 3) for k, v in lat.items()}
+    inf = {}
+    cfgs = out.get("configs") or {}
+    for key, short in (("c1_pwg_inference", "pwg"), ("c4_mbmelgan_inference", "mb")):
+        rec = cfgs.get(key) or {}
+        if "batch" in rec:  # M samples/s: resident batch, B1 x 100 frames; max|hip - oracle| of the timed batch
+            inf[short] = [_r(rec["batch"]["samples_per_s"] / 1e6, 2), _r(rec["B1_F100"]["samples_per_s"] / 1e6, 2),
+                          float(f"{rec['batch']['parity']['max_abs_vs_oracle']:.2g}")]
+    if inf:
+        line["infer_Msps_b16_b1_err"] = inf
     if par:
         line["parity"] = {"max_abs_vs_oracle": float(f"{par['max_abs_vs_oracle']:.3g}"), "tol": par["tolerance"],
                           "ok": par["ok"]}
@@ -553,7 +740,7 @@ def compact_line(out):
     line["detail"] = out.get("detail_file")
     text = json.dumps(line, separators=(",", ":"))
     if len(text) > COMPACT_LIMIT:  # never exceed the tail: drop the optional objects, least important first
-        for key in ("detail", "train", "parity"):
+        for key in ("detail", "train", "infer_Msps_b16_b1_err", "parity"):
             line.pop(key, None)
             text = json.dumps(line, separators=(",", ":"))
             if len(text) <= COMPACT_LIMIT:
@@ -802,6 +989,10 @@ def main():
             configs["c1_pwg_inference"] = bench_pwg_inference(dev)
         except Exception as e:  # noqa: BLE001
             configs["c1_pwg_inference"] = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            configs["c4_mbmelgan_inference"] = bench_mbmelgan_inference(dev)
+        except Exception as e:  # noqa: BLE001
+            configs["c4_mbmelgan_inference"] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         value = samples_per_step * world * args.steps / elapsed
@@ -848,6 +1039,11 @@ def main():
             out["configs"] = configs
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(g_params)
+            if not args.no_extra_configs:
+                try:
+                    out["cpu_baseline"]["others"] = cpu_baseline_other_generators()
+                except Exception as e:  # noqa: BLE001
+                    out["cpu_baseline"]["others"] = {"error": f"{type(e).__name__}: {e}"}
             if train is not None:
                 train["cpu_baseline"] = cpu_train_baseline(load_conf("hifigan.v1"))
         out["train_config"] = main_tag

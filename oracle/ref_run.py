@@ -22,8 +22,8 @@ def generator(generator_type, generator_params):
     return g.eval()
 
 
-def trainer(conf, batch):
-    """A reference ``Trainer`` (bin/train.py:52-96) on CPU, everything built from the recipe dict the way
+def trainer(conf, batch, device="cpu"):
+    """A reference ``Trainer`` (bin/train.py:52-96) on CPU (or, for tools/bench_reference_rocm.py, on ``device``), everything built from the recipe dict the way
     ``bin/train.py:1364-1493`` does, both phases active from the first step."""
     ref_shim.install()
     import parallel_wavegan.layers as RLy
@@ -36,20 +36,22 @@ def trainer(conf, batch):
     cfg = dict(conf)
     gcls = getattr(RM, cfg.get("generator_type", "ParallelWaveGANGenerator"))
     dcls = getattr(RM, cfg.get("discriminator_type", "ParallelWaveGANDiscriminator"))
-    model = {"generator": gcls(**cfg["generator_params"]), "discriminator": dcls(**cfg["discriminator_params"])}
+    device = torch.device(device)
+    model = {"generator": gcls(**cfg["generator_params"]).to(device),
+             "discriminator": dcls(**cfg["discriminator_params"]).to(device)}
     criterion = {"gen_adv": RL.GeneratorAdversarialLoss(**cfg.get("generator_adv_loss_params", {})),
                  "dis_adv": RL.DiscriminatorAdversarialLoss(**cfg.get("discriminator_adv_loss_params", {}))}
     cfg.setdefault("use_stft_loss", True)
     for k in ("use_subband_stft_loss", "use_mel_loss", "use_feat_match_loss"):
         cfg.setdefault(k, False)
     if cfg["use_stft_loss"]:
-        criterion["stft"] = RL.MultiResolutionSTFTLoss(**cfg["stft_loss_params"])
+        criterion["stft"] = RL.MultiResolutionSTFTLoss(**cfg["stft_loss_params"]).to(device)
     if cfg["use_subband_stft_loss"]:
-        criterion["sub_stft"] = RL.MultiResolutionSTFTLoss(**cfg["subband_stft_loss_params"])
+        criterion["sub_stft"] = RL.MultiResolutionSTFTLoss(**cfg["subband_stft_loss_params"]).to(device)
     if cfg["generator_params"]["out_channels"] > 1:
-        criterion["pqmf"] = RLy.PQMF(subbands=cfg["generator_params"]["out_channels"])
+        criterion["pqmf"] = RLy.PQMF(subbands=cfg["generator_params"]["out_channels"]).to(device)
     if cfg["use_mel_loss"]:
-        criterion["mel"] = RL.MelSpectrogramLoss(**cfg["mel_loss_params"])
+        criterion["mel"] = RL.MelSpectrogramLoss(**cfg["mel_loss_params"]).to(device)
     if cfg["use_feat_match_loss"]:
         criterion["feat_match"] = RL.FeatureMatchLoss(**cfg.get("feat_match_loss_params", {}))
     opt_cls = {"RAdam": RO.RAdam, "Adam": torch.optim.Adam}
@@ -62,6 +64,6 @@ def trainer(conf, batch):
                discriminator_train_start_steps=0)
     tr = Trainer(steps=1, epochs=0, data_loader={"train": [batch], "dev": [batch]}, sampler={"train": None, "dev": None},
                  model=model, criterion=criterion, optimizer=optimizer, scheduler=scheduler, config=cfg,
-                 device=torch.device("cpu"))
+                 device=device)
     tr.tqdm = tqdm(disable=True)
     return tr

@@ -108,7 +108,7 @@ class GradReducer:
         # backward pass (``epoch``).  PWG_DDP_DIRECT=0: every gradient goes through a hook copy as in round 3.
         self.direct_slots = os.environ.get("PWG_DDP_DIRECT", "1") == "1"
         self.epoch = 0
-        self._filled, self._replaying = set(), False
+        self._filled = set()
         self.zero_buckets = os.environ.get("PWG_DDP_ZERO_BUCKETS", "0") == "1"
         self.zero_fills = 0  # slots zeroed because no gradient arrived (tests / bench)
         self.copies = 0  # hook copies since construction (bench / tests: how many gradients did NOT arrive in place)
@@ -154,7 +154,6 @@ class GradReducer:
                 b.flat.zero_()
                 b.zeroed = True
         self._filled = set()
-        self._replaying = False
         self._next = 0
         self.epoch += 1  # every slot may be claimed once in the coming backward pass
 
@@ -183,7 +182,6 @@ class GradReducer:
             b.work = None
             b.launched = False
             b.zeroed = True  # the captured segment re-zeroes the slots that were empty at capture time
-        self._replaying = True
         self._next = 0
 
     def _hook(self, p):
@@ -214,17 +212,19 @@ class GradReducer:
 
     def _all_reduce(self, b):
         b.launched = True
-        if not b.zeroed and not self.defer:
-            for p in b.params:  # (ordered after the producers of this bucket's other slots: see the event waits below)
-                if id(p) not in self._filled:
-                    b.views[p].zero_()
-                    self.zero_fills += 1
-            b.zeroed = True
-        if b.events:
+        if b.events:  # first: this stream joins every stream a slot of the bucket was produced on
             cur = torch.cuda.current_stream(b.flat.device)
             for ev in b.events:
                 cur.wait_event(ev)
             b.events = []
+        if not b.zeroed and not self.defer:
+            # slots no gradient arrived for contribute 0 (disjoint from the produced slots; issued after the event
+            # waits so that fill and collective are ordered behind every producer of the bucket all the same)
+            for p in b.params:
+                if id(p) not in self._filled:
+                    b.views[p].zero_()
+                    self.zero_fills += 1
+            b.zeroed = True
         if (self.world > 1 or self.force) and not self.skip_comm:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 

@@ -8,6 +8,14 @@ as one graph launch per utterance shape.
 import torch
 
 
+def _version_of(t):
+    """torch's version counter of ``t``; tensors created or loaded under ``torch.inference_mode()`` do not track one
+    (reading it raises) and cannot be written in place outside inference mode either: a constant stands in."""
+    if t.is_inference():
+        return -1
+    return t._version
+
+
 class GraphedInference:
     """Capture ``model.forward`` for fixed input shapes; ``__call__`` copies the new inputs into the
     static buffers and replays.  One graph per distinct input shape (cached).
@@ -19,9 +27,12 @@ class GraphedInference:
     the stale graphs are dropped and the call captures again, so a replay can never synthesise with old weights
     (VERDICT r04).  :meth:`reset` does the same by hand."""
 
-    def __init__(self, model, warmup=2):
+    def __init__(self, model, warmup=2, frozen=False):
         self.model = model
         self.warmup = warmup
+        # frozen=True: latency-critical loops where the caller guarantees that no parameter changes between calls;
+        # the parameter state is then taken once (at the first capture) instead of on every call
+        self.frozen = frozen
         self._graphs = {}
         self._state = None
 
@@ -36,11 +47,13 @@ class GraphedInference:
         model = self.model
         if not isinstance(model, torch.nn.Module):
             return None
+        if self.frozen and self._state is not None:
+            return self._state  # the caller vouches for frozen weights: no per-call walk over the tensors
         st = [ops.PARAM_EPOCH[0], model.training]
         for t in model.parameters():
-            st.append((t.data_ptr(), t._version, ops.param_epoch(t)))
+            st.append((t.data_ptr(), _version_of(t), ops.param_epoch(t)))
         for t in model.buffers():
-            st.append((t.data_ptr(), t._version))
+            st.append((t.data_ptr(), _version_of(t)))
         return st
 
     def _capture(self, inputs):

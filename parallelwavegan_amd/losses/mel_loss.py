@@ -122,7 +122,7 @@ class MelPairLossFn(torch.autograd.Function):
         b, t = x.shape
         frames = mod.frames(t)
         n_cols = frames + mod.taps - 1
-        pad = mod.fft_size // 2 - mod.frame_offset
+        pad = mod.fold_pad
         fx = torch.empty(b, mod.hop_size, n_cols, device=x.device, dtype=torch.float32)
         fy = torch.empty_like(fx)
         L = _lib.lib()

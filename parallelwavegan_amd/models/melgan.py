@@ -230,12 +230,14 @@ class MelGANMultiScaleDiscriminator(torch.nn.Module, _MelGANNormMixin):
             # never used, is dropped), then the scale discriminators as independent branches (streams.run_branches
             # forks only while the stream is being captured)
             xs = []
-            for _ in self.discriminators:
+            for i in range(len(self.discriminators)):
                 xs.append(x)
-                x = self.pooling(x)
+                if i + 1 < len(self.discriminators):
+                    x = self.pooling(x)
             return run_branches([(lambda f=f, xi=xi: f(xi)) for f, xi in zip(self.discriminators, xs)], xs[0].device, True)
         outs = []
-        for f in self.discriminators:
+        for i, f in enumerate(self.discriminators):
             outs.append(f(x))
-            x = self.pooling(x)
+            if i + 1 < len(self.discriminators):  # (the reference pools once more; that result is never used)
+                x = self.pooling(x)
         return outs

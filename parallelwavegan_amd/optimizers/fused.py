@@ -204,12 +204,27 @@ class _FusedBase(torch.optim.Optimizer):
         return loss
 
 
+# torch.optim keyword arguments that select an implementation, not an update rule: accepted and ignored
+_NOOP_KWARGS = {"foreach": (None, True, False), "fused": (None, True, False), "capturable": (True, False),
+                "differentiable": (False,), "maximize": (False,)}
+
+
+def _reject_unknown(cls, kwargs):
+    """Keyword arguments beyond ``_NOOP_KWARGS`` (e.g. ``maximize=True``) would change the update rule: refuse them
+    instead of running the recipe with a different optimiser than it asked for."""
+    for k, v in kwargs.items():
+        if k not in _NOOP_KWARGS or v not in _NOOP_KWARGS[k]:
+            raise TypeError(f"{cls.__name__}: unsupported option {k}={v!r} (the fused optimizer implements "
+                            f"lr / betas / eps / weight_decay" + (" / amsgrad" if cls is not RAdam else "") + " only)")
+
+
 class Adam(_FusedBase):
     """``torch.optim.Adam`` semantics (L2 weight decay, optional amsgrad) in one launch per group."""
 
     _entry = "pwg_adam_step_dev"
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, **unused):
+        _reject_unknown(type(self), unused)
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=amsgrad))
 
     def _amsgrad(self, group):
@@ -228,7 +243,7 @@ class AdamW(Adam):
     (include/pwg_kernels.h).  Two of the reference's recipes (egs/yesno/voc1/conf/*.v1.debug.yaml) name it."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False, **unused):
-        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad)
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, **unused)
 
     def _hyper(self, group, t):
         h = super()._hyper(group, t)
@@ -242,6 +257,7 @@ class RAdam(_FusedBase):
     _entry = "pwg_radam_step_dev"
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, **unused):
+        _reject_unknown(type(self), unused)
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
 
     def _hyper(self, group, t):

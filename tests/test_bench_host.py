@@ -110,6 +110,14 @@ def _canned_record(world=1):
     out["roofline"]["launches_timed"] = 141
     out["train"]["cpu_baseline"].setdefault("batch", 16)
     out["n_gpus"] = world
+    # round 6: B = 1 latencies, the MB-MelGAN inference leg and the two further CPU baselines ride in the line
+    out["latency"] = {"B1_F100": {"ms": 1.5012345, "samples_per_s": 1.7e7, "rtf": 1e-3},
+                      "B1_F800": {"ms": 5.3912345, "samples_per_s": 3.8e7, "rtf": 1e-3}}
+    leg = {"batch": {"samples_per_s": 123456789.123, "parity": {"max_abs_vs_oracle": 2.123456e-6}},
+           "B1_F100": {"samples_per_s": 23456789.123}}
+    out.setdefault("configs", {})["c1_pwg_inference"] = leg
+    out["configs"]["c4_mbmelgan_inference"] = leg
+    out["cpu_baseline"]["others"] = {"pwg_v1_c0": {"value": 51234.5678}, "mb_melgan_v2": {"value": 812345.678}}
     if world > 1:  # the distributed detail a --gpus 8 run carries
         out["train"]["dist"] = {
             "backend": "nccl", "world_size": world,
@@ -140,6 +148,10 @@ def test_stdout_line_is_compact_strict_json_with_the_contract_keys(world):
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in rec["cpu_baseline"], k
     assert set(rec["train_steps_per_s"]) == {"c2", "c3", "c4", "c5"}
+    # B = 1 latencies, MB-MelGAN / PWG inference and the three CPU baselines in the parsed line
+    assert set(rec["lat_ms"]) == {"b1f100", "b1f800"}
+    assert set(rec["infer_Msps_b16_b1_err"]) == {"pwg", "mb"} and len(rec["infer_Msps_b16_b1_err"]["mb"]) == 3
+    assert rec["cpu_baseline"]["pwg_v1_c0"] > 0 and rec["cpu_baseline"]["mb_melgan_v2"] > 0
     if world > 1:
         d = rec["train"]["dist"]
         assert d["rccl"]["nranks"] == world and d["rccl"]["large_allreduce"]["algo"] == "Ring"

@@ -120,3 +120,20 @@ def test_resunit_geometry_queries_answer_without_a_gpu():
     assert not ops.resunit_profitable(ops.make_resunit_desc(2, 64, 8192, 11, 5))
     assert ops.resunit_profitable(ops.make_resunit_desc(2, 64, 8192, 11, 5, False))
     assert _lib.lib().pwg_resunit_packed_weight_floats(64, 11) == 11 * 64 * 64
+
+
+def test_fused_optimizers_reject_options_that_change_the_update_rule():
+    """ADVICE r05: ``maximize=True`` & co. must not be swallowed (a recipe would silently train with another rule);
+    implementation selectors (foreach / fused / capturable) are accepted."""
+    import pytest
+    import torch
+
+    from parallelwavegan_amd.optimizers import fused
+
+    p = [torch.nn.Parameter(torch.zeros(4))]
+    for cls in (fused.Adam, fused.AdamW, fused.RAdam):
+        with pytest.raises(TypeError):
+            cls(p, lr=1e-3, maximize=True)
+        with pytest.raises(TypeError):
+            cls(p, lr=1e-3, nesterov=True)
+        cls(p, lr=1e-3, foreach=None, capturable=False)

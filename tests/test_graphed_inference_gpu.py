@@ -91,3 +91,21 @@ def test_branches_fork_onto_side_streams_only_inside_a_capture(device):
     torch.cuda.synchronize()
     assert len(set(seen)) == 3 and origin not in seen, "three branches, three side streams, none the capturing stream"
     assert [o[0].item() for o in outs] == [0.0, 2.0, 4.0]
+
+
+def test_model_built_under_inference_mode_and_frozen_flag(device):
+    """ADVICE r05: parameters created under ``torch.inference_mode()`` track no version counter (reading it raises);
+    such a model must still be callable, and ``frozen=True`` skips the per-call walk over the tensors."""
+    with torch.inference_mode():
+        g = _small_hifigan(device)
+        g.remove_weight_norm()
+    assert any(p.is_inference() for p in g.parameters())
+    c = torch.randn(1, 80, 20, device=device)
+    with torch.inference_mode():
+        ref = g(c).clone()
+    run = GraphedInference(g)
+    assert max_abs(run(c), ref) == 0.0 and max_abs(run(c), ref) == 0.0
+    fast = GraphedInference(g, frozen=True)
+    y = fast(c).clone()
+    state = fast._state
+    assert fast(c) is not None and fast._state is state and max_abs(y, ref) == 0.0

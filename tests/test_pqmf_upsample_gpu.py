@@ -218,3 +218,33 @@ def test_mel_spectrogram_stft_options(center, normalized, win_length, log_base, 
     assert max_abs(xd.grad, xr.grad) <= 2e-3 * xr.grad.abs().max().item()
     with pytest.raises(ValueError):
         MelSpectrogram(onesided=False)
+
+
+@pytest.mark.parametrize("fft, hop, win", [(512, 128, None), (1024, 256, 600), (384, 30, 150)])
+def test_stft_pair_losses_without_centring(fft, hop, win, device):
+    """``STFTMagnitude(center=False).pair_losses`` (the fused pair kernel, not only ``spectrum``) folds the
+    UNPADDED signal: spectral convergence + log-magnitude loss and the gradient against torch.stft(center=False) in
+    float64 (losses/stft_loss.py:16-40,50-82 with the centring switched off)."""
+    from parallelwavegan_amd.losses.stft import STFTMagnitude
+
+    mod = STFTMagnitude(fft, hop, win, "hann", eps=1e-7, center=False).to(device)
+    g = torch.Generator().manual_seed(23)
+    x, y = 0.3 * torch.randn(3, 5000, generator=g), 0.3 * torch.randn(3, 5000, generator=g)
+    wl = fft if win is None else win
+
+    def mag(sig):
+        st = torch.stft(sig, n_fft=fft, hop_length=hop, win_length=wl, window=torch.hann_window(wl, dtype=torch.float64),
+                        center=False, return_complex=True)
+        return torch.sqrt(torch.clamp(st.real ** 2 + st.imag ** 2, min=1e-7))
+
+    xr = x.double().requires_grad_(True)
+    mx, my = mag(xr), mag(y.double())
+    sc_r = torch.norm(my - mx, p="fro") / torch.norm(my, p="fro")
+    lm_r = F.l1_loss(torch.log(my), torch.log(mx))
+    xd = x.to(device).requires_grad_(True)
+    out = mod.pair_losses(xd, y.to(device))
+    assert abs(out[0].item() - sc_r.item()) <= 2e-5 * max(1.0, sc_r.item())
+    assert abs(out[1].item() - lm_r.item()) <= 2e-5 * max(1.0, lm_r.item())
+    (out[0] + out[1]).backward()
+    (sc_r + lm_r).backward()
+    assert max_abs(xd.grad, xr.grad) <= 2e-3 * xr.grad.abs().max().item()
