@@ -1483,6 +1483,18 @@ static int choose_cfg(const Geometry& g, int W, int batch, int groups, bool dma,
       const long full = (long)(512.f * concurrency_hint());
       while (split < 4 && nchunks >= 32 * (2 * split) && blocks * split < full) split *= 2;
     }
+    // Round 6: launches that leave HALF the chip (or more) without a workgroup -- the batch-folded tail layers of the
+    // scale discriminators (one item of 144 .. 512 columns: grouped k = 41 layers 64 .. 128 workgroups of 8 chunks of
+    // 164 MFMAs per wave each, which the latency rule above never splits; 1024 -> 1024 k = 5: 48 .. 128) -- are cut
+    // until the slices fill it, whatever a chunk carries: forced sweep tools/bench_dsplit.py fold
+    // (profiles/r06_fold_split_sweep.txt): k = 41 g16 at T = 9 / 17 / 32: 86.6 / 85.9 / 89.5 us -> 32.4 / 51.5 / 54.1 us
+    // (32x128x8 split 4 / 2 / 2), 512 -> 1024 k = 41 s4 g16: 50.6 -> 22.2 / 32.2 / 34.5 us, 1024 -> 1024 k = 5 at T = 9 / 17:
+    // 57.1 / 76.6 -> 41.5 / 57.6 us (split 16 / 8).  (PWG_SPLIT_UNDERFILL=0 restores the round-5 rule.)
+    static const bool split_underfill = !(getenv("PWG_SPLIT_UNDERFILL") && atoi(getenv("PWG_SPLIT_UNDERFILL")) == 0);
+    if (split_underfill) {
+      const long full = (long)((k >= 32 ? 256.f : 512.f) * concurrency_hint());
+      while (split < 16 && nchunks >= 2 * split && blocks * split * 2 <= full) split *= 2;
+    }
     return split;
   };
   int best = -1, best_split = 1;

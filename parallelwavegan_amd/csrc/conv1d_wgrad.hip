@@ -54,8 +54,12 @@ struct WgArgs {
 //              layers); the 4 waves share the tiles and split the block's 4*TG taps between them.
 // MODE 0: width 1, stride 1, no pre-activation; 1: width 1, stride 1, leaky-ReLU/ReLU applied to the
 //      operands on the fly; 3: width 1, any stride; 2: width > 1 ((k,1) Conv2d of the period
-//      discriminators).  Modes 2/3 always evaluate the activation formula (slope 1 = identity).
-template <int TG, bool WIN, bool SMALL, int TT, int MODE>
+//      discriminators).  ACT23 (modes 2 / 3 only): evaluate the activation formula there too -- round 6: the
+//      discriminators hand both operands over already activated (slopes 1), and the 2 x (TG + 1) VALU operations per
+//      reduction step of the always-on formula were a third of the strided layers' loop (profiles/r06_wgrad_strided.txt).
+// STRIDE3 (mode 3 only): compile-time stride (0 = run time) -- the step offsets of the X reads fold into the LDS
+//      instructions as in the stride-1 modes.
+template <int TG, bool WIN, bool SMALL, int TT, int MODE, bool ACT23 = true, int STRIDE3 = 0>
 __global__ __launch_bounds__(256, (TG > 7 ? 1 : 2)) void conv1d_wgrad_kernel(WgArgs a) {
   constexpr int BT = SMALL ? 32 : 64;          // tile rows (o) and columns (i)
   constexpr int TAPS_BLOCK = SMALL ? 4 * TG : TG;
@@ -225,13 +229,14 @@ __global__ __launch_bounds__(256, (TG > 7 ? 1 : 2)) void conv1d_wgrad_kernel(WgA
   }
   float bsum = 0.f;
   auto mac_chunk = [&](const float* grow, const float* xrow, int n0, int h0, int orow, int irow) {
-    constexpr bool ACT = MODE != 0;
+    constexpr bool ACT = MODE == 1 || (MODE >= 2 && ACT23);
     constexpr bool S1 = MODE <= 1 && !WIN;  // stride 1, width 1: step offsets fold into the LDS instructions
+    constexpr bool S3C = MODE == 3 && STRIDE3 > 0;  // compile-time stride: likewise
     constexpr int STEPS = TT / 2;
     const int rot0 = (lhi + orow) & 31, roti = (lhi + irow) & 31;
     const float* xt[TG];
 #pragma unroll
-    for (int t = 0; t < TG; ++t) xt[t] = xrow + toff[t] + (S1 ? lhi : 0);
+    for (int t = 0; t < TG; ++t) xt[t] = xrow + toff[t] + (S1 ? lhi : (S3C ? lhi * STRIDE3 : 0));
     // MODE 2 state of the next load_ops call: column n = n0 + lhi, its in-row position w2 and tile offset xo2
     int w2 = 0, xo2 = 0;
     if (MODE == 2) {
@@ -249,6 +254,8 @@ __global__ __launch_bounds__(256, (TG > 7 ? 1 : 2)) void conv1d_wgrad_kernel(WgA
         xo = cb * (BT * 32) + ((2 * step + roti) & 31);
       } else if (S1) {
         xo = 2 * step;
+      } else if (S3C) {
+        xo = 2 * step * STRIDE3;
       } else if (MODE == 3) {
         xo = (2 * step + lhi) * a.stride;
       } else {
@@ -744,6 +751,14 @@ static WgPlan wgrad_plan(int co_g, int ci_g, int groups, int k, int stride, int 
   const int min_chunks = 256 / p.tt > 1 ? 256 / p.tt : 1;
   if (splits > p.chunks_total / min_chunks) splits = p.chunks_total / min_chunks;
   if (splits < 1) splits = 1;
+  // Round 6: a launch that leaves most of the chip without a workgroup (the batch-folded tail layers of the scale
+  // discriminators: ONE item of 144 .. 512 columns, 32 tiles x 3 tap groups = 96 workgroups walking 5 .. 16 chunks each
+  // at 9 - 27 TFLOP/s) is cut down to 2 chunks per slice until one workgroup per CU exists.  (PWG_WG_UNDERFILL=0: round 5.)
+  static const bool underfill = !(getenv("PWG_WG_UNDERFILL") && atoi(getenv("PWG_WG_UNDERFILL")) == 0);
+  if (underfill && env_res <= 0) {
+    const int wgs = p.tiles * p.tap_groups;
+    while (wgs * splits * 2 <= 256 && p.chunks_total / (splits * 2) >= 2) splits *= 2;
+  }
   p.splits = ceil_div(p.chunks_total, ceil_div(p.chunks_total, splits));
   return p;
 }
@@ -800,7 +815,7 @@ static int finish_wgrad_slabs(float* workspace, int splits, long slab_elems, lon
   return PWG_OK;
 }
 
-template <int TG, bool SMALL, int TT, bool WIN, int MODE>
+template <int TG, bool SMALL, int TT, bool WIN, int MODE, bool ACT23 = true, int STRIDE3 = 0>
 static int launch_wgrad_mode(WgArgs a, const WgPlan& p, float* dw_out, float* workspace, size_t ws_floats,
                         hipStream_t stream, double flops, double bytes, const WnFinish* wn) {
   a.xs_stride = p.xs_stride;
@@ -808,7 +823,7 @@ static int launch_wgrad_mode(WgArgs a, const WgPlan& p, float* dw_out, float* wo
   a.chunks_total = p.chunks_total;
   const size_t lds = p.lds;
   PWG_REQUIRE(lds <= 160 * 1024, PWG_ERR_UNSUPPORTED, "conv1d_backward_weight: tile needs %zu B of LDS", lds);
-  void (*kern)(WgArgs) = conv1d_wgrad_kernel<TG, WIN, SMALL, TT, MODE>;
+  void (*kern)(WgArgs) = conv1d_wgrad_kernel<TG, WIN, SMALL, TT, MODE, ACT23, STRIDE3>;
   if (lds > 64 * 1024 && !lds_limit_is_set(reinterpret_cast<const void*>(kern), lds)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -851,8 +866,28 @@ static int launch_wgrad(WgArgs a, const WgPlan& p, float* dw_out, float* workspa
   const bool act = (a.slope_g != 1.f || a.slope_x != 1.f) && !(a.dbg & 8);
 #define WG_GO(WINV, MODEV) \
   return launch_wgrad_mode<TG, SMALL, TT, WINV, MODEV>(a, p, dw_out, workspace, ws_floats, stream, flops, bytes, wn)
-  if (a.width != 1) WG_GO(false, 2);  // per-tap windows need width == 1 and stride == 1 (wgrad_plan)
-  if (a.stride != 1) WG_GO(false, 3);
+#define WG_GO23(MODEV, ACTV, SV) \
+  return launch_wgrad_mode<TG, SMALL, TT, false, MODEV, ACTV, SV>(a, p, dw_out, workspace, ws_floats, stream, flops, bytes, wn)
+  static const bool fast23 = !(getenv("PWG_WG_FAST23") && atoi(getenv("PWG_WG_FAST23")) == 0);  // (0: the round-5 loops, A/B)
+  if (a.width != 1) {  // per-tap windows need width == 1 and stride == 1 (wgrad_plan)
+    if (act || !fast23) WG_GO23(2, true, 0);
+    WG_GO23(2, false, 0);
+  }
+  if (a.stride != 1) {
+    if (fast23 && !act) {  // the strides of the recipes' layers: scale discriminators 4 (2 in some recipes), upsamplers 8 / 5 / 3
+      switch (a.stride) {
+        case 2: WG_GO23(3, false, 2);
+        case 3: WG_GO23(3, false, 3);
+        case 4: WG_GO23(3, false, 4);
+        case 8: WG_GO23(3, false, 8);
+        default: WG_GO23(3, false, 0);
+      }
+    }
+    if (fast23 && a.stride == 8) WG_GO23(3, true, 8);  // (ConvTranspose1d of the generators: activated input)
+    if (fast23 && a.stride == 4) WG_GO23(3, true, 4);
+    if (fast23 && a.stride == 2) WG_GO23(3, true, 2);
+    WG_GO23(3, true, 0);
+  }
   if (p.win) {
     if (act) WG_GO(true, 1);
     WG_GO(true, 0);
@@ -860,6 +895,7 @@ static int launch_wgrad(WgArgs a, const WgPlan& p, float* dw_out, float* workspa
   if (act) WG_GO(false, 1);
   WG_GO(false, 0);
 #undef WG_GO
+#undef WG_GO23
 }
 
 }  // namespace pwg

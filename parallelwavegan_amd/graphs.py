@@ -8,14 +8,6 @@ as one graph launch per utterance shape.
 import torch
 
 
-def _version_of(t):
-    """torch's version counter of ``t``; tensors created or loaded under ``torch.inference_mode()`` do not track one
-    (reading it raises) and cannot be written in place outside inference mode either: a constant stands in."""
-    if t.is_inference():
-        return -1
-    return t._version
-
-
 class GraphedInference:
     """Capture ``model.forward`` for fixed input shapes; ``__call__`` copies the new inputs into the
     static buffers and replays.  One graph per distinct input shape (cached).
@@ -51,9 +43,9 @@ class GraphedInference:
             return self._state  # the caller vouches for frozen weights: no per-call walk over the tensors
         st = [ops.PARAM_EPOCH[0], model.training]
         for t in model.parameters():
-            st.append((t.data_ptr(), _version_of(t), ops.param_epoch(t)))
+            st.append((t.data_ptr(), ops.tensor_version(t), ops.param_epoch(t)))
         for t in model.buffers():
-            st.append((t.data_ptr(), _version_of(t)))
+            st.append((t.data_ptr(), ops.tensor_version(t)))
         return st
 
     def _capture(self, inputs):

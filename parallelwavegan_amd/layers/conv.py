@@ -177,7 +177,7 @@ class _ConvNd(torch.nn.Module):
             ps += [self.weight_u, self.weight_v]
         # the fused optimizers update parameters through raw pointers: they bump a per-parameter
         # epoch (ops.param_epoch) instead of torch's version counter
-        return (ops.PARAM_EPOCH[0],) + tuple((p.data_ptr(), p._version, ops.param_epoch(p), str(p.device)) for p in ps)
+        return (ops.PARAM_EPOCH[0],) + tuple((p.data_ptr(), ops.tensor_version(p), ops.param_epoch(p), str(p.device)) for p in ps)
 
     def prepared(self):
         """:class:`functional.PreparedWeights` for the current parameter values (weight or weight-norm

@@ -29,6 +29,12 @@ def param_epoch(p):
     return getattr(p, "_pwg_epoch", 0)
 
 
+def tensor_version(t):
+    """torch's version counter of ``t``.  Tensors created or loaded under ``torch.inference_mode()`` track none (reading
+    it raises) and cannot be written in place outside inference mode either: a constant stands in."""
+    return -1 if t.is_inference() else t._version
+
+
 def bump_params(params):
     """Mark parameters as changed through raw pointers (fused optimizer kernels)."""
     for p in params:

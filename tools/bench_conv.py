@@ -10,6 +10,8 @@ CFG = {0:(128,128,8),1:(128,128,16),2:(128,128,4),3:(64,256,8),4:(64,256,16),5:(
        8:(32,512,16),9:(128,64,8),10:(32,128,8),11:(64,256,4),12:(64,128,8),13:(64,64,8),14:(128,32,8),15:(64,64,16),
        16:(32,128,16),17:(64,64,4),18:(128,256,4),19:(128,256,8)}
 
+PRE = None if os.environ.get("PWG_BENCH_ACT") == "0" else "leaky_relu"  # PWG_BENCH_ACT=0: no in-loop pre-activation (round 6 A/B)
+
 def timeit(fn, reps=10):
     for _ in range(2): fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -39,13 +41,13 @@ def main():
         k = p["kernel"]
         if p.get("transposed"):
             s = p["stride"]; t_out = p["T"] * s
-            desc = ops.make_conv_desc(B, p["c_in"], p["c_out"], p["T"], t_out, k, stride=s, pad_left=s // 2 + s % 2, transposed=True, pre_act="leaky_relu", pre_slope=0.1)
+            desc = ops.make_conv_desc(B, p["c_in"], p["c_out"], p["T"], t_out, k, stride=s, pad_left=s // 2 + s % 2, transposed=True, pre_act=PRE, pre_slope=0.1)
             w = torch.randn(p["c_in"], p["c_out"], k, device=dev) * 0.05
             flops = 2.0 * p["c_in"] * p["c_out"] * k * p["T"] * B
             m_g = p["c_out"] * s
         else:
             d = p["dil"]; t_out = p["T"]
-            desc = ops.make_conv_desc(B, p["c_in"], p["c_out"], p["T"], t_out, k, dilation=d, pad_left=(k - 1) // 2 * d, pre_act="leaky_relu", pre_slope=0.1)
+            desc = ops.make_conv_desc(B, p["c_in"], p["c_out"], p["T"], t_out, k, dilation=d, pad_left=(k - 1) // 2 * d, pre_act=PRE, pre_slope=0.1)
             w = torch.randn(p["c_out"], p["c_in"], k, device=dev) * 0.05
             flops = 2.0 * p["c_in"] * p["c_out"] * k * t_out * B
             m_g = p["c_out"]

@@ -10,7 +10,7 @@ from parallelwavegan_amd import ops
 
 CFG = {0: (128, 128, 8), 1: (128, 128, 16), 2: (128, 128, 4), 9: (128, 64, 8), 12: (64, 128, 8), 13: (64, 64, 8), 15: (64, 64, 16),
        16: (32, 128, 16), 11: (64, 256, 4), 3: (64, 256, 8), 14: (128, 32, 8), 4: (64, 256, 16), 5: (32, 256, 8), 6: (32, 256, 16),
-       7: (32, 512, 8), 8: (32, 512, 16), 10: (32, 128, 8)}
+       7: (32, 512, 8), 8: (32, 512, 16), 10: (32, 128, 8), 17: (64, 64, 4)}
 
 
 def timeit(fn, reps=10):
@@ -29,7 +29,16 @@ def timeit(fn, reps=10):
 dev = torch.device("cuda:0")
 B = 16
 K1 = len(sys.argv) > 1 and sys.argv[1] == "k1"
-shapes = [("c4 k1 96->96 T2048 B64", dict(c_in=96, c_out=96, t_in=2048, t_out=2048, k=1, stride=1, pad=0, batch=64)),
+FOLD = len(sys.argv) > 1 and sys.argv[1] == "fold"
+# round 6: the batch-FOLDED tail layers of the scale discriminators (layers/conv.py: _fold_batch): one item of width 16
+fold_shapes = []
+for t in (32, 17, 9):
+    fold_shapes += [(f"fold T{t} 1024->1024 k41 g16", dict(c_in=1024, c_out=1024, t_in=t, t_out=t, k=41, stride=1, pad=20, groups=16, width=16, batch=1)),
+                    (f"fold T{t} 1024->1024 k41 g16 dgrad", dict(c_in=1024, c_out=1024, t_in=t, t_out=t, k=41, stride=1, pad=20, groups=16, width=16, batch=1, transposed=True)),
+                    (f"fold T{t} 1024->1024 k5", dict(c_in=1024, c_out=1024, t_in=t, t_out=t, k=5, stride=1, pad=2, width=16, batch=1)),
+                    (f"fold T{t} 512->1024 k41 s4 g16", dict(c_in=512, c_out=1024, t_in=4 * t - 3 if t != 32 else 128, t_out=t, k=41, stride=4, pad=20, groups=16, width=16, batch=1)),
+                    (f"fold T{t} 512->1024 k41 s4 g16 dgrad", dict(c_in=1024, c_out=512, t_in=t, t_out=4 * t - 3 if t != 32 else 128, k=41, stride=4, pad=20, groups=16, width=16, batch=1, transposed=True))]
+shapes = fold_shapes if FOLD else [("c4 k1 96->96 T2048 B64", dict(c_in=96, c_out=96, t_in=2048, t_out=2048, k=1, stride=1, pad=0, batch=64)),
           ("c4 k1 48->48 T4096 B64", dict(c_in=48, c_out=48, t_in=4096, t_out=4096, k=1, stride=1, pad=0, batch=64)),
           ("c4 k1 192->192 T512 B64", dict(c_in=192, c_out=192, t_in=512, t_out=512, k=1, stride=1, pad=0, batch=64)),
           ("c4 k3 96->96 d3 T2048 B64", dict(c_in=96, c_out=96, t_in=2048, t_out=2048, k=3, stride=1, pad=3, batch=64, dil=3)),
@@ -43,21 +52,22 @@ for name, p in shapes:
     w_ = p.get("width", 1)
     tr = p.get("transposed", False)
     B = p.get("batch", 16)
+    g_ = p.get("groups", 1)
     desc = ops.make_conv_desc(B, p["c_in"], p["c_out"], p["t_in"], p["t_out"], p["k"], stride=p["stride"], pad_left=p["pad"], dilation=p.get("dil", 1),
-                              transposed=tr, width=w_, pre_act="leaky_relu", pre_slope=0.1)
-    w = (torch.randn(p["c_in"], p["c_out"], p["k"], device=dev) if tr else torch.randn(p["c_out"], p["c_in"], p["k"], device=dev)) * 0.03
+                              groups=g_, transposed=tr, width=w_, pre_act=None if FOLD else "leaky_relu", pre_slope=0.1)
+    w = (torch.randn(p["c_in"], p["c_out"] // g_, p["k"], device=dev) if tr else torch.randn(p["c_out"], p["c_in"] // g_, p["k"], device=dev)) * 0.03
     wp = ops.pack_weight(desc, w)
     x = torch.randn(B, p["c_in"], p["t_in"] * w_, device=dev)
     bias = torch.randn(p["c_out"], device=dev)
     y = torch.empty(B, p["c_out"], p["t_out"] * w_, device=dev)
-    flops = 2.0 * p["c_in"] * p["c_out"] * p["k"] * (p["t_in"] if tr else p["t_out"]) * w_ * B
+    flops = 2.0 * p["c_in"] * p["c_out"] // g_ * p["k"] * (p["t_in"] if tr else p["t_out"]) * w_ * B
     os.environ.pop("PWG_FORCE_CFG", None)
     ref = ops.conv1d_forward(desc, x, wp, bias).clone()
     ms = timeit(lambda: ops.conv1d_forward(desc, x, wp, bias, out=y))
     print(f"{name}: planner {ms * 1e3:.1f} us {flops / ms / 1e9:.1f} TF")
     res = []
     for cid, (bm, bn, ck) in CFG.items():
-        for ks in ((1,) if K1 else (1, 2, 4, 8)):
+        for ks in ((1,) if K1 else (1, 2, 4, 8, 16) if FOLD else (1, 2, 4, 8)):
             os.environ["PWG_FORCE_CFG"] = f"{cid},{ks}"
             try:
                 out = ops.conv1d_forward(desc, x, wp, bias, out=y)
