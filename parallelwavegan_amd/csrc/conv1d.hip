@@ -771,6 +771,82 @@ __global__ __launch_bounds__(256) void conv1d_small_cout_kernel(const float* __r
   }
 }
 
+// Round 6: the same layer as a pure stream (dilation 1, "same" padding (k - 1) / 2 <= 4, 16-B aligned rows): no LDS
+// round trip and no barrier per input channel -- every thread owns 4 consecutive outputs, loads the 12-sample window
+// [t - 4, t + 8) of each input row with three 16-B loads (neighbouring threads' windows overlap: the vector L1 serves
+// the re-reads, HBM sees every byte once), applies the pre-activation in registers and accumulates in the SAME
+// (ci, tap) order with the same fmaf chain as the kernel above (bit-identical results).  HiFi-GAN's 32 -> 1 k = 7
+// output layer at B16 x 204 800: 230 us = 1.8 TB/s (0.29 of the 6.3 TB/s streaming rate) with the LDS kernel
+// (profiles/r05_hbm_helpers.txt); this kernel: profiles/r06_hbm_helpers.txt.
+template <int K, int PAD, int COUT>
+__global__ __launch_bounds__(256) void conv1d_small_cout_stream_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                                       const float* __restrict__ bias, float* __restrict__ y,
+                                                                       int cin, int cin_pad, int m_pad, int t_in, int t_out,
+                                                                       int pre_act, float pre_slope, int post_act,
+                                                                       float post_slope, float out_mul) {
+  static_assert(PAD <= 4 && K - 1 - PAD <= 4, "window [t - 4, t + 8)");
+  extern __shared__ float ws[];  // [cin][K][COUT]
+  for (int i = threadIdx.x; i < cin * K * COUT; i += 256) {  // from the packed image [tap][ci][m]
+    const int c = i % COUT, tap = (i / COUT) % K, ci = i / (COUT * K);
+    ws[i] = wp[((long)tap * cin_pad + ci) * m_pad + c];
+  }
+  __syncthreads();
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 1024 + 4 * (int)threadIdx.x;
+  if (t >= t_out) return;
+  const float* xb = x + (long)b * cin * t_in;
+  float acc[4][COUT];
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[o][c] = 0.f;
+  const bool interior = t >= 4 && t + 8 <= t_in;
+  // LeakyReLU / ReLU as one select per value; slope_eff: 1 = no activation
+  const float slope_eff = pre_act == PWG_ACT_LEAKY_RELU ? pre_slope : (pre_act == PWG_ACT_RELU ? 0.f : 1.f);
+#pragma unroll 4
+  for (int ci = 0; ci < cin; ++ci) {
+    const float* row = xb + (long)ci * t_in;
+    float w12[12];
+    if (interior) {
+      const float4 a = *reinterpret_cast<const float4*>(row + t - 4);
+      const float4 m = *reinterpret_cast<const float4*>(row + t);
+      const float4 e = *reinterpret_cast<const float4*>(row + t + 4);
+      w12[0] = a.x; w12[1] = a.y; w12[2] = a.z; w12[3] = a.w;
+      w12[4] = m.x; w12[5] = m.y; w12[6] = m.z; w12[7] = m.w;
+      w12[8] = e.x; w12[9] = e.y; w12[10] = e.z; w12[11] = e.w;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 12; ++q) {
+        const int f = t - 4 + q;
+        w12[q] = (f >= 0 && f < t_in) ? row[f] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int q = 4 - PAD; q < 4 + 3 + K - PAD; ++q) w12[q] = w12[q] > 0.f ? w12[q] : w12[q] * slope_eff;
+    const float* wc = ws + ci * (K * COUT);
+#pragma unroll
+    for (int tap = 0; tap < K; ++tap)
+#pragma unroll
+      for (int c = 0; c < COUT; ++c) {
+        const float wv = wc[tap * COUT + c];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[o][c] = __builtin_fmaf(wv, w12[4 + o + tap - PAD], acc[o][c]);
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < COUT; ++c) {
+    const float bv = bias ? bias[c] : 0.f;
+    float r[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      float v = acc[o][c] + bv;
+      if (out_mul != 1.0f) v *= out_mul;
+      r[o] = apply_act(v, post_act, post_slope);
+    }
+    *reinterpret_cast<float4*>(y + ((long)b * COUT + c) * t_out + t) = make_float4(r[0], r[1], r[2], r[3]);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Single-input-channel convolutions at the audio rate: the first layer of every discriminator (HiFi-GAN MSD 1 -> 128,
 // k = 15; MelGAN 1 -> 16, k = 15; PWG 1 -> 64, k = 3 -- reference models/hifigan.py:516-528, models/melgan.py:318-327,
@@ -787,7 +863,9 @@ constexpr int SI_MAXK = 16;
 // 8 tiles = 128 workgroups each walking 128 channels (round 4: 126 us = 0.5 TB/s; the write of y is the whole job).
 // VEC: every thread owns 4 CONSECUTIVE columns and stores them as one 16-B piece (t_out % 4 == 0, y 16-B aligned);
 // else the columns of a thread are 256 apart (4-B stores, each wave instruction one contiguous 256-B run).
-template <bool VEC>
+// NT: the output leaves through non-temporal stores (written once, read by a later launch: keeping 67 MB of it in the
+// L2s only evicts what the neighbours need) -- round 6 A/B: profiles/r06_hbm_helpers.txt.
+template <bool VEC, bool NT = false>
 __global__ __launch_bounds__(256) void conv1d_small_cin_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                                const float* __restrict__ bias, float* __restrict__ y,
                                                                int cin_pad, int m_pad, int cout, int cg, int t_in, int t_out,
@@ -847,7 +925,12 @@ __global__ __launch_bounds__(256) void conv1d_small_cin_kernel(const float* __re
     }
     if (VEC) {
       const int t = t0 + col0;
-      if (t < t_out) *reinterpret_cast<float4*>(yb + (long)c * t_out + t) = make_float4(r[0], r[1], r[2], r[3]);
+      if (t < t_out) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const f32x4 r4 = {r[0], r[1], r[2], r[3]};
+        if (NT) __builtin_nontemporal_store(r4, reinterpret_cast<f32x4*>(yb + (long)c * t_out + t));
+        else *reinterpret_cast<f32x4*>(yb + (long)c * t_out + t) = r4;
+      }
     } else {
 #pragma unroll
       for (int o = 0; o < 4; ++o) {
@@ -1483,15 +1566,18 @@ static int choose_cfg(const Geometry& g, int W, int batch, int groups, bool dma,
       const long full = (long)(512.f * concurrency_hint());
       while (split < 4 && nchunks >= 32 * (2 * split) && blocks * split < full) split *= 2;
     }
-    // Round 6: launches that leave HALF the chip (or more) without a workgroup -- the batch-folded tail layers of the
-    // scale discriminators (one item of 144 .. 512 columns: grouped k = 41 layers 64 .. 128 workgroups of 8 chunks of
-    // 164 MFMAs per wave each, which the latency rule above never splits; 1024 -> 1024 k = 5: 48 .. 128) -- are cut
-    // until the slices fill it, whatever a chunk carries: forced sweep tools/bench_dsplit.py fold
-    // (profiles/r06_fold_split_sweep.txt): k = 41 g16 at T = 9 / 17 / 32: 86.6 / 85.9 / 89.5 us -> 32.4 / 51.5 / 54.1 us
-    // (32x128x8 split 4 / 2 / 2), 512 -> 1024 k = 41 s4 g16: 50.6 -> 22.2 / 32.2 / 34.5 us, 1024 -> 1024 k = 5 at T = 9 / 17:
-    // 57.1 / 76.6 -> 41.5 / 57.6 us (split 16 / 8).  (PWG_SPLIT_UNDERFILL=0 restores the round-5 rule.)
+    // Round 6: SINGLE-UTTERANCE launches (batch 1, width 1: bin/decode.py's regime) that leave half the chip (or more)
+    // without a workgroup are cut until the slices fill it, whatever a chunk carries -- the latency rule above never
+    // splits heavy chunks.  Measured on the batch-folded training layers first (tools/bench_dsplit.py fold,
+    // profiles/r06_fold_split_sweep.txt: grouped k = 41 layers of 64 .. 128 workgroups 86 -> 32 .. 54 us stand-alone),
+    // but NOT applied to them: inside the captured training step those launches share the chip with the other
+    // sub-discriminators' branches, the idle CUs are not idle, and the extra slabs cost more than the shorter launch
+    // gains (C5 44.04 ms with the rule against 43.73 ms without, C3 within the spread: profiles/r06_train_ab.txt); on
+    // multi-item launches it made the planner trade tiles that fill the chip for split big tiles (C3: +115 finish
+    // launches, +2.0 ms of splitk_finish per step) and changes summation orders the full-shape training bars are
+    // calibrated on.  (PWG_SPLIT_UNDERFILL=0 restores the round-5 rule.)
     static const bool split_underfill = !(getenv("PWG_SPLIT_UNDERFILL") && atoi(getenv("PWG_SPLIT_UNDERFILL")) == 0);
-    if (split_underfill) {
+    if (split_underfill && batch == 1 && W == 1) {
       const long full = (long)((k >= 32 ? 256.f : 512.f) * concurrency_hint());
       while (split < 16 && nchunks >= 2 * split && blocks * split * 2 <= full) split *= 2;
     }
@@ -1715,7 +1801,9 @@ extern "C" int pwg_conv1d_forward(const pwg_conv1d_desc* d_in, const float* x, c
     if (rc != PWG_OK) return rc;
     // channel groups: at least ~1024 workgroups per launch (4 per CU), never fewer than 8 channels per group
     const int pairs = ceil_div(d->t_out, SI_TILE) * d->batch;
-    int ngroups = ceil_div(1024, pairs);
+    static const int wgs_target = getenv("PWG_SMALL_CIN_WGS") ? atoi(getenv("PWG_SMALL_CIN_WGS")) : 1024;
+    static const bool nt_store = getenv("PWG_SMALL_CIN_NT") && atoi(getenv("PWG_SMALL_CIN_NT")) != 0;
+    int ngroups = ceil_div(wgs_target, pairs);
     if (ngroups > d->c_out / 8) ngroups = d->c_out / 8;
     if (ngroups < 1) ngroups = 1;
     const int cg = ceil_div(d->c_out, ngroups);
@@ -1726,7 +1814,11 @@ extern "C" int pwg_conv1d_forward(const pwg_conv1d_desc* d_in, const float* x, c
     const bool vec = d->t_out % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15u) == 0;
     ProfScope prof((hipStream_t)stream, "conv1d_small_cin_kernel", 2.0 * out_elems * d->kernel,
                    4.0 * ((double)d->batch * d->t_in + out_elems));
-    hipLaunchKernelGGL(vec ? conv1d_small_cin_kernel<true> : conv1d_small_cin_kernel<false>,
+    void (*sik)(const float*, const float*, const float*, float*, int, int, int, int, int, int, int, int, int, int, float, int,
+                float, float) = conv1d_small_cin_kernel<false, false>;
+    if (vec && nt_store) sik = conv1d_small_cin_kernel<true, true>;
+    else if (vec) sik = conv1d_small_cin_kernel<true, false>;
+    hipLaunchKernelGGL(sik,
                        dim3(ceil_div(d->t_out, SI_TILE), d->batch, ngroups), dim3(256), lds, (hipStream_t)stream, x, w_packed,
                        bias, y, g.cin_pad, g.m_pad, d->c_out, cg, d->t_in, d->t_out, d->kernel, d->dilation, d->pad_left,
                        d->pre_act, d->pre_slope, d->post_act, d->post_slope, d->out_mul);
@@ -1739,6 +1831,32 @@ extern "C" int pwg_conv1d_forward(const pwg_conv1d_desc* d_in, const float* x, c
     rc = fill_args(d, g, x, w_packed, bias, add1, add2, y, &chk);
     if (rc != PWG_OK) return rc;
     // few output channels over a long sequence: streaming VALU kernel (see conv1d_small_cout_kernel)
+    {
+      // round 6: the LDS-free stream for "same"-padded dilation-1 layers with 16-B aligned rows (PWG_SMALL_COUT_STREAM=0: off)
+      static const bool stream_on = !(getenv("PWG_SMALL_COUT_STREAM") && atoi(getenv("PWG_SMALL_COUT_STREAM")) == 0);
+      const int kk = d->kernel;
+      void (*sk)(const float*, const float*, const float*, float*, int, int, int, int, int, int, float, int, float, float) = nullptr;
+      if (stream_on && d->dilation == 1 && (kk & 1) && d->pad_left == (kk - 1) / 2 && d->t_out == d->t_in &&
+          (d->t_in & 3) == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && (d->c_out == 1 || d->c_out == 4)) {
+#define PWG_SCS(KV) (d->c_out == 1 ? conv1d_small_cout_stream_kernel<KV, (KV - 1) / 2, 1> : conv1d_small_cout_stream_kernel<KV, (KV - 1) / 2, 4>)
+        if (kk == 1) sk = PWG_SCS(1);
+        else if (kk == 3) sk = PWG_SCS(3);
+        else if (kk == 5) sk = PWG_SCS(5);
+        else if (kk == 7) sk = PWG_SCS(7);
+#undef PWG_SCS
+      }
+      if (sk) {
+        const double out_elems = (double)d->batch * d->c_out * d->t_out;
+        ProfScope prof((hipStream_t)stream, "conv1d_small_cout_stream_kernel", 2.0 * out_elems * d->c_in * d->kernel,
+                       4.0 * ((double)d->batch * d->c_in * d->t_in + out_elems));
+        hipLaunchKernelGGL(sk, dim3(ceil_div(d->t_out, 1024), d->batch), dim3(256),
+                           (size_t)d->c_out * d->c_in * d->kernel * sizeof(float), (hipStream_t)stream, x, w_packed, bias, y,
+                           d->c_in, g.cin_pad, g.m_pad, d->t_in, d->t_out, d->pre_act, d->pre_slope, d->post_act,
+                           d->post_slope, d->out_mul);
+        PWG_CHECK_LAUNCH("conv1d_small_cout_stream");
+        return PWG_OK;
+      }
+    }
     int opt = 4;
     while (opt > 1 && (long)ceil_div(d->t_out, 256 * opt) * d->batch < 1024) opt >>= 1;
     const int tile = 256 * opt;

@@ -38,6 +38,7 @@ struct WgArgs {
   long slab_stride; // floats between consecutive slabs (dW + fused bias row)
   float slope_g, slope_x;  // branch-free pre-activation slopes (1 = none)
   unsigned g_bytes, x_bytes;
+  int rows_half;  // MODE 4 (row-aligned (k,1) chunks): G rows per lane half of a chunk (a chunk = 2 * rows_half rows x width)
   int tap_major;  // slab layout: 1 = [tap][o][i] (coalesced partial-sum stores, the finishers permute), 0 = torch (o, i, tap)
   int dbg;  // timing experiments only (PWG_WG_DBG env): 1 = no DMA after the first chunk, 2 = no waits / barriers, 4 = no stores
 };
@@ -57,12 +58,21 @@ struct WgArgs {
 //      discriminators).  ACT23 (modes 2 / 3 only): evaluate the activation formula there too -- round 6: the
 //      discriminators hand both operands over already activated (slopes 1), and the 2 x (TG + 1) VALU operations per
 //      reduction step of the always-on formula were a third of the strided layers' loop (profiles/r06_wgrad_strided.txt).
+// MODE 4 (round 6): width > 1 with ROW-ALIGNED chunks.  Mode 2 walks the reduction columns n = h * W + w two at a time
+//      (lane halves n, n + 1): with odd W the row wrap falls on different steps in different lanes, so every step
+//      recomputes its X offset per lane (7 VALU) and adds it to every tap pointer (TG VALU) -- 31 VALU operations
+//      per 5 MFMAs on the period discriminators' stride-3 layers, 43 TFLOP/s.  Here a chunk is 2 * rows_half whole rows
+//      of G: the lower lane half walks the first rows_half rows, the upper half the others, both at the same (row,
+//      column) step, so the walk is wave-uniform (scalar registers) and the G tile is two 32-column blocks, one per
+//      half (rows_half * W <= 32), read exactly like the stride-1 modes' tile.
 // STRIDE3 (mode 3 only): compile-time stride (0 = run time) -- the step offsets of the X reads fold into the LDS
 //      instructions as in the stride-1 modes.
 template <int TG, bool WIN, bool SMALL, int TT, int MODE, bool ACT23 = true, int STRIDE3 = 0>
 __global__ __launch_bounds__(256, (TG > 7 ? 1 : 2)) void conv1d_wgrad_kernel(WgArgs a) {
   constexpr int BT = SMALL ? 32 : 64;          // tile rows (o) and columns (i)
   constexpr int TAPS_BLOCK = SMALL ? 4 * TG : TG;
+  constexpr bool ROWS = MODE == 4;
+  static_assert(!ROWS || (TT == 64 && !WIN), "row-aligned chunks: two 32-column G blocks, shared X tile");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int XS = a.xs_stride;
   const int buf_floats = BT * TT + (WIN ? TAPS_BLOCK * BT * TT : BT * XS);
@@ -123,7 +133,21 @@ __global__ __launch_bounds__(256, (TG > 7 ? 1 : 2)) void conv1d_wgrad_kernel(WgA
     // ---- G tile: [TT/32 column blocks][BT rows][32]; element (o, n) at column (n + o) & 31 of its block
     // (tensors are below 4 GiB, checked by the host: 32-bit element indices)
     const int g_base = (b * co_tot + grp * a.co_g + o0) * a.n_cols + n0;
-    if (o_full && n0 + TT <= a.n_cols) {
+    if (ROWS) {
+      // two column blocks: block cb holds the rows_half * W columns of the chunk's rows [cb * rows_half, (cb + 1) * rows_half)
+      const int hc = a.rows_half * a.width;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int jj = 4 * q + wave;
+        const int cb = jj / (BT / 2), j = jj - cb * (BT / 2);
+        const int row = 2 * j + lhi;
+        const int nrel = (l31 - row) & 31;
+        const int nc = cb * hc + nrel;
+        const bool ok = o0 + row < a.co_g && nrel < hc && n0 + nc < a.n_cols;
+        const unsigned off = ok ? (unsigned)(g_base + row * a.n_cols + nc) * 4u : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(g_rs, (lds_ptr_t)(gs + cb * (BT * 32) + j * 64), 4, off, 0, 0, 0);
+      }
+    } else if (o_full && n0 + TT <= a.n_cols) {
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const int jj = 4 * q + wave;
@@ -175,13 +199,14 @@ __global__ __launch_bounds__(256, (TG > 7 ? 1 : 2)) void conv1d_wgrad_kernel(WgA
     const int h0 = n0 / W;
     int n_last = n0 + TT - 1;
     if (n_last > a.n_cols - 1) n_last = a.n_cols - 1;
-    const int h1 = n_last / W;
+    // (row-aligned chunks always stage -- and walk -- all 2 * rows_half rows: rows past the item meet G = 0)
+    const int h1 = ROWS ? h0 + 2 * a.rows_half - 1 : n_last / W;
     const int f0 = (h0 * a.stride + k0 * a.dil - a.pad) * W;
     const int L = ((h1 - h0) * a.stride + (ntaps_block - 1) * a.dil + 1) * W;
     const int Lr = (L + 63) & ~63;  // whole DMA pieces (the row stride XS covers them)
     // (full chunks only: the last chunk of an item stages fewer columns than the MFMA loop walks, and the
     // predicated path below zero-fills the rest -- stale LDS there meets G = 0, and 0 * NaN is NaN)
-    if (i_full && f0 >= 0 && f0 + Lr <= a.x_len && n0 + TT <= a.n_cols) {
+    if (i_full && f0 >= 0 && f0 + Lr <= a.x_len && (ROWS || n0 + TT <= a.n_cols)) {
 #pragma unroll 1
       for (int e0 = 0; e0 < Lr; e0 += 64) {
         const int fl = f0 + e0 + lane;
@@ -300,13 +325,68 @@ __global__ __launch_bounds__(256, (TG > 7 ? 1 : 2)) void conv1d_wgrad_kernel(WgA
     }
   };
 
+  // MODE 4: one chunk = rows_half * W reduction steps; step (hr, w) pairs row hr of the lower half with row
+  // rows_half + hr of the upper half, column w.  u = X-tile offset of the step (wave-uniform), the G column is the step
+  // index inside the lane half's 32-column block.
+  auto mac_rows = [&](const float* gs, const float* xrow, int orow, int irow) {
+    constexpr bool ACT = ACT23;
+    const int W_ = a.width;
+    const int steps = a.rows_half * W_;
+    const int row_skip = (a.stride - 1) * W_;
+    const float* gb = gs + lhi * (BT * 32) + orow * 32;
+    const int rot = orow & 31;
+    const float* xt[TG];
+#pragma unroll
+    for (int t = 0; t < TG; ++t) xt[t] = xrow + toff[t] + lhi * (a.rows_half * a.stride * W_);
+    int si = 0, u = 0, w = 0;  // the step the next load_ops call reads (wave-uniform)
+    auto load_ops = [&](float& av, float(&bv)[TG]) {
+      av = gb[(si + rot) & 31];
+#pragma unroll
+      for (int t = 0; t < TG; ++t) bv[t] = xt[t][u];
+      if (si + 1 < steps) {  // (the call past the last step re-reads it: harmless, never used)
+        ++si;
+        ++u;
+        if (++w == W_) {
+          w = 0;
+          u += row_skip;
+        }
+      }
+    };
+    auto mma = [&](float av, float(&bv)[TG]) {
+      bsum += av;
+      if (ACT) av = __builtin_fmaxf(av, av * a.slope_g);
+#pragma unroll
+      for (int t = 0; t < TG; ++t) {
+        float v = bv[t];
+        if (ACT) v = __builtin_fmaxf(v, v * a.slope_x);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, v, acc[t], 0, 0, 0);
+      }
+    };
+    float a0, a1, b0[TG], b1[TG];
+    load_ops(a0, b0);
+    int s = 0;
+#pragma unroll 2
+    for (; s + 2 <= steps; s += 2) {
+      load_ops(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_ops(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (s < steps) mma(a0, b0);  // odd step count: the last step is in (a0, b0)
+  };
+
   // (b, n0) of the chunk being computed and of the one being staged, carried without divisions
+  const int chunk_cols = ROWS ? 2 * a.rows_half * a.width : TT;
   int cb_b = c_begin / a.chunks_per_item;
-  int cb_n0 = (c_begin - cb_b * a.chunks_per_item) * TT;
+  int cb_n0 = (c_begin - cb_b * a.chunks_per_item) * chunk_cols;
   int nb_b = cb_b, nb_n0 = cb_n0;
   auto advance = [&](int& b, int& n0) {
-    n0 += TT;
-    if (n0 >= a.chunks_per_item * TT) {
+    n0 += chunk_cols;
+    if (n0 >= a.chunks_per_item * chunk_cols) {
       n0 = 0;
       ++b;
     }
@@ -332,7 +412,10 @@ __global__ __launch_bounds__(256, (TG > 7 ? 1 : 2)) void conv1d_wgrad_kernel(WgA
     const float* grow = gs + orow * 32;
     const int irow = wave_i * 32 + l31;
     const float* xrow = xs + irow * (WIN ? 32 : XS) + (WIN ? t0 * (BT * TT) : t0 * a.dil * W);
-    if (ntaps > 0) mac_chunk(grow, xrow, n0, h0, orow, irow);
+    if (ntaps > 0) {
+      if constexpr (ROWS) mac_rows(gs, xrow, orow, irow);
+      else mac_chunk(grow, xrow, n0, h0, orow, irow);
+    }
   }
 
   // ---- epilogue: D layout col = lane&31 (-> i), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (-> o).
@@ -639,6 +722,7 @@ struct WgPlan {
   size_t lds;
   int chunks_per_item, chunks_total;
   int tap_groups, tiles, splits;
+  int rows_half;  // > 0: MODE 4 (row-aligned chunks of 2 * rows_half rows), tt = 64
 };
 
 static size_t wgrad_lds(bool small, bool win, int taps_block, int tt, int stride, int dil, int width, int k,
@@ -732,7 +816,36 @@ static WgPlan wgrad_plan(int co_g, int ci_g, int groups, int k, int stride, int 
     p.small = true;
   }
   const int bt = p.small ? 32 : 64;
-  p.chunks_per_item = ceil_div(n_cols, p.tt);
+  // Round 6, MODE 4: (k,1) layers that stay in width mode (strided: the period discriminators' stride-3 layers, the
+  // batch-folded stride-4 layers) walk row-aligned chunks when a row fits a 32-column G block.  rows_half: the even
+  // split with the fewest wasted rows at the item's tail, larger chunks first.
+  static const bool rows_on = !(getenv("PWG_WG_ROWS") && atoi(getenv("PWG_WG_ROWS")) == 0);
+  p.rows_half = 0;
+  if (rows_on && width > 1 && width <= 32 && !p.win && n_cols % width == 0) {
+    const int h_out = n_cols / width;
+    const int ntaps_max = k < p.taps_block ? k : p.taps_block;
+    float best = -1.f;
+    for (int r = 32 / width; r >= 1; --r) {
+      const int xs_len = ((2 * r - 1) * stride + (ntaps_max - 1) * dil + 1) * width;
+      const int xs = round_up(xs_len, 64) + 1;
+      const size_t lds = 2 * (size_t)(bt * 64 + bt * xs) * sizeof(float);
+      if (lds > 160 * 1024) continue;
+      const float useful = (float)h_out / (float)(ceil_div(h_out, 2 * r) * 2 * r);
+      // (a chunk below ~24 columns carries too little work per barrier: small penalty)
+      const float score = useful * (2 * r * width >= 24 ? 1.f : 0.85f) * (lds <= 80 * 1024 ? 1.05f : 1.f);
+      if (score > best + 1e-6f) {
+        best = score;
+        p.rows_half = r;
+        p.xs_stride = xs;
+        p.lds = lds;
+      }
+    }
+    if (p.rows_half > 0) {
+      p.tt = 64;
+      p.chunks_per_item = ceil_div(h_out, 2 * p.rows_half);
+    }
+  }
+  if (p.rows_half == 0) p.chunks_per_item = ceil_div(n_cols, p.tt);
   p.chunks_total = p.chunks_per_item * batch;
   p.tap_groups = ceil_div(k, p.taps_block);
   p.tiles = ceil_div(co_g, bt) * ceil_div(ci_g, bt) * groups;
@@ -748,17 +861,10 @@ static WgPlan wgrad_plan(int co_g, int ci_g, int groups, int k, int stride, int 
                           : (!p.small && p.tg >= 6) ? 2 : (concurrency_hint() < 1.f ? 2 : 3);
   const int resident = 256 * (env_res > 0 ? env_res : res_default);
   int splits = resident / (p.tiles * p.tap_groups);
-  const int min_chunks = 256 / p.tt > 1 ? 256 / p.tt : 1;
+  const int chunk_cols = p.rows_half > 0 ? 2 * p.rows_half * width : p.tt;
+  const int min_chunks = 256 / chunk_cols > 1 ? 256 / chunk_cols : 1;
   if (splits > p.chunks_total / min_chunks) splits = p.chunks_total / min_chunks;
   if (splits < 1) splits = 1;
-  // Round 6: a launch that leaves most of the chip without a workgroup (the batch-folded tail layers of the scale
-  // discriminators: ONE item of 144 .. 512 columns, 32 tiles x 3 tap groups = 96 workgroups walking 5 .. 16 chunks each
-  // at 9 - 27 TFLOP/s) is cut down to 2 chunks per slice until one workgroup per CU exists.  (PWG_WG_UNDERFILL=0: round 5.)
-  static const bool underfill = !(getenv("PWG_WG_UNDERFILL") && atoi(getenv("PWG_WG_UNDERFILL")) == 0);
-  if (underfill && env_res <= 0) {
-    const int wgs = p.tiles * p.tap_groups;
-    while (wgs * splits * 2 <= 256 && p.chunks_total / (splits * 2) >= 2) splits *= 2;
-  }
   p.splits = ceil_div(p.chunks_total, ceil_div(p.chunks_total, splits));
   return p;
 }
@@ -849,9 +955,9 @@ static int launch_wgrad_mode(WgArgs a, const WgPlan& p, float* dw_out, float* wo
   maybe_poison_lds(stream);
   {
     ProfScope prof(stream,
-                   prof_shape_name("conv1d_wgrad_kernel", "B%d Co%d Ci%d k%d s%d d%d g%d W%d cols%d splits%d tiles%d tg%d small%d win%d tt%d",
+                   prof_shape_name("conv1d_wgrad_kernel", "B%d Co%d Ci%d k%d s%d d%d g%d W%d cols%d splits%d tiles%d tg%d small%d win%d tt%d rows%d",
                                    a.batch, a.co_g * a.groups, a.ci_g * a.groups, a.k, a.stride, a.dil, a.groups, a.width,
-                                   a.n_cols, p.splits, p.tiles, p.tg, (int)p.small, (int)p.win, p.tt),
+                                   a.n_cols, p.splits, p.tiles, p.tg, (int)p.small, (int)p.win, p.tt, 2 * p.rows_half),
                    flops, bytes);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
   }
@@ -896,6 +1002,16 @@ static int launch_wgrad(WgArgs a, const WgPlan& p, float* dw_out, float* workspa
   WG_GO(false, 0);
 #undef WG_GO
 #undef WG_GO23
+}
+
+// MODE 4 only (row-aligned (k,1) chunks, TT = 64): kept apart so that the 64 x 64 tile gets no other TT = 64 instantiation
+template <int TG, bool SMALL>
+static int launch_wgrad_rows(WgArgs a, const WgPlan& p, float* dw_out, float* workspace, size_t ws_floats,
+                             hipStream_t stream, double flops, double bytes, const WnFinish* wn) {
+  const bool act = (a.slope_g != 1.f || a.slope_x != 1.f) && !(a.dbg & 8);
+  a.rows_half = p.rows_half;
+  if (act) return launch_wgrad_mode<TG, SMALL, 64, false, 4, true, 0>(a, p, dw_out, workspace, ws_floats, stream, flops, bytes, wn);
+  return launch_wgrad_mode<TG, SMALL, 64, false, 4, false, 0>(a, p, dw_out, workspace, ws_floats, stream, flops, bytes, wn);
 }
 
 }  // namespace pwg
@@ -1042,6 +1158,28 @@ static int backward_weight_impl(const pwg_conv1d_desc* d_in, const float* x, con
     case 128: return launch_wgrad<TGV, SM, 128>(a, p, dw, workspace, workspace_floats, stream, flops, bytes, wn); \
     case 64: return launch_wgrad<TGV, SM, 64>(a, p, dw, workspace, workspace_floats, stream, flops, bytes, wn);   \
     default: return launch_wgrad<TGV, SM, 32>(a, p, dw, workspace, workspace_floats, stream, flops, bytes, wn);   \
+  }
+  a.rows_half = 0;
+  if (p.rows_half > 0) {
+#define WG_ROWS(TGV, SM) return launch_wgrad_rows<TGV, SM>(a, p, dw, workspace, workspace_floats, stream, flops, bytes, wn)
+    if (p.small) {
+      switch (p.tg) {
+        case 1: WG_ROWS(1, true);
+        case 2: WG_ROWS(2, true);
+        case 3: WG_ROWS(3, true);
+        default: WG_ROWS(4, true);
+      }
+    }
+    switch (p.tg) {
+      case 1: WG_ROWS(1, false);
+      case 2: WG_ROWS(2, false);
+      case 3: WG_ROWS(3, false);
+      case 4: WG_ROWS(4, false);
+      case 5: WG_ROWS(5, false);
+      case 6: WG_ROWS(6, false);
+      default: WG_ROWS(7, false);
+    }
+#undef WG_ROWS
   }
   if (p.small) {
     switch (p.tg) {

@@ -386,6 +386,43 @@ __global__ void stretch_conv_fwd_kernel(const float* x, const float* w, float* y
     y[i] = apply_act(acc, act, slope);  // the optional nonlinearity after each stage (layers/upsample.py:105-110)
   }
 }
+// Round 6: the same sum for the recipes' geometry (no channel-axis taps, k = 2 s + 1, pad = s, s in {2, 4}, t_out % 4 == 0):
+// a thread owns 4 CONSECUTIVE outputs, loads the <= 4 input samples they touch once (the generic kernel issues one
+// load and one integer division per tap and stores 4 B per thread: 0.5 TB/s on a 21 MB write, profiles/r05_hbm_helpers.txt)
+// and stores 16 B.  Same products in the same tap order (bit-identical): a padded tap adds w * 0.
+template <int S>
+__global__ __launch_bounds__(256) void stretch_conv_fwd4_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                float* __restrict__ y, long rows, int t_in, int act,
+                                                                float slope) {
+  static_assert(4 % S == 0, "4 outputs per thread start on an input sample");
+  constexpr int K = 2 * S + 1, NQ = (3 + 2 * S) / S + 1;
+  const int t4 = t_in * S / 4;  // 16-B pieces per row
+  const long n = rows * t4;
+  float wr[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) wr[j] = w[j];
+  GRID_STRIDE(i, n) {
+    const long r = i / t4;
+    const int p = (int)(i - r * t4);
+    const int q0 = p * 4 / S - 1;  // input sample of u = t0 - S
+    const float* xr = x + r * t_in;
+    float xq[NQ];
+#pragma unroll
+    for (int m = 0; m < NQ; ++m) {
+      const int q = q0 + m;
+      xq[m] = (q >= 0 && q < t_in) ? xr[q] : 0.f;
+    }
+    float o4[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < K; ++j) acc += wr[j] * xq[(o + j) / S];
+      o4[o] = apply_act(acc, act, slope);
+    }
+    *reinterpret_cast<float4*>(y + i * 4) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+  }
+}
 __global__ void stretch_conv_bwd_data_kernel(const float* dy, const float* w, float* dx, long rows, int t_in, int s,
                                              int k, int pad, int channels, int fk) {
   const int t_out = t_in * s;
@@ -918,6 +955,14 @@ extern "C" int pwg_stretch_conv_forward(const float* x, const float* w, float* y
   const long n = rows * (long)t_in * scale;
   ProfScope prof((hipStream_t)stream, "stretch_conv_fwd_kernel", 2.0 * n * kernel * freq_kernel,
                  4.0 * (rows * (double)t_in + n));
+  static const bool fast4 = !(getenv("PWG_STRETCH_FAST") && atoi(getenv("PWG_STRETCH_FAST")) == 0);
+  if (fast4 && freq_kernel == 1 && kernel == 2 * scale + 1 && pad_left == scale && (scale == 2 || scale == 4) &&
+      ((long)t_in * scale) % 4 == 0 && (((uintptr_t)y) & 15) == 0) {
+    const long n4 = n / 4;
+    if (scale == 4) LAUNCH1D(stretch_conv_fwd4_kernel<4>, n4, stream, x, w, y, (long)rows, t_in, act, slope);
+    else LAUNCH1D(stretch_conv_fwd4_kernel<2>, n4, stream, x, w, y, (long)rows, t_in, act, slope);
+    return PWG_OK;
+  }
   LAUNCH1D(stretch_conv_fwd_kernel, n, stream, x, w, y, (long)rows, t_in, scale, kernel, pad_left, channels, freq_kernel,
            act, slope);
   return PWG_OK;

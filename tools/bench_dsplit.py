@@ -38,7 +38,23 @@ for t in (32, 17, 9):
                     (f"fold T{t} 1024->1024 k5", dict(c_in=1024, c_out=1024, t_in=t, t_out=t, k=5, stride=1, pad=2, width=16, batch=1)),
                     (f"fold T{t} 512->1024 k41 s4 g16", dict(c_in=512, c_out=1024, t_in=4 * t - 3 if t != 32 else 128, t_out=t, k=41, stride=4, pad=20, groups=16, width=16, batch=1)),
                     (f"fold T{t} 512->1024 k41 s4 g16 dgrad", dict(c_in=1024, c_out=512, t_in=t, t_out=4 * t - 3 if t != 32 else 128, k=41, stride=4, pad=20, groups=16, width=16, batch=1, transposed=True))]
-shapes = fold_shapes if FOLD else [("c4 k1 96->96 T2048 B64", dict(c_in=96, c_out=96, t_in=2048, t_out=2048, k=1, stride=1, pad=0, batch=64)),
+# round 6: the C3 categories furthest below 100 TFLOP/s that are not folded (profiles/r06_a_train_shapes_c3.txt)
+C3X = len(sys.argv) > 1 and sys.argv[1] == "c3x"
+c3x_shapes = [
+    ("msd L2 128->128 k41 s4 g4 T8192", dict(c_in=128, c_out=128, t_in=8192, t_out=2048, k=41, stride=4, pad=20, groups=4)),
+    ("msd L2 128->128 k41 s4 g4 T4097", dict(c_in=128, c_out=128, t_in=4097, t_out=1025, k=41, stride=4, pad=20, groups=4)),
+    ("msd L2 dgrad (convT 128->128 k41 s4 g4) T2048", dict(c_in=128, c_out=128, t_in=2048, t_out=8192, k=41, stride=4, pad=20, groups=4, transposed=True)),
+    ("mpd p5 L4 dgrad (convT 1024->512 k5 s3)", dict(c_in=1024, c_out=512, t_in=21, t_out=61, k=5, stride=3, pad=2, width=5, transposed=True)),
+    ("mpd p5 L3 dgrad (convT 512->128 k5 s3)", dict(c_in=512, c_out=128, t_in=61, t_out=183, k=5, stride=3, pad=2, width=5, transposed=True)),
+    ("mpd p5 L5 1024->1024 k5 s1", dict(c_in=1024, c_out=1024, t_in=21, t_out=21, k=5, stride=1, pad=2, width=5)),
+    ("mpd p11 L5 1024->1024 k5 s1", dict(c_in=1024, c_out=1024, t_in=10, t_out=10, k=5, stride=1, pad=2, width=11)),
+    ("G res 256 k3 T256", dict(c_in=256, c_out=256, t_in=256, t_out=256, k=3, stride=1, pad=1)),
+    ("G res 256 k7 T256", dict(c_in=256, c_out=256, t_in=256, t_out=256, k=7, stride=1, pad=3)),
+    ("G res 128 k3 T2048", dict(c_in=128, c_out=128, t_in=2048, t_out=2048, k=3, stride=1, pad=1)),
+    ("G convT 512->256 k16 s8 T32", dict(c_in=512, c_out=256, t_in=32, t_out=256, k=16, stride=8, pad=4, transposed=True)),
+    ("G convT 256->128 k16 s8 T256", dict(c_in=256, c_out=128, t_in=256, t_out=2048, k=16, stride=8, pad=4, transposed=True)),
+]
+shapes = fold_shapes if FOLD else c3x_shapes if C3X else [("c4 k1 96->96 T2048 B64", dict(c_in=96, c_out=96, t_in=2048, t_out=2048, k=1, stride=1, pad=0, batch=64)),
           ("c4 k1 48->48 T4096 B64", dict(c_in=48, c_out=48, t_in=4096, t_out=4096, k=1, stride=1, pad=0, batch=64)),
           ("c4 k1 192->192 T512 B64", dict(c_in=192, c_out=192, t_in=512, t_out=512, k=1, stride=1, pad=0, batch=64)),
           ("c4 k3 96->96 d3 T2048 B64", dict(c_in=96, c_out=96, t_in=2048, t_out=2048, k=3, stride=1, pad=3, batch=64, dil=3)),

@@ -78,6 +78,12 @@ with torch.no_grad():
         x = torch.randn(b, 1, t, device=dev)
         measure(f"Conv1d 1 -> {cout} k15  B{b} x {t} ({tag})", lambda conv=conv, x=x: conv(x), "conv1d_small_cin_kernel")
 
+    # ---- few-output-channel last layers of the generators (round 6: LDS-free stream; PWG_SMALL_COUT_STREAM=0 = the LDS kernel)
+    for b, t, cin, k, tag in ((16, 204800, 32, 7, "HiFi-GAN output layer, inference batch"), (16, 8192, 32, 7, "HiFi-GAN output layer, C3 batch"),
+                              (6, 25600, 64, 1, "PWG last layer, C2 batch")):
+        conv = Conv1d(cin, 1, k, padding=(k - 1) // 2).to(dev)
+        x = torch.randn(b, cin, t, device=dev)
+        measure(f"Conv1d {cin} -> 1 k{k}  B{b} x {t} ({tag})", lambda conv=conv, x=x: conv(x, pre_act="leaky_relu", pre_slope=0.01, post_act="tanh"))
 # ---- backward-side helpers (need autograd)
 ct = ConvTranspose1d(64, 32, 4, 2, padding=1).to(dev)
 x = torch.randn(16, 64, 4096, device=dev)
@@ -103,6 +109,11 @@ up = layers.UpsampleNetwork([4, 4, 4, 4]).to(dev)
 c = torch.randn(6, 80, 104, device=dev)
 with torch.no_grad():
     measure("PWG upsampling stage (stretch x 4 + k9), C2 batch", lambda: up(c), "stretch_conv_fwd_kernel")
+
+st = layers.UpsampleNetwork([4]).to(dev)  # ONE stage at the last stage's size (C2: 6 x 80 x 6400 -> 25600)
+c1 = torch.randn(6, 80, 6400, device=dev)
+with torch.no_grad():
+    measure("PWG upsampling, last stage alone (6 x 80 x 6400 -> 25600)", lambda: st(c1), "stretch_conv_fwd_kernel")
 
 print(f"{'kernel / shape':58s} {'MB':>8s} {'eager us':>9s} {'GB/s':>8s} {'frac':>6s} {'graph us':>9s} {'GB/s':>8s} {'frac':>6s}")
 for label, kernel, mb, us, gbs, gus, ggbs in rows:

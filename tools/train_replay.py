@@ -28,10 +28,11 @@ tr = Trainer(steps=1, epochs=0, data_loader={"train": [batch], "dev": [batch]}, 
 tr.tqdm = None
 import time  # noqa: E402
 
+timed = 6 if n < 20 else n - 10  # (long runs: everything after 10 warm-up / capture steps)
 for i in range(n):
-    if i == n - 6:
+    if i == n - timed:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
     tr._train_step(batch)
 torch.cuda.synchronize()
-print(f"{tag}: last 6 steps {(time.perf_counter() - t0) / 6 * 1e3:.2f} ms per step (graph: {bool(tr._graphs)})")
+print(f"{tag}: last {timed} steps {(time.perf_counter() - t0) / timed * 1e3:.2f} ms per step (graph: {bool(tr._graphs)})")
