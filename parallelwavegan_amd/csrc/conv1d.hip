@@ -863,9 +863,9 @@ constexpr int SI_MAXK = 16;
 // 8 tiles = 128 workgroups each walking 128 channels (round 4: 126 us = 0.5 TB/s; the write of y is the whole job).
 // VEC: every thread owns 4 CONSECUTIVE columns and stores them as one 16-B piece (t_out % 4 == 0, y 16-B aligned);
 // else the columns of a thread are 256 apart (4-B stores, each wave instruction one contiguous 256-B run).
-// NT: the output leaves through non-temporal stores (written once, read by a later launch: keeping 67 MB of it in the
-// L2s only evicts what the neighbours need) -- round 6 A/B: profiles/r06_hbm_helpers.txt.
-template <bool VEC, bool NT = false>
+// (round 6 A/B, profiles/r06_hbm_helpers.txt: non-temporal stores 28.7 -> 27.6 us at the C3 shape, 512 / 2048 / 256
+// workgroups per launch instead of 1024: 40 / 33 / 65 us -- neither kept)
+template <bool VEC>
 __global__ __launch_bounds__(256) void conv1d_small_cin_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                                const float* __restrict__ bias, float* __restrict__ y,
                                                                int cin_pad, int m_pad, int cout, int cg, int t_in, int t_out,
@@ -925,12 +925,7 @@ __global__ __launch_bounds__(256) void conv1d_small_cin_kernel(const float* __re
     }
     if (VEC) {
       const int t = t0 + col0;
-      if (t < t_out) {
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-        const f32x4 r4 = {r[0], r[1], r[2], r[3]};
-        if (NT) __builtin_nontemporal_store(r4, reinterpret_cast<f32x4*>(yb + (long)c * t_out + t));
-        else *reinterpret_cast<f32x4*>(yb + (long)c * t_out + t) = r4;
-      }
+      if (t < t_out) *reinterpret_cast<float4*>(yb + (long)c * t_out + t) = make_float4(r[0], r[1], r[2], r[3]);
     } else {
 #pragma unroll
       for (int o = 0; o < 4; ++o) {
@@ -1801,9 +1796,7 @@ extern "C" int pwg_conv1d_forward(const pwg_conv1d_desc* d_in, const float* x, c
     if (rc != PWG_OK) return rc;
     // channel groups: at least ~1024 workgroups per launch (4 per CU), never fewer than 8 channels per group
     const int pairs = ceil_div(d->t_out, SI_TILE) * d->batch;
-    static const int wgs_target = getenv("PWG_SMALL_CIN_WGS") ? atoi(getenv("PWG_SMALL_CIN_WGS")) : 1024;
-    static const bool nt_store = getenv("PWG_SMALL_CIN_NT") && atoi(getenv("PWG_SMALL_CIN_NT")) != 0;
-    int ngroups = ceil_div(wgs_target, pairs);
+    int ngroups = ceil_div(1024, pairs);
     if (ngroups > d->c_out / 8) ngroups = d->c_out / 8;
     if (ngroups < 1) ngroups = 1;
     const int cg = ceil_div(d->c_out, ngroups);
@@ -1814,11 +1807,7 @@ extern "C" int pwg_conv1d_forward(const pwg_conv1d_desc* d_in, const float* x, c
     const bool vec = d->t_out % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15u) == 0;
     ProfScope prof((hipStream_t)stream, "conv1d_small_cin_kernel", 2.0 * out_elems * d->kernel,
                    4.0 * ((double)d->batch * d->t_in + out_elems));
-    void (*sik)(const float*, const float*, const float*, float*, int, int, int, int, int, int, int, int, int, int, float, int,
-                float, float) = conv1d_small_cin_kernel<false, false>;
-    if (vec && nt_store) sik = conv1d_small_cin_kernel<true, true>;
-    else if (vec) sik = conv1d_small_cin_kernel<true, false>;
-    hipLaunchKernelGGL(sik,
+    hipLaunchKernelGGL(vec ? conv1d_small_cin_kernel<true> : conv1d_small_cin_kernel<false>,
                        dim3(ceil_div(d->t_out, SI_TILE), d->batch, ngroups), dim3(256), lds, (hipStream_t)stream, x, w_packed,
                        bias, y, g.cin_pad, g.m_pad, d->c_out, cg, d->t_in, d->t_out, d->kernel, d->dilation, d->pad_left,
                        d->pre_act, d->pre_slope, d->post_act, d->post_slope, d->out_mul);

@@ -38,6 +38,7 @@ struct WgArgs {
   long slab_stride; // floats between consecutive slabs (dW + fused bias row)
   float slope_g, slope_x;  // branch-free pre-activation slopes (1 = none)
   unsigned g_bytes, x_bytes;
+  int rows_x4;    // MODE 4: stage the X rows with 16-B DMAs (one instruction per row)
   int rows_half;  // MODE 4 (row-aligned (k,1) chunks): G rows per lane half of a chunk (a chunk = 2 * rows_half rows x width)
   int tap_major;  // slab layout: 1 = [tap][o][i] (coalesced partial-sum stores, the finishers permute), 0 = torch (o, i, tap)
   int dbg;  // timing experiments only (PWG_WG_DBG env): 1 = no DMA after the first chunk, 2 = no waits / barriers, 4 = no stores
@@ -203,6 +204,29 @@ __global__ __launch_bounds__(256, (TG > 7 ? 1 : 2)) void conv1d_wgrad_kernel(WgA
     const int h1 = ROWS ? h0 + 2 * a.rows_half - 1 : n_last / W;
     const int f0 = (h0 * a.stride + k0 * a.dil - a.pad) * W;
     const int L = ((h1 - h0) * a.stride + (ntaps_block - 1) * a.dil + 1) * W;
+    if (ROWS && a.rows_x4) {
+      // Row-aligned chunks stage 154 .. 196 floats per X row: 3 - 4 dword pieces (256 B each), i.e. 48 - 64 DMA
+      // instructions per wave and chunk next to 110 - 160 MFMAs -- issue-bound.  16-B pieces: ONE instruction per row
+      // (lane l carries floats [4 l, 4 l + 4) of the row's window; the window start is moved down to a multiple of 4
+      // so that no piece straddles the row's first sample; pieces wholly outside the row are out-of-range lanes that
+      // land as 0.0; the one piece that may straddle the row's END is repaired before the barrier, see fix_tail).
+      // A 4-byte-aligned LDS destination is legal for the 16-B form (tools/probes/glds_x3.hip), so the rows keep their
+      // odd stride.
+      const int sh = f0 & 3;  // (two's complement: also right for negative f0)
+      const int f0a = f0 - sh;
+      const int fl = f0a + 4 * lane;
+      const bool lane_ok = 4 * lane < L + sh && fl >= 0 && fl < a.x_len;
+      int rowoff = x_base + wave * a.x_len + fl;
+      if (4 * lane < L + sh) {  // (lanes past the window must not store: their 16 B would land in the next row)
+#pragma unroll 4
+        for (int r = wave; r < BT; r += 4) {
+          const unsigned off = (lane_ok && i0 + r < a.ci_g) ? (unsigned)rowoff * 4u : 0xFFFFFFF0u;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr_t)(xs + r * XS), 16, off, 0, 0, 0);
+          rowoff += 4 * a.x_len;
+        }
+      }
+      return;
+    }
     const int Lr = (L + 63) & ~63;  // whole DMA pieces (the row stride XS covers them)
     // (full chunks only: the last chunk of an item stages fewer columns than the MFMA loop walks, and the
     // predicated path below zero-fills the rest -- stale LDS there meets G = 0, and 0 * NaN is NaN)
@@ -393,12 +417,23 @@ __global__ __launch_bounds__(256, (TG > 7 ? 1 : 2)) void conv1d_wgrad_kernel(WgA
   };
   if (c_begin < c_end) issue(nb_b, nb_n0, smem);
   for (int c = c_begin; c < c_end; ++c) {
-    if (!(a.dbg & 2)) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
     const int par = (c - c_begin) & 1;
     float* buf = smem + par * buf_floats;
+    if (!(a.dbg & 2)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (ROWS && a.rows_x4 && (a.x_len & 3)) {
+        // fix_tail: the 16-B piece that straddles the end of an X row carries the first samples of the next row where
+        // the convolution's bottom padding (zeros) belongs; every wave overwrites them in the rows it staged itself
+        // (its own DMAs have landed: vmcnt(0)), the barrier below publishes the stores.
+        const int f0a = ((cb_n0 / W) * a.stride + k0 * a.dil - a.pad) * W & ~3;
+        const int es = a.x_len - f0a;  // first float past the row, relative to the window
+        const int rows_l = lane >> 2, q = lane & 3;
+        const int r = wave + 4 * rows_l;  // 16 rows per wave (BT = 64) / 8 (BT = 32)
+        if (es > 0 && es < a.xs_stride - 4 && (es & 3) && r < BT && q >= (es & 3))
+          (buf + BT * TT)[r * XS + (es & ~3) + q] = 0.f;
+      }
+      __syncthreads();
+    }
     if (c + 1 < c_end && !(a.dbg & 1)) {
       advance(nb_b, nb_n0);
       issue(nb_b, nb_n0, smem + (par ^ 1) * buf_floats);
@@ -408,10 +443,12 @@ __global__ __launch_bounds__(256, (TG > 7 ? 1 : 2)) void conv1d_wgrad_kernel(WgA
     const int n0 = cb_n0;
     advance(cb_b, cb_n0);
     const int h0 = n0 / W;
+    int x_shift = 0;
+    if (ROWS && a.rows_x4) x_shift = ((h0 * a.stride + k0 * a.dil - a.pad) * W) & 3;
     const int orow = wave_o * 32 + l31;
     const float* grow = gs + orow * 32;
     const int irow = wave_i * 32 + l31;
-    const float* xrow = xs + irow * (WIN ? 32 : XS) + (WIN ? t0 * (BT * TT) : t0 * a.dil * W);
+    const float* xrow = xs + irow * (WIN ? 32 : XS) + (WIN ? t0 * (BT * TT) : t0 * a.dil * W) + x_shift;
     if (ntaps > 0) {
       if constexpr (ROWS) mac_rows(gs, xrow, orow, irow);
       else mac_chunk(grow, xrow, n0, h0, orow, irow);
@@ -723,6 +760,7 @@ struct WgPlan {
   int chunks_per_item, chunks_total;
   int tap_groups, tiles, splits;
   int rows_half;  // > 0: MODE 4 (row-aligned chunks of 2 * rows_half rows), tt = 64
+  bool rows_x4;   // MODE 4: X rows staged with 16-B DMAs
 };
 
 static size_t wgrad_lds(bool small, bool win, int taps_block, int tt, int stride, int dil, int width, int k,
@@ -787,6 +825,10 @@ static WgPlan wgrad_plan(int co_g, int ci_g, int groups, int k, int stride, int 
       p.win = stride == 1 && width == 1 && (ntaps_max - 1) * dil > 96;  // taps far apart: per-tap windows
       // longest chunk whose double-buffered tiles keep two workgroups per CU (<= 80 KB), at most ~n_cols
       p.tt = 32;
+      // (round 6, measured and NOT kept: 64-column chunks for 1 x 1 convolutions on the 64 x 64 tile -- the MelGAN residual
+      // stacks' pointwise layers, 22 - 50 TFLOP/s -- so that an X row's 64-float DMA piece is used whole: 0.763 / 0.430 /
+      // 0.386 ms -> 0.846 / 0.534 / 0.488 ms for 96 / 48 / 192 channels at the C4 batch, gpurun_out/r06j: half as many
+      // slices to fill the chip with)
       for (int tt = p.small ? 128 : 32; tt >= 32; tt >>= 1) {
         int xs;
         if (tt > 32 && tt > n_cols) continue;
@@ -821,13 +863,18 @@ static WgPlan wgrad_plan(int co_g, int ci_g, int groups, int k, int stride, int 
   // split with the fewest wasted rows at the item's tail, larger chunks first.
   static const bool rows_on = !(getenv("PWG_WG_ROWS") && atoi(getenv("PWG_WG_ROWS")) == 0);
   p.rows_half = 0;
+  p.rows_x4 = false;
   if (rows_on && width > 1 && width <= 32 && !p.win && n_cols % width == 0) {
     const int h_out = n_cols / width;
     const int ntaps_max = k < p.taps_block ? k : p.taps_block;
     float best = -1.f;
+    static const bool rows_x4_on = !(getenv("PWG_WG_ROWS_X4") && atoi(getenv("PWG_WG_ROWS_X4")) == 0);
     for (int r = 32 / width; r >= 1; --r) {
       const int xs_len = ((2 * r - 1) * stride + (ntaps_max - 1) * dil + 1) * width;
-      const int xs = round_up(xs_len, 64) + 1;
+      // 16-B pieces (one DMA instruction per row, <= 64 lanes): the window starts up to 3 floats early and ends on a
+      // multiple of 4 -- an odd stride that covers it; dword pieces: whole 64-float pieces per row
+      const bool x4 = rows_x4_on && xs_len + 6 <= 256;
+      const int xs = x4 ? ((xs_len + 6) | 1) : round_up(xs_len, 64) + 1;
       const size_t lds = 2 * (size_t)(bt * 64 + bt * xs) * sizeof(float);
       if (lds > 160 * 1024) continue;
       const float useful = (float)h_out / (float)(ceil_div(h_out, 2 * r) * 2 * r);
@@ -836,6 +883,7 @@ static WgPlan wgrad_plan(int co_g, int ci_g, int groups, int k, int stride, int 
       if (score > best + 1e-6f) {
         best = score;
         p.rows_half = r;
+        p.rows_x4 = x4;
         p.xs_stride = xs;
         p.lds = lds;
       }
@@ -1010,6 +1058,7 @@ static int launch_wgrad_rows(WgArgs a, const WgPlan& p, float* dw_out, float* wo
                              hipStream_t stream, double flops, double bytes, const WnFinish* wn) {
   const bool act = (a.slope_g != 1.f || a.slope_x != 1.f) && !(a.dbg & 8);
   a.rows_half = p.rows_half;
+  a.rows_x4 = p.rows_x4 ? 1 : 0;
   if (act) return launch_wgrad_mode<TG, SMALL, 64, false, 4, true, 0>(a, p, dw_out, workspace, ws_floats, stream, flops, bytes, wn);
   return launch_wgrad_mode<TG, SMALL, 64, false, 4, false, 0>(a, p, dw_out, workspace, ws_floats, stream, flops, bytes, wn);
 }
@@ -1160,6 +1209,7 @@ static int backward_weight_impl(const pwg_conv1d_desc* d_in, const float* x, con
     default: return launch_wgrad<TGV, SM, 32>(a, p, dw, workspace, workspace_floats, stream, flops, bytes, wn);   \
   }
   a.rows_half = 0;
+  a.rows_x4 = 0;
   if (p.rows_half > 0) {
 #define WG_ROWS(TGV, SM) return launch_wgrad_rows<TGV, SM>(a, p, dw, workspace, workspace_floats, stream, flops, bytes, wn)
     if (p.small) {

@@ -417,7 +417,8 @@ __global__ __launch_bounds__(256) void stretch_conv_fwd4_kernel(const float* __r
     for (int o = 0; o < 4; ++o) {
       float acc = 0.f;
 #pragma unroll
-      for (int j = 0; j < K; ++j) acc += wr[j] * xq[(o + j) / S];
+      for (int j = 0; j < K; ++j) acc = __builtin_fmaf(wr[j], xq[(o + j) / S], acc);  // (explicit: the generic kernel's
+      // `acc += w * x` is one v_fmac; written the same way here hipcc shares the products between outputs as v_mul + v_add)
       o4[o] = apply_act(acc, act, slope);
     }
     *reinterpret_cast<float4*>(y + i * 4) = make_float4(o4[0], o4[1], o4[2], o4[3]);

@@ -237,15 +237,19 @@ def test_split_reduction_forward_backward(B, Cin, Cout, T, K, stride, pad, group
     _close(dx, x.grad + acc, "split backward_data")
 
 
-@pytest.mark.parametrize("cin,cout,t,k,dil,pre,post", [
-    (32, 1, 5000, 7, 1, "leaky_relu", "tanh"),   # HiFi-GAN / MelGAN output layer
-    (48, 4, 9000, 7, 2, "leaky_relu", None),     # multi-band output, dilated
-    (64, 1, 4100, 1, 1, "relu", None),           # Parallel WaveGAN's last 1x1
-    (16, 3, 4096, 15, 1, None, None),
+@pytest.mark.parametrize("cin,cout,t,k,dil,pre,post,kernel", [
+    (32, 1, 5000, 7, 1, "leaky_relu", "tanh", "conv1d_small_cout_stream_kernel"),   # HiFi-GAN / MelGAN output layer
+    (48, 4, 9000, 7, 2, "leaky_relu", None, "conv1d_small_cout_kernel"),     # multi-band output, dilated
+    (64, 1, 4100, 1, 1, "relu", None, "conv1d_small_cout_stream_kernel"),           # Parallel WaveGAN's last 1x1
+    (16, 3, 4096, 15, 1, None, None, "conv1d_small_cout_kernel"),
+    (32, 1, 4098, 7, 1, "leaky_relu", "tanh", "conv1d_small_cout_kernel"),  # rows not 16-B aligned: the LDS kernel
+    (24, 4, 4096, 3, 1, "leaky_relu", None, "conv1d_small_cout_stream_kernel"),  # 4 output channels, exactly 4 tiles
+    (8, 1, 6148, 5, 1, None, "tanh", "conv1d_small_cout_stream_kernel"),  # ragged last tile
 ])
-def test_small_cout_streaming_kernel(cin, cout, t, k, dil, pre, post, device):
-    """C -> <= 4 channels over a long sequence takes the streaming VALU kernel (conv1d_small_cout_kernel)
-    instead of a 1-row MFMA tile; values vs ATen CPU."""
+def test_small_cout_streaming_kernel(cin, cout, t, k, dil, pre, post, kernel, device):
+    """C -> <= 4 channels over a long sequence takes a streaming VALU kernel instead of a 1-row MFMA tile: the LDS-free
+    stream (round 6: dilation 1, "same" padding, 16-B aligned rows) or conv1d_small_cout_kernel; values vs ATen CPU
+    (the two kernels run the same fmaf chain in the same (ci, tap) order: tools/experiments/r6_i.sh compares them bit for bit)."""
     g = torch.Generator().manual_seed(cin + k)
     x = torch.randn(2, cin, t, generator=g)
     w = torch.randn(cout, cin, k, generator=g) / (cin * k) ** 0.5
@@ -260,7 +264,7 @@ def test_small_cout_streaming_kernel(cin, cout, t, k, dil, pre, post, device):
     wd = w.to(device)
     with ops.profile() as prof:
         y = ops.conv1d_forward(desc, x.to(device), ops.pack_weight(desc, wd), b.to(device))
-    assert "conv1d_small_cout_kernel" in prof.results
+    assert kernel in prof.results, sorted(prof.results)
     assert (y.cpu() - ref).abs().max().item() <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
