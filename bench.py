@@ -904,7 +904,7 @@ def main():
         name, r = max(prof.results.items(), key=lambda kv: kv[1]["ms"])
         achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
         traffic, traffic_src = None, None
-        for pmc_name in ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json"):
+        for pmc_name in ("r06_pmc_hbm_traffic.json", "r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json"):
             pmc_file = os.path.join(ROOT, "profiles", pmc_name)
             if os.path.exists(pmc_file) and args.batch == 16 and args.frames == 800:
                 # HBM bytes per launch of this kernel on THIS workload, from separate rocprofv3 --pmc passes

@@ -326,7 +326,7 @@ extern "C" int pwg_adam_step(const void* chunks, int32_t n_chunks, float lr, flo
   PWG_REQUIRE(chunks, PWG_ERR_NULL, "adam_step: NULL chunk table");
   PWG_REQUIRE(n_chunks > 0 && step >= 1, PWG_ERR_BAD_SHAPE, "adam_step: bad arguments");
   const double c1 = 1.0 - pow((double)beta1, step), c2 = 1.0 - pow((double)beta2, step);
-  ProfScope prof((hipStream_t)stream, "adam_multi_kernel", 0, 28.0 * 65536.0 * n_chunks);
+  ProfScope prof((hipStream_t)stream, "adam_multi_kernel", 0, 0);  // (bytes: 28 per element; the chunk lengths are only in the device table)
   hipLaunchKernelGGL(adam_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream,
                      (const OptChunk*)chunks, lr, beta1, beta2, eps, weight_decay, (float)c1, (float)sqrt(c2),
                      grad_scale);
@@ -375,7 +375,7 @@ extern "C" int pwg_clip_grad_norm(const void* chunks, int32_t n_chunks, float ma
 extern "C" int pwg_adam_step_dev(const void* chunks, int32_t n_chunks, const float* hyper, void* stream) {
   PWG_REQUIRE(chunks && hyper, PWG_ERR_NULL, "adam_step_dev: NULL pointer");
   PWG_REQUIRE(n_chunks > 0, PWG_ERR_BAD_SHAPE, "adam_step_dev: bad arguments");
-  ProfScope prof((hipStream_t)stream, "adam_multi_kernel", 0, 28.0 * 65536.0 * n_chunks);
+  ProfScope prof((hipStream_t)stream, "adam_multi_kernel", 0, 0);  // (bytes: 28 per element; the chunk lengths are only in the device table)
   hipLaunchKernelGGL(adam_multi_dev_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream,
                      (const OptChunk*)chunks, hyper);
   PWG_CHECK_LAUNCH("adam_step_dev");

@@ -101,12 +101,13 @@ class HiFiGANGenerator(torch.nn.Module):
                 c = run_branches_chained(
                     [(lambda join, j=j, c=c: self.blocks[i * nb + j](c, accum_join=join,
                                                                      out_div=float(nb) if j == nb - 1 else 1.0))
-                     for j in range(nb)], c.device)
+                     for j in range(nb)], c.device, inputs=c)
                 continue
             if fork and 2 <= nb <= 3:
                 # training: the MRF blocks as parallel branches; combined by one small kernel in the same order
                 # ((b0 + b1) + b2) / nb as the reference's running sum
-                outs = run_branches([(lambda j=j, c=c: self.blocks[i * nb + j](c)) for j in range(nb)], c.device, True)
+                outs = run_branches([(lambda j=j, c=c: self.blocks[i * nb + j](c)) for j in range(nb)], c.device, True,
+                                    inputs=c)
                 c = Fn.Add3DivFn.apply(outs[0], outs[1], outs[2] if nb == 3 else None, float(nb))
                 continue
             cs = None
@@ -266,7 +267,7 @@ class HiFiGANMultiPeriodDiscriminator(torch.nn.Module):
     branch_streams = False  # set True (e.g. by the trainer's hipGraph mode) to fork one stream per period
 
     def forward(self, x):
-        return run_branches([(lambda d=d: d(x)) for d in self.discriminators], x.device, self.branch_streams)
+        return run_branches([(lambda d=d: d(x)) for d in self.discriminators], x.device, self.branch_streams, inputs=x)
 
 
 class HiFiGANScaleDiscriminator(torch.nn.Module):
@@ -400,14 +401,13 @@ class HiFiGANMultiScaleDiscriminator(torch.nn.Module):
     branch_streams = False
 
     def forward(self, x):
-        xs = []
-        for _ in self.discriminators:  # the pooled inputs first (cheap, sequential) ...
-            xs.append(x)
-            x = self.pooling(x)
+        xs = [x]
+        for _ in range(len(self.discriminators) - 1):  # the pooled inputs first (cheap, sequential) ...
+            xs.append(self.pooling(xs[-1]))
         # ... then the scale discriminators as independent branches (the trailing pooling of the
         # reference's loop, whose result is never used, is dropped)
-        return run_branches([(lambda f=f, xi=xi: f(xi)) for f, xi in zip(self.discriminators, xs[: len(self.discriminators)])],
-                            xs[0].device, self.branch_streams)
+        return run_branches([(lambda f=f, xi=xi: f(xi)) for f, xi in zip(self.discriminators, xs)],
+                            xs[0].device, self.branch_streams, inputs=xs)
 
 
 class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
@@ -465,21 +465,19 @@ class HiFiGANMultiScaleMultiPeriodDiscriminator(torch.nn.Module):
     def forward(self, x, only=None):
         """``only``: optional list of sub-discriminator indices to evaluate (the other entries of the
         returned list are None)."""
-        xs = []
-        xi = x
-        for _ in self.msd.discriminators:
-            xs.append(xi)
-            xi = self.msd.pooling(xi)
+        xs = [x]
+        for _ in range(len(self.msd.discriminators) - 1):  # (no pooling after the last scale: its result is unused)
+            xs.append(self.msd.pooling(xs[-1]))
         if only is not None:
             subs = list(zip(self.msd.discriminators, xs)) + [(d, x) for d in self.mpd.discriminators]
             outs = [None] * len(subs)
             res = run_branches([(lambda f=subs[i][0], v=subs[i][1]: f(v)) for i in only], x.device,
-                               self.msd.branch_streams and len(only) > 1)
+                               self.msd.branch_streams and len(only) > 1, inputs=xs)
             for i, r in zip(only, res):
                 outs[i] = r
             return outs
         if self.msd.branch_streams:  # one fork over all 3 + 5 sub-discriminators
             fns = [(lambda f=f, v=v: f(v)) for f, v in zip(self.msd.discriminators, xs)]
             fns += [(lambda d=d: d(x)) for d in self.mpd.discriminators]
-            return run_branches(fns, x.device, True)
+            return run_branches(fns, x.device, True, inputs=xs)
         return self.msd(x) + self.mpd(x)

@@ -234,7 +234,8 @@ class MelGANMultiScaleDiscriminator(torch.nn.Module, _MelGANNormMixin):
                 xs.append(x)
                 if i + 1 < len(self.discriminators):
                     x = self.pooling(x)
-            return run_branches([(lambda f=f, xi=xi: f(xi)) for f, xi in zip(self.discriminators, xs)], xs[0].device, True)
+            return run_branches([(lambda f=f, xi=xi: f(xi)) for f, xi in zip(self.discriminators, xs)], xs[0].device, True,
+                                inputs=xs)
         outs = []
         for i, f in enumerate(self.discriminators):
             outs.append(f(x))

@@ -13,21 +13,27 @@ _POOL = {}
 
 # At most this many side streams: more branches than that share streams round-robin (branches on one stream run in
 # program order).  The device exposes 4 hardware queues to a process by default; measured on the HiFi-GAN V1 step
-# (tools/experiments/exp_queues.sh, profiles/r04_queues_and_streams.txt): 8 or 16 queues make the captured step 35 % SLOWER (the
+# (profiles/r04_queues_and_streams.txt): 8 or 16 queues make the captured step 35 % SLOWER (the
 # concurrent MFMA kernels evict each other's tiles), one stream is 22 % slower than the default.
 MAX_SIDE_STREAMS = int(os.environ.get("PWG_MAX_SIDE_STREAMS", "8"))
 
 
 # Fork only while the stream is being captured into a hipGraph (default), or also in eager execution
 # (PWG_EAGER_BRANCH_STREAMS=1).  Inside a capture the side streams are bookkeeping: they become dependency edges of
-# the graph and the replay involves no stream scheduling at all.  Eagerly, the same fork runs 8 HIP streams over the
-# device's hardware queues -- and round 5's strict graph == eager test caught that mode producing, about once in four
-# fresh processes under NaN-poisoned allocations, a whole feature map of a HiFi-GAN scale discriminator that a LATER
-# consumer on the joined stream read as NaN although the next layer on the producing stream had read finite values
-# (tools/experiments/debug_graphmode_eager_nan2.py, profiles/r05_eager_branch_streams_nan.txt).  Every cross-stream hand-over in
-# this file is event-ordered and record_stream'ed, the captured form of the same program replays bit-identically, and
-# the eager fork bought nothing a warm-up step needs; so eager steps (graph warm-up, the data-parallel fallback) run
-# their branches one after the other on the caller's stream.
+# the graph and the replay involves no stream scheduling at all; the eager fork bought nothing a warm-up step needs,
+# so eager steps (graph warm-up, the data-parallel fallback) run their branches one after the other on the caller's
+# stream.
+#
+# Round 5 found the eager fork producing NaN about once in four fresh processes under NaN-poisoned allocations; round 6
+# bisected it (profiles/r06_eager_nan_bisect.txt) to a missing ``record_stream`` on the branch INPUTS: a tensor
+# allocated on the caller's stream and read on a side stream -- in the forward and again, as a saved tensor, by the
+# branch's backward nodes, which autograd replays on the side stream -- went back to the caller's stream's pool the
+# moment its last reference died, while the side stream's reader was still queued.  The pooled input of HiFi-GAN's
+# second scale discriminator (16 x 4097 floats) was then handed to the equally-sized gradient of the pooling's
+# backward on the caller's stream, whose (poison) fill overtook the first layer's weight-gradient kernel.  The outputs
+# of a branch were always recorded; now the inputs are too (``inputs=`` below), which also pins them until the end of a
+# capture (the caching allocator defers the reuse of a block with recorded streams to the end of the capture), so the
+# captured graph cannot contain that write-after-read pair without an edge either.
 EAGER_FORK = os.environ.get("PWG_EAGER_BRANCH_STREAMS", "0") == "1"
 
 
@@ -59,8 +65,10 @@ def _record(obj, stream):
             _record(o, stream)
 
 
-def run_branches(branches, device, enabled=True):
-    """branches: list of zero-argument callables -> list of their results."""
+def run_branches(branches, device, enabled=True, inputs=None):
+    """branches: list of zero-argument callables -> list of their results.  ``inputs``: the tensors (nested lists /
+    tuples allowed) that the branches read but did not allocate -- they are recorded on every side stream so that the
+    caching allocator does not hand their memory out while a side stream still reads it (forward or backward)."""
     if not enabled or len(branches) < 2 or device.type != "cuda" or not fork_now():
         return [fn() for fn in branches]
     cur = torch.cuda.current_stream(device)
@@ -74,12 +82,13 @@ def run_branches(branches, device, enabled=True):
             outs.append(fn())
     for s in dict.fromkeys(side):
         cur.wait_stream(s)
+        _record(inputs, s)  # allocated on the caller's stream (or further up), read on the side stream
     for o in outs:
         _record(o, cur)  # produced on a side stream, consumed on the caller's stream
     return outs
 
 
-def run_branches_chained(branches, device):
+def run_branches_chained(branches, device, inputs=None):
     """Like :func:`run_branches`, for branches whose results are summed in order (``cs += block(c)``): branch j is
     called as ``fn(join)`` where ``join()`` -- to be called right before the branch's LAST kernel -- makes the
     branch's stream wait for branch j-1 and returns that branch's result (None for j = 0), so the running sum
@@ -113,5 +122,6 @@ def run_branches_chained(branches, device):
             prev = (done, out)
     for s in dict.fromkeys(side):
         cur.wait_stream(s)
+        _record(inputs, s)  # (see run_branches)
     _record(prev[1], cur)
     return prev[1]

@@ -93,6 +93,40 @@ def test_branches_fork_onto_side_streams_only_inside_a_capture(device):
     assert [o[0].item() for o in outs] == [0.0, 2.0, 4.0]
 
 
+def test_branch_inputs_are_recorded_on_the_side_streams(device, monkeypatch):
+    """Round 6 root cause of the eager multi-stream NaN (profiles/r06_eager_nan_bisect.txt): a branch INPUT allocated on
+    the caller's stream and read on a side stream must be ``record_stream``'ed there, or the caching allocator hands
+    its memory to the caller's next allocation of that size while the side stream's reader is still queued.  Here the
+    side streams are kept busy (``torch.cuda._sleep``), the input is dropped, and the next allocation of the same
+    size on the caller's stream must NOT receive the input's block; without ``inputs=`` it does (the control)."""
+    from parallelwavegan_amd import streams
+
+    monkeypatch.setattr(streams, "EAGER_FORK", True)
+    n = 16 * 4097  # (the pooled input of HiFi-GAN's second scale discriminator)
+
+    def attempt(declare_inputs):
+        torch.cuda.synchronize()
+        x = torch.ones(n, device=device)
+        ptr = x.data_ptr()
+
+        def branch():
+            torch.cuda._sleep(200_000_000)  # ~0.1 s: the reader below stays queued behind it
+            return x * 2.0
+
+        outs = streams.run_branches([branch, branch], device, True, inputs=x if declare_inputs else None)
+        del x, branch
+        # a different stream than the joined caller's stream would not even wait for the readers; the allocator hands a
+        # block of a stream's pool only to that stream, so ask on the caller's stream
+        y = torch.empty(n, device=device)
+        reused = y.data_ptr() == ptr
+        torch.cuda.synchronize()
+        assert all(bool((o == 2.0).all()) for o in outs)
+        return reused
+
+    assert attempt(False), "control: without inputs= the block goes straight back to the caller's pool"
+    assert not attempt(True), "a recorded input's block must stay out of the pool while a side stream may read it"
+
+
 def test_model_built_under_inference_mode_and_frozen_flag(device):
     """ADVICE r05: parameters created under ``torch.inference_mode()`` track no version counter (reading it raises);
     such a model must still be callable, and ``frozen=True`` skips the per-call walk over the tensors."""
