@@ -85,6 +85,13 @@ size_t gconv_wgrad_workspace_floats(const pwg_conv1d_desc* d);
 int gconv_backward_weight(const pwg_conv1d_desc* d, const float* x, const float* dy, float* dw, float* db, float* workspace,
                           size_t ws_floats, hipStream_t stream);
 
+// wgrad_k1.hip: weight gradient of 1 x 1 convolutions with <= 96 channels and a long reduction (`d` flattened, forward
+// descriptor); one tap-major slab (+ bias row when `write_bias`) per workgroup, `slab_stride` floats apart
+bool k1_wgrad_applicable(const pwg_conv1d_desc* d);
+int k1_wgrad_slabs(const pwg_conv1d_desc* d);
+int k1_wgrad_launch(const pwg_conv1d_desc* d, const float* x, const float* dy, float* slabs, long slab_stride, int nslabs,
+                    float slope_x, bool write_bias, hipStream_t stream);
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 

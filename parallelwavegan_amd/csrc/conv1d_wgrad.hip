@@ -702,7 +702,7 @@ __global__ __launch_bounds__(256) void conv1d_small_cin_wgrad_kernel(const float
                                                                      float* __restrict__ slabs, long slab_stride, int cout,
                                                                      int t_in, int t_out, int k, int dil, int pad,
                                                                      int chunks_per_item, float slope_x, int write_bias) {
-  extern __shared__ float xs[];  // [SIW_TILE + halo]
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [SIW_TILE + halo (+ 4: see the dilation-1 loop)]
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int t0 = chunk * SIW_TILE;
   const int L = SIW_TILE + (k - 1) * dil;
@@ -717,6 +717,78 @@ __global__ __launch_bounds__(256) void conv1d_small_cin_wgrad_kernel(const float
   const int n = min(SIW_TILE, t_out - t0);
   float* slab = slabs + ((long)b * chunks_per_item + chunk) * slab_stride;
   const int co_end = min(cout, ((int)blockIdx.z + 1) * SIW_CO_PER_WG);
+  if (dil == 1) {
+    // Round 6 (0.2 of the streaming rate before, profiles/r06_wgrad_k1.txt): a lane owns 4 consecutive columns per round
+    // (one 16-B load of dy per channel), holds their k + 3 window samples in registers (five 16-B LDS reads instead of
+    // 4 * k dword reads) and feeds TWO output channels from them.
+    for (int co = blockIdx.z * SIW_CO_PER_WG + wave; co < co_end; co += 8) {
+      const bool two = co + 4 < co_end;
+      const float* g0 = dy + ((long)b * cout + co) * t_out + t0;
+      const float* g1 = g0 + (two ? 4 * (long)t_out : 0);
+      float acc0[SIW_MAXK], acc1[SIW_MAXK], accb0 = 0.f, accb1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < SIW_MAXK; ++j) acc0[j] = acc1[j] = 0.f;
+      for (int t = 4 * lane; t < n; t += 256) {
+        float v0[4], v1[4];
+        if (t + 4 <= n) {
+          float4 a, c;
+          __builtin_memcpy(&a, g0 + t, 16);  // (rows of dy are only 4-B aligned: t_out is arbitrary)
+          __builtin_memcpy(&c, g1 + t, 16);
+          v0[0] = a.x, v0[1] = a.y, v0[2] = a.z, v0[3] = a.w;
+          v1[0] = c.x, v1[1] = c.y, v1[2] = c.z, v1[3] = c.w;
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            v0[u] = t + u < n ? g0[t + u] : 0.f;
+            v1[u] = t + u < n ? g1[t + u] : 0.f;
+          }
+        }
+        // window samples t .. t + k + 2, fetched four at a time (the launcher allocates 4 floats past the staged tile:
+        // the last fetch of the last lane may run up to 3 floats over, into entries no tap uses)
+        float xw[SIW_MAXK + 4];
+#pragma unroll
+        for (int q = 0; q < (SIW_MAXK + 4) / 4; ++q) {
+          float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (4 * q < k + 3) w = *reinterpret_cast<const float4*>(xs + t + 4 * q);
+          xw[4 * q + 0] = w.x, xw[4 * q + 1] = w.y, xw[4 * q + 2] = w.z, xw[4 * q + 3] = w.w;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          accb0 += v0[u];
+          accb1 += v1[u];
+#pragma unroll
+          for (int j = 0; j < SIW_MAXK; ++j)
+            if (j < k) {
+              acc0[j] = __builtin_fmaf(v0[u], xw[u + j], acc0[j]);
+              acc1[j] = __builtin_fmaf(v1[u], xw[u + j], acc1[j]);
+            }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < SIW_MAXK; ++j)
+        for (int o = 32; o > 0; o >>= 1) {
+          acc0[j] += __shfl_down(acc0[j], o, 64);
+          acc1[j] += __shfl_down(acc1[j], o, 64);
+        }
+      for (int o = 32; o > 0; o >>= 1) {
+        accb0 += __shfl_down(accb0, o, 64);
+        accb1 += __shfl_down(accb1, o, 64);
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < SIW_MAXK; ++j)
+          if (j < k) {
+            slab[(long)j * cout + co] = acc0[j];
+            if (two) slab[(long)j * cout + co + 4] = acc1[j];
+          }
+        if (write_bias) {
+          slab[(long)k * cout + co] = accb0;
+          if (two) slab[(long)k * cout + co + 4] = accb1;
+        }
+      }
+    }
+    return;
+  }
   for (int co = blockIdx.z * SIW_CO_PER_WG + wave; co < co_end; co += 4) {
     const float* g = dy + ((long)b * cout + co) * t_out + t0;
     float acc[SIW_MAXK], accb = 0.f;
@@ -745,181 +817,6 @@ __global__ __launch_bounds__(256) void conv1d_small_cin_wgrad_kernel(const float
       for (int j = 0; j < SIW_MAXK; ++j)
         if (j < k) slab[(long)j * cout + co] = acc[j];
       if (write_bias) slab[(long)k * cout + co] = accb;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// Weight gradient of 1 x 1 convolutions with few channels (MelGAN's residual stacks: C = 48 / 96 per stack, two per
-// stack and step): dW[o][i] = sum_{b,n} G[b][o][n] * act(X[b][i][n]).  24 flop per byte at C = 96, 12 at C = 48 -- at
-// or below the ridge, so the bound is the ONE read of G and X.  On the general kernel above these layers ran at 0.9 -
-// 1.5 TB/s (round 6, profiles/r06_wgrad_k1.txt): its 64 x 64 tile reads every operand row twice at C = 96 and pads 48
-// to 64, and its rotation-swizzled tiles are staged by dword LDS-DMA pieces (32 DMA instructions per wave next to 32
-// MFMAs per chunk).  Here one workgroup owns the WHOLE (padded) Co x Ci output: a chunk = 64 reduction columns of all
-// Co + Ci rows, fetched with 16-B global loads into registers one chunk ahead (rows are contiguous along n), the
-// activation applied and the bias row sums taken on the way, written to LDS with ds_write_b128 (row stride 68 floats:
-// 16-B aligned, ds_read_b64 operand reads 2-way conflicted -- there are 2 * NB of them per 2 * NB^2 MFMAs); the four waves
-// split the chunk's columns (16 each) and run all NB x NB accumulator blocks, so nothing is read twice.  A lane's b64
-// read at column c + 2 * (lane / 32) feeds two MFMAs (reduction pairs {c, c + 2} and {c + 1, c + 3}; A and B use the
-// same pairing).  At the end the four waves' partial blocks are added in wave order through the LDS and written as one
-// tap-major slab (+ bias row) per workgroup; the usual finishers sum the slabs in order (deterministic, no atomics).
-// ---------------------------------------------------------------------------
-constexpr int K1_KC = 64;       // reduction columns per chunk
-constexpr int K1_S = K1_KC + 4;  // LDS row stride (floats)
-struct K1Args {
-  const float* g;  // (B, co, n_cols)
-  const float* x;  // (B, ci, n_cols)
-  float* slabs;
-  long slab_stride, slab_elems;
-  int co, ci, n_cols, batch;
-  int chunks_per_item, chunks_total, chunks_per_block;
-  float slope_x;
-  int write_bias;
-  int vec_ok;  // both tensors 16-B aligned (n_cols % 4 == 0 is a condition of the path)
-};
-
-template <int NB>
-__global__ __launch_bounds__(256, 2) void wgrad_k1_kernel(K1Args a) {
-  constexpr int ROWS = 32 * NB;            // padded rows of each operand tile
-  constexpr int R4 = K1_KC / 4;            // 16-B pieces per row and chunk
-  constexpr int RPJ = 256 / R4;            // rows covered by one round of the 256 threads
-  constexpr int NJ = 2 * ROWS / RPJ;       // rounds (float4 per thread and chunk)
-  constexpr int KW = K1_KC / 4;            // reduction columns per wave and chunk
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* gs = smem;
-  float* xs = smem + ROWS * K1_S;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, lhi = lane >> 5;
-  const int c4 = tid % R4, r0 = tid / R4;
-
-  for (int i = tid; i < 2 * ROWS * K1_S; i += 256) smem[i] = 0.f;  // (padding rows stay zero)
-
-  // round j of this thread: operand row r0 + j * RPJ of the stacked (G rows, then X rows) tile
-  const int c_begin = blockIdx.x * a.chunks_per_block;
-  const int c_end = min(c_begin + a.chunks_per_block, a.chunks_total);
-  float4 pre[NJ];
-  float bsum[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) bsum[j] = 0.f;
-
-  auto fetch = [&](int b, int n0) {
-    const int n = n0 + 4 * c4;
-    const bool col_ok = n < a.n_cols;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int row = r0 + j * RPJ;
-      const bool is_g = row < a.co;
-      const int xr = row - a.co;
-      const bool ok = col_ok && (is_g || xr < a.ci);
-      const float* src = is_g ? a.g + ((long)b * a.co + row) * a.n_cols + n : a.x + ((long)b * a.ci + xr) * a.n_cols + n;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) {
-        if (a.vec_ok) v = *reinterpret_cast<const float4*>(src);
-        else v = make_float4(src[0], src[1], src[2], src[3]);
-      }
-      pre[j] = v;
-    }
-  };
-  auto stash = [&]() {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int row = r0 + j * RPJ;
-      float4 v = pre[j];
-      if (row < a.co) {
-        bsum[j] += (v.x + v.y) + (v.z + v.w);
-        *reinterpret_cast<float4*>(gs + row * K1_S + 4 * c4) = v;
-      } else if (row - a.co < a.ci) {
-        v.x = __builtin_fmaxf(v.x, v.x * a.slope_x);
-        v.y = __builtin_fmaxf(v.y, v.y * a.slope_x);
-        v.z = __builtin_fmaxf(v.z, v.z * a.slope_x);
-        v.w = __builtin_fmaxf(v.w, v.w * a.slope_x);
-        *reinterpret_cast<float4*>(xs + (row - a.co) * K1_S + 4 * c4) = v;
-      }
-    }
-  };
-
-  f32x16 acc[NB][NB];
-#pragma unroll
-  for (int p = 0; p < NB; ++p)
-#pragma unroll
-    for (int q = 0; q < NB; ++q)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[p][q][r] = 0.f;
-
-  int b = c_begin / a.chunks_per_item;
-  int n0 = (c_begin - b * a.chunks_per_item) * K1_KC;
-  if (c_begin < c_end) fetch(b, n0);
-  const float* ga = gs + l31 * K1_S + wave * KW + 2 * lhi;
-  const float* xa = xs + l31 * K1_S + wave * KW + 2 * lhi;
-  for (int c = c_begin; c < c_end; ++c) {
-    __syncthreads();  // the previous chunk's operand reads (and the zero fill) are done
-    stash();
-    __syncthreads();
-    if (c + 1 < c_end) {
-      n0 += K1_KC;
-      if (n0 >= a.chunks_per_item * K1_KC) {
-        n0 = 0;
-        ++b;
-      }
-      fetch(b, n0);
-    }
-#pragma unroll
-    for (int kk = 0; kk < KW; kk += 4) {
-      float2 av[NB], bv[NB];
-#pragma unroll
-      for (int p = 0; p < NB; ++p) av[p] = *reinterpret_cast<const float2*>(ga + p * 32 * K1_S + kk);
-#pragma unroll
-      for (int q = 0; q < NB; ++q) bv[q] = *reinterpret_cast<const float2*>(xa + q * 32 * K1_S + kk);
-#pragma unroll
-      for (int p = 0; p < NB; ++p)
-#pragma unroll
-        for (int q = 0; q < NB; ++q) {
-          acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p].x, bv[q].x, acc[p][q], 0, 0, 0);
-          acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p].y, bv[q].y, acc[p][q], 0, 0, 0);
-        }
-    }
-  }
-
-  // ---- bias row: the R4 consecutive lanes of a row add their partial sums (fixed shuffle tree)
-  float* slab = a.slabs + (long)blockIdx.x * a.slab_stride;
-  if (a.write_bias) {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      float s = bsum[j];
-#pragma unroll
-      for (int o = R4 / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-      const int row = r0 + j * RPJ;
-      if (c4 == 0 && row < a.co) slab[a.slab_elems + row] = s;
-    }
-  }
-  // ---- the four waves' partial blocks, added in wave order through the LDS (one block row of NB blocks at a time:
-  // 3 waves x NB x 1024 floats fit the operand tiles), then stored by wave 0: D layout col = lane & 31 (-> i),
-  // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (-> o)
-  static_assert(3 * NB * 1024 <= 2 * ROWS * K1_S, "reduction scratch must fit the operand tiles");
-#pragma unroll
-  for (int p = 0; p < NB; ++p) {
-    __syncthreads();
-    if (wave > 0) {
-#pragma unroll
-      for (int q = 0; q < NB; ++q)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) smem[((wave - 1) * NB + q) * 1024 + r * 64 + lane] = acc[p][q][r];
-    }
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-      for (int q = 0; q < NB; ++q) {
-        const int i = q * 32 + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = acc[p][q][r];
-#pragma unroll
-          for (int w = 0; w < 3; ++w) v += smem[(w * NB + q) * 1024 + r * 64 + lane];
-          const int o = p * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          if (o < a.co && i < a.ci) slab[(long)o * a.ci + i] = v;
-        }
-      }
     }
   }
 }
@@ -1247,31 +1144,9 @@ static bool small_cin_wgrad_applicable(const pwg_conv1d_desc* d) {
   static const bool on = !(getenv("PWG_SMALL_CIN") && atoi(getenv("PWG_SMALL_CIN")) == 0);
   return on && !d->transposed && d->groups == 1 && d->c_in == 1 && d->width == 1 && d->stride == 1 &&
          d->pad_mode == PWG_PAD_ZERO && d->kernel <= SIW_MAXK && d->c_out >= 8 && d->c_out <= 1024 && d->t_out >= 2048 &&
-         (size_t)(SIW_TILE + (d->kernel - 1) * d->dilation) * sizeof(float) <= 64 * 1024;
+         (size_t)(SIW_TILE + (d->kernel - 1) * d->dilation + 4) * sizeof(float) <= 64 * 1024;
 }
 static long small_cin_wgrad_slabs(const pwg_conv1d_desc* d) { return (long)d->batch * ceil_div(d->t_out, SIW_TILE); }
-
-// 1 x 1 convolutions with <= 96 channels on either side and a long reduction (wgrad_k1_kernel): `d` flattened;
-// PWG_WG_K1=0 disables the path (A/B against the general kernel)
-static bool k1_wgrad_applicable(const pwg_conv1d_desc* d) {
-  static const bool on = !(getenv("PWG_WG_K1") && atoi(getenv("PWG_WG_K1")) == 0);
-  return on && !d->transposed && d->groups == 1 && d->kernel == 1 && d->stride == 1 && d->width == 1 && d->pad_left == 0 &&
-         d->t_in == d->t_out && d->pad_mode == PWG_PAD_ZERO && d->c_in >= 8 && d->c_out >= 8 && d->c_in <= 96 &&
-         d->c_out <= 96 && (d->t_out & 3) == 0 && (long)d->batch * d->t_out >= 32768;
-}
-// One slab per workgroup: two workgroups per CU, fewer when the slabs (written once, read once by the finisher) would
-// exceed about a tenth of the operand bytes.
-static int k1_wgrad_slabs(const pwg_conv1d_desc* d) {
-  const int chunks = d->batch * ceil_div(d->t_out, K1_KC);
-  const double in_bytes = 4.0 * d->batch * (double)d->t_out * (d->c_in + d->c_out);
-  const double slab_bytes = 4.0 * ((double)d->c_out * d->c_in + d->c_out);
-  int wgs = (int)(0.05 * in_bytes / slab_bytes);
-  if (wgs > 512) wgs = 512;
-  if (wgs < 128) wgs = 128;
-  if (wgs > chunks) wgs = chunks;
-  const int per = ceil_div(chunks, wgs);
-  return ceil_div(chunks, per);
-}
 
 static void wgrad_roles(const pwg_conv1d_desc* d, int* co_g, int* ci_g, int* n_cols) {
   if (!d->transposed) {
@@ -1353,7 +1228,7 @@ static int backward_weight_impl(const pwg_conv1d_desc* d_in, const float* x, con
       ProfScope prof(stream, "conv1d_small_cin_wgrad_kernel", 2.0 * y_elems * d->kernel, 4.0 * ((double)x_elems + (double)y_elems));
       hipLaunchKernelGGL(conv1d_small_cin_wgrad_kernel,
                          dim3(ceil_div(d->t_out, SIW_TILE), d->batch, ceil_div(d->c_out, SIW_CO_PER_WG)), dim3(256),
-                         (size_t)(SIW_TILE + (d->kernel - 1) * d->dilation) * sizeof(float), stream, x, dy, workspace,
+                         (size_t)(SIW_TILE + (d->kernel - 1) * d->dilation + 4) * sizeof(float), stream, x, dy, workspace,
                          slab_stride, d->c_out, d->t_in, d->t_out, d->kernel, d->dilation, d->pad_left,
                          ceil_div(d->t_out, SIW_TILE), slope, db ? 1 : 0);
       PWG_CHECK_LAUNCH("conv1d_small_cin_wgrad");
@@ -1361,40 +1236,15 @@ static int backward_weight_impl(const pwg_conv1d_desc* d_in, const float* x, con
     return finish_wgrad_slabs(workspace, (int)nslabs, slab_elems, slab_stride, d->c_out, 1, d->kernel, dw, db, wn, stream);
   }
   if (k1_wgrad_applicable(d)) {
-    K1Args k;
-    k.g = dy;
-    k.x = x;
-    k.slabs = workspace;
-    k.slab_elems = (long)d->c_out * d->c_in;
-    k.slab_stride = k.slab_elems + (db ? d->c_out : 0);
-    k.co = d->c_out;
-    k.ci = d->c_in;
-    k.n_cols = d->t_out;
-    k.batch = d->batch;
-    k.chunks_per_item = ceil_div(d->t_out, K1_KC);
-    k.chunks_total = d->batch * k.chunks_per_item;
+    // 1 x 1 layers with few channels: HBM-bound kernel of wgrad_k1.hip, one slab per workgroup
     const int nslabs = k1_wgrad_slabs(d);
-    k.chunks_per_block = ceil_div(k.chunks_total, nslabs);
-    k.slope_x = slope;
-    k.write_bias = db ? 1 : 0;
-    k.vec_ok = ((((unsigned long long)x) | ((unsigned long long)dy)) & 15ull) == 0;
-    const size_t need = (size_t)(nslabs + (wn ? 1 : 0)) * k.slab_stride;
+    const long slab_elems = (long)d->c_out * d->c_in, slab_stride = slab_elems + (db ? d->c_out : 0);
+    const size_t need = (size_t)(nslabs + (wn ? 1 : 0)) * slab_stride;
     PWG_REQUIRE(workspace && workspace_floats >= need, PWG_ERR_WORKSPACE,
                 "conv1d_backward_weight: workspace of %zu floats needed, %zu given", need, workspace_floats);
-    PWG_REQUIRE(nslabs >= 2, PWG_ERR_UNSUPPORTED, "conv1d_backward_weight: 1 x 1 path with a single slab");
-    const int nb = ceil_div(d->c_in > d->c_out ? d->c_in : d->c_out, 32);
-    const size_t lds = (size_t)2 * 32 * nb * K1_S * sizeof(float);
-    maybe_poison_lds(stream);
-    {
-      ProfScope prof(stream, prof_shape_name("wgrad_k1_kernel", "B%d Co%d Ci%d cols%d slabs%d", d->batch, d->c_out, d->c_in,
-                                             d->t_out, nslabs),
-                     2.0 * y_elems * d->c_in, 4.0 * ((double)x_elems + (double)y_elems));
-      if (nb == 1) hipLaunchKernelGGL(wgrad_k1_kernel<1>, dim3(nslabs), dim3(256), lds, stream, k);
-      else if (nb == 2) hipLaunchKernelGGL(wgrad_k1_kernel<2>, dim3(nslabs), dim3(256), lds, stream, k);
-      else hipLaunchKernelGGL(wgrad_k1_kernel<3>, dim3(nslabs), dim3(256), lds, stream, k);
-      PWG_CHECK_LAUNCH("wgrad_k1");
-    }
-    return finish_wgrad_slabs(workspace, nslabs, k.slab_elems, k.slab_stride, d->c_out, d->c_in, 1, dw, db, wn, stream);
+    const int rc = k1_wgrad_launch(d, x, dy, workspace, slab_stride, nslabs, slope, db != nullptr, stream);
+    if (rc != PWG_OK) return rc;
+    return finish_wgrad_slabs(workspace, nslabs, slab_elems, slab_stride, d->c_out, d->c_in, 1, dw, db, wn, stream);
   }
   if (!d->transposed) {
     a.g = dy;

@@ -319,3 +319,49 @@ def test_single_input_channel_kernels(B, cout, t, k, dil, pad, pre, post, wn, de
     else:
         assert none is None
         _close(dw_only, v.grad, "weight gradient (no bias)")
+
+
+@pytest.mark.parametrize("B,cin,cout,t,pre,wn,bias", [
+    (8, 96, 96, 4096, "leaky_relu", True, True),    # MelGAN residual stack at C = 96 (B * T as in a quarter of a C4 batch)
+    (8, 48, 48, 4100, None, True, True),            # C = 48, ragged last chunk (4100 = 64 * 64 + 4)
+    (16, 80, 96, 2048, "leaky_relu", False, True),  # Cin != Cout, padded rows on one side only
+    (32, 32, 24, 1024, None, False, False),         # one accumulator block, no bias
+    (4, 96, 96, 8192, "relu", False, True),         # ReLU operand (slope 0)
+])
+def test_1x1_weight_gradient_kernel(B, cin, cout, t, pre, wn, bias, device):
+    """1 x 1 convolutions with <= 96 channels and a long reduction take the HBM-bound wgrad_k1_kernel (csrc/wgrad_k1.hip:
+    whole Co x Ci output per workgroup, operands read once): weight and bias gradient, plain and through the weight-norm
+    finish, vs ATen CPU; deterministic (fixed slabs, fixed summation order); PWG_WG_K1-independent data gradient."""
+    from tests.util import poison_empty, poison_lds
+
+    g = torch.Generator().manual_seed(cin + cout + t)
+    x = torch.randn(B, cin, t, generator=g)
+    v = (torch.randn(cout, cin, 1, generator=g) / cin ** 0.5).requires_grad_()
+    gg = (1.0 + 0.1 * torch.randn(cout, 1, 1, generator=g)).requires_grad_()
+    b = (0.1 * torch.randn(cout, generator=g)).requires_grad_() if bias else None
+    w = gg * v / v.flatten(1).norm(dim=1).view(-1, 1, 1) if wn else v
+    xa = x if pre is None else (F.leaky_relu(x, 0.2) if pre == "leaky_relu" else F.relu(x))
+    ref = F.conv1d(xa, w, b)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    desc = ops.make_conv_desc(B, cin, cout, t, t, 1, pre_act=pre, pre_slope=0.2)
+    xd, dyd = x.to(device), dy.to(device)
+    with poison_lds(), poison_empty(), ops.profile() as prof:
+        if wn:
+            vd, gd = v.detach().to(device), gg.detach().reshape(-1).to(device)
+            dv, dg, db = ops.conv1d_backward_weight_wn(desc, xd, dyd, vd, gd, need_db=bias)
+            dv2, dg2, db2 = ops.conv1d_backward_weight_wn(desc, xd, dyd, vd, gd, need_db=bias)
+        else:
+            dv, db = ops.conv1d_backward_weight(desc, xd, dyd, tuple(v.shape), need_db=bias)
+            dv2, db2 = ops.conv1d_backward_weight(desc, xd, dyd, tuple(v.shape), need_db=bias)
+    assert any(k.startswith("wgrad_k1_kernel") for k in prof.results), sorted(prof.results)
+    _close(dv, v.grad, "weight gradient")
+    assert torch.equal(dv, dv2)
+    if bias:
+        _close(db, b.grad, "bias gradient")
+        assert torch.equal(db, db2)
+    else:
+        assert db is None
+    if wn:
+        _close(dg.reshape(-1), gg.grad.reshape(-1), "dg")
+        assert torch.equal(dg, dg2)
