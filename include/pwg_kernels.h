@@ -390,6 +390,12 @@ int pwg_weight_norm_backward(const float* dw, const float* v, const float* g, fl
  * tmp: max(rows, 32 * cols) floats of workspace (row-sliced partial sums of W^T u). */
 int pwg_spectral_norm_forward(const float* w_orig, float* u, float* v, float* sigma, float* w, float* tmp,
                               int32_t rows, int32_t cols, int32_t do_iter, float eps, void* stream);
+/* The same, also leaving this forward's u / v in u_saved (rows) / v_saved (cols): the copies torch's hook takes for the
+ * backward pass (torch/nn/utils/spectral_norm.py compute_weight: `u.clone()`, `v.clone()`), written by the iteration's own
+ * kernels; fewer dependent launches (ABI v11).  u_saved == u / v_saved == v is allowed when do_iter == 0.  */
+int pwg_spectral_norm_forward_saved(const float* w_orig, float* u, float* v, float* sigma, float* w, float* tmp,
+                                    float* u_saved, float* v_saved, int32_t rows, int32_t cols, int32_t do_iter,
+                                    float eps, void* stream);
 /* dw_orig = dw / sigma - (<dw, w_orig> / sigma^2) u v^T ;  scratch: PWG_SPECTRAL_NORM_SCRATCH_FLOATS floats
  * (the dot product is summed through per-block shares in a fixed order: no atomics).  */
 #define PWG_SPECTRAL_NORM_SCRATCH_FLOATS 257

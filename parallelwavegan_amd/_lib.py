@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("PWG_KERNEL_LIB") or os.path.join(_HERE, "libpwgkernel
 
 PWG_ACT_NONE, PWG_ACT_LEAKY_RELU, PWG_ACT_TANH, PWG_ACT_RELU = 0, 1, 2, 3
 PWG_PAD_ZERO, PWG_PAD_REFLECT, PWG_PAD_REPLICATE = 0, 1, 2
-ABI_VERSION = 10
+ABI_VERSION = 11
 SPECTRAL_NORM_SCRATCH_FLOATS = 257  # PWG_SPECTRAL_NORM_SCRATCH_FLOATS (include/pwg_kernels.h)
 
 
@@ -191,6 +191,7 @@ SIGNATURES = {
     "pwg_normalize_transpose": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pwg_weight_norm_backward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "pwg_spectral_norm_forward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
+    "pwg_spectral_norm_forward_saved": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "pwg_spectral_norm_backward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "pwg_gate_forward": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i64, _vp]),
     "pwg_gate_backward": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i64, _vp]),

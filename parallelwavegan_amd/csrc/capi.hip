@@ -175,5 +175,5 @@ extern "C" int pwg_prof_get(int32_t idx, char* name, size_t name_cap, double* to
 }
 
 extern "C" const char* pwg_last_error(void) { return pwg::g_err; }
-extern "C" int pwg_abi_version(void) { return 10; }
+extern "C" int pwg_abi_version(void) { return 11; }
 extern "C" int pwg_target_arch(void) { return 950; }

@@ -999,6 +999,9 @@ static int finish_wgrad_slabs(float* workspace, int splits, long slab_elems, lon
   // per 32 elements) followed by the row-wise weight-norm backward, into a spare slab of the workspace
   const long plane = (long)n0 * ci_g;  // elements per tap of a tap-major slab
   const int inner = ci_g * k;
+  // (round 6, measured and NOT kept: the fused finisher also for short rows cut into many slabs -- MelGAN's 48 / 96 / 192-channel
+  // stacks, one workgroup per row walking 128 - 512 slabs: 62 - 121 us per layer instead of 13 - 16 us for the two launches,
+  // C4 step 26.4 -> 27.9 ms, profiles/r06_wgrad_k1.txt)
   const bool wn_fused = wn != nullptr && (splits < 16 || n0 >= 512);
   if (wn != nullptr && !wn_fused) {
     float* dw_tmp = workspace + (size_t)splits * slab_stride;

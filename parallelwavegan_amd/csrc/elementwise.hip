@@ -301,6 +301,50 @@ __global__ void dot_kernel(const float* a, const float* b, float* out, int n) {
   s = block_sum_256(s, red);
   if (threadIdx.x == 0) out[0] = s;
 }
+// Round 6: the power iteration in fewer dependent launches (8 + two host-side clones of u / v -> 4 or 5 per layer and
+// forward; 32 layer-forwards per HiFi-GAN V1 training step, a serial chain of ~5 us launches on the first scale
+// discriminator's branch: profiles/r06_graph_gaps.txt).  Same arithmetic, same summation orders, bit-identical results.
+// s[r] = sum_c W[r][c] * (raw[c] / max(|raw|, eps)): matvec_kernel with normalize_kernel folded in -- every workgroup
+// recomputes the norm of `raw` (cols floats, from L2) with normalize_kernel's strided sums and tree; workgroup 0 also
+// writes the normalised vector to v and to v_saved (the copy the backward pass keeps).
+__global__ void matvec_normalized_kernel(const float* w, const float* raw, float* v, float* v_saved, float* s, int cols,
+                                         float eps) {
+  __shared__ float red[4];
+  float q = 0.f;
+  for (int i = threadIdx.x; i < cols; i += blockDim.x) q += raw[i] * raw[i];
+  q = block_sum_256(q, red);
+  const float d = fmaxf(sqrtf(q), eps);
+  const long base = (long)blockIdx.x * cols;
+  float acc = 0.f;
+  for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+    const float vc = raw[c] / d;
+    if (blockIdx.x == 0) {
+      v[c] = vc;
+      v_saved[c] = vc;
+    }
+    acc += w[base + c] * vc;
+  }
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0) s[blockIdx.x] = acc;
+}
+// u = t / max(|t|, eps) (also to u_saved), sigma = <u, t> with t = W v: normalize_kernel + dot_kernel in one single-workgroup
+// launch; the second matvec of the unfused chain recomputed exactly this t.
+__global__ void sn_finalize_kernel(const float* t, float* u, float* u_saved, float* sigma, int n, float eps) {
+  __shared__ float red[4];
+  float q = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) q += t[i] * t[i];
+  q = block_sum_256(q, red);
+  const float d = fmaxf(sqrtf(q), eps);
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float ui = t[i] / d;
+    u[i] = ui;
+    u_saved[i] = ui;
+    s += ui * t[i];
+  }
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) sigma[0] = s;
+}
 // dW_orig = dW / sigma - (<dW, W_orig> / sigma^2) u v^T ; dot2[0] must hold <dW, W_orig>
 __global__ void spectral_norm_bwd_kernel(const float* dw, const float* u, const float* v, const float* sigma,
                                          const float* dot_dw_w, float* dwo, int rows, int cols) {
@@ -896,6 +940,39 @@ extern "C" int pwg_spectral_norm_forward(const float* w_orig, float* u, float* v
   const long n = (long)rows * cols;
   hipLaunchKernelGGL(div_scalar_kernel, dim3(grid_for(n)), dim3(256), 0, stream, w_orig, sigma, w, n);
   PWG_CHECK_LAUNCH("spectral_norm_forward");
+  return PWG_OK;
+}
+
+// The same, additionally leaving the u / v of THIS forward in u_saved / v_saved (what torch's hook clones for the backward
+// pass: later forwards update u and v in place).  do_iter == 0: nothing is updated, the copies are plain device copies.
+extern "C" int pwg_spectral_norm_forward_saved(const float* w_orig, float* u, float* v, float* sigma, float* w, float* tmp,
+                                               float* u_saved, float* v_saved, int32_t rows, int32_t cols, int32_t do_iter,
+                                               float eps, void* stream_) {
+  PWG_REQUIRE(w_orig && u && v && sigma && w && tmp && u_saved && v_saved, PWG_ERR_NULL,
+              "spectral_norm_forward_saved: NULL pointer");
+  PWG_REQUIRE(rows > 0 && cols > 0, PWG_ERR_BAD_SHAPE, "spectral_norm: bad shape");
+  hipStream_t stream = (hipStream_t)stream_;
+  static const bool fused = !(getenv("PWG_SN_FUSED") && atoi(getenv("PWG_SN_FUSED")) == 0);
+  const int splits = rows >= 4 * SN_SPLITS ? SN_SPLITS : 1;
+  // W v goes behind the (summed) W^T u in the workspace: needs cols + rows <= max(rows, 32 * cols) floats
+  const long ws = rows > 32L * cols ? rows : 32L * cols;
+  if (!do_iter || !fused || (long)cols + rows > ws) {
+    const int rc = pwg_spectral_norm_forward(w_orig, u, v, sigma, w, tmp, rows, cols, do_iter, eps, stream_);
+    if (rc != PWG_OK) return rc;
+    if (u_saved != u) (void)hipMemcpyAsync(u_saved, u, sizeof(float) * rows, hipMemcpyDeviceToDevice, stream);
+    if (v_saved != v) (void)hipMemcpyAsync(v_saved, v, sizeof(float) * cols, hipMemcpyDeviceToDevice, stream);
+    PWG_CHECK_LAUNCH("spectral_norm_forward_saved");
+    return PWG_OK;
+  }
+  const int rps = (rows + splits - 1) / splits;
+  hipLaunchKernelGGL(matvec_t_kernel, dim3((cols + 63) / 64, splits), dim3(256), 0, stream, w_orig, u, tmp, rows, cols, rps);
+  if (splits > 1) hipLaunchKernelGGL(sum_parts_kernel, dim3(grid_for(cols)), dim3(256), 0, stream, tmp, cols, splits);
+  float* t = tmp + cols;
+  hipLaunchKernelGGL(matvec_normalized_kernel, dim3(rows), dim3(256), 0, stream, w_orig, tmp, v, v_saved, t, cols, eps);
+  hipLaunchKernelGGL(sn_finalize_kernel, dim3(1), dim3(256), 0, stream, t, u, u_saved, sigma, rows, eps);
+  const long n = (long)rows * cols;
+  hipLaunchKernelGGL(div_scalar_kernel, dim3(grid_for(n)), dim3(256), 0, stream, w_orig, sigma, w, n);
+  PWG_CHECK_LAUNCH("spectral_norm_forward_saved");
   return PWG_OK;
 }
 

@@ -58,11 +58,13 @@ class SpectralNormFn(torch.autograd.Function):
         sigma = torch.empty(1, device=w_orig.device, dtype=torch.float32)
         w = torch.empty_like(w_orig)
         tmp = torch.empty(max(rows, 32 * cols), device=w_orig.device, dtype=torch.float32)
-        _lib.check(_L().pwg_spectral_norm_forward(_ptr(w_orig), _ptr(u), _ptr(v), _ptr(sigma), _ptr(w), _ptr(tmp),
-                                                  rows, cols, int(bool(do_iter)), float(eps), _stream()),
-                   "spectral_norm_forward")
-        # torch clones u, v after the iteration so that later in-place updates do not alter this graph
-        ctx.save_for_backward(w_orig, u.clone(), v.clone(), sigma)
+        # torch clones u, v after the iteration so that later in-place updates do not alter this graph: the iteration's
+        # kernels write those copies themselves (without an iteration: cloned here, as before)
+        u_saved, v_saved = (torch.empty_like(u), torch.empty_like(v)) if do_iter else (u.clone(), v.clone())
+        _lib.check(_L().pwg_spectral_norm_forward_saved(_ptr(w_orig), _ptr(u), _ptr(v), _ptr(sigma), _ptr(w), _ptr(tmp),
+                                                        _ptr(u_saved), _ptr(v_saved), rows, cols, int(bool(do_iter)),
+                                                        float(eps), _stream()), "spectral_norm_forward_saved")
+        ctx.save_for_backward(w_orig, u_saved, v_saved, sigma)
         return w
 
     @staticmethod

@@ -327,10 +327,13 @@ def test_single_input_channel_kernels(B, cout, t, k, dil, pad, pre, post, wn, de
     (16, 80, 96, 2048, "leaky_relu", False, True),  # Cin != Cout, padded rows on one side only
     (32, 32, 24, 1024, None, False, False),         # one accumulator block, no bias
     (4, 96, 96, 8192, "relu", False, True),         # ReLU operand (slope 0)
+    (64, 192, 192, 512, "leaky_relu", True, True),  # MB-MelGAN's first stack at the C4 batch: two output halves per slab
+    (8, 128, 160, 4100, None, False, True),         # 96 < C <= 192, ragged rows on both sides, ragged last chunk
+    (16, 192, 40, 2048, "leaky_relu", False, False),  # wide on one side only
 ])
 def test_1x1_weight_gradient_kernel(B, cin, cout, t, pre, wn, bias, device):
-    """1 x 1 convolutions with <= 96 channels and a long reduction take the HBM-bound wgrad_k1_kernel (csrc/wgrad_k1.hip:
-    whole Co x Ci output per workgroup, operands read once): weight and bias gradient, plain and through the weight-norm
+    """1 x 1 convolutions with <= 192 channels and a long reduction take the HBM-bound wgrad_k1_kernel (csrc/wgrad_k1.hip:
+    whole Co x Ci output per workgroup up to C = 96, operands read once; two output halves above): weight and bias gradient, plain and through the weight-norm
     finish, vs ATen CPU; deterministic (fixed slabs, fixed summation order); PWG_WG_K1-independent data gradient."""
     from tests.util import poison_empty, poison_lds
 

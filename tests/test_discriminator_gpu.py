@@ -144,3 +144,47 @@ def test_deferred_activation_form_equals_the_post_activation_form(device):
         assert (gx0 - gx1).abs().max().item() <= 2e-6 * scale, name
         for a, b in zip(gp0, gp1):
             assert (a - b).abs().max().item() <= 3e-6 * max(a.abs().max().item(), 1e-6), name
+
+
+@pytest.mark.parametrize("rows,cols", [(128, 15), (128, 1312), (1024, 5120), (1, 3072), (1024, 20)])
+def test_spectral_norm_iteration_in_fewer_launches_is_bit_identical(rows, cols, device):
+    """Round 6: pwg_spectral_norm_forward_saved (normalisation folded into the following matrix-vector product, sigma into
+    the second normalisation, the backward pass's u / v copies written by the same kernels) against the 8-launch chain +
+    clones, on the weight shapes of HiFi-GAN's spectrally normalised scale discriminator (and one that does not fit the
+    workspace split and falls back): w, sigma, u, v and the saved copies are equal bit for bit; float64 check of sigma."""
+    import ctypes
+
+    from parallelwavegan_amd import _lib
+    from parallelwavegan_amd.ops import _ptr, _stream
+
+    g = torch.Generator().manual_seed(rows + cols)
+    w0 = torch.randn(rows, cols, generator=g).to(device)
+    u0 = torch.nn.functional.normalize(torch.randn(rows, generator=g), dim=0).to(device)
+    v0 = torch.nn.functional.normalize(torch.randn(cols, generator=g), dim=0).to(device)
+    L = _lib.lib()
+
+    def old():
+        u, v = u0.clone(), v0.clone()
+        sigma, w = torch.empty(1, device=device), torch.empty_like(w0)
+        tmp = torch.empty(max(rows, 32 * cols), device=device)
+        _lib.check(L.pwg_spectral_norm_forward(_ptr(w0), _ptr(u), _ptr(v), _ptr(sigma), _ptr(w), _ptr(tmp), rows, cols, 1,
+                                               1e-12, _stream()), "spectral_norm_forward")
+        return w, sigma, u, v, u.clone(), v.clone()
+
+    def new():
+        u, v = u0.clone(), v0.clone()
+        sigma, w = torch.empty(1, device=device), torch.empty_like(w0)
+        tmp = torch.full((max(rows, 32 * cols),), float("nan"), device=device)
+        us, vs = torch.full_like(u, float("nan")), torch.full_like(v, float("nan"))
+        _lib.check(L.pwg_spectral_norm_forward_saved(_ptr(w0), _ptr(u), _ptr(v), _ptr(sigma), _ptr(w), _ptr(tmp), _ptr(us),
+                                                     _ptr(vs), rows, cols, 1, 1e-12, _stream()), "spectral_norm_forward_saved")
+        return w, sigma, u, v, us, vs
+
+    a, b = old(), new()
+    for name, x, y in zip(("w", "sigma", "u", "v", "u_saved", "v_saved"), a, b):
+        assert torch.equal(x, y), name
+    wd = w0.double().cpu()
+    v_ref = torch.nn.functional.normalize(wd.t() @ u0.double().cpu(), dim=0)
+    u_ref = torch.nn.functional.normalize(wd @ v_ref, dim=0)
+    sigma_ref = float(u_ref @ (wd @ v_ref))
+    assert abs(b[1].item() - sigma_ref) <= 1e-5 * abs(sigma_ref)

@@ -11,7 +11,7 @@ import torch
 
 from parallelwavegan_amd import ops
 
-SHAPES = [(64, 96, 96, 2048), (64, 48, 48, 4096), (64, 192, 192, 512), (64, 64, 64, 4096), (16, 32, 32, 8192)]
+SHAPES = [(64, 96, 96, 2048), (64, 48, 48, 4096), (64, 192, 192, 512), (64, 64, 64, 4096), (16, 32, 32, 8192), (16, 128, 128, 2048)]
 
 
 def main():
