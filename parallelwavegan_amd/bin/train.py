@@ -71,6 +71,7 @@ class Trainer(object):
         # sync) so that a run can say afterwards WHICH loss went non-finite at WHICH step (bench.py)
         self._loss_hist = [] if config.get("record_loss_history", False) else None
         self._capturing = False
+        self._bank_stream = None
         self._graphs, self._graph_seen = {}, {}
         if config.get("use_hip_graph", False) and config.get("branch_streams", True):
             for m in self.model.values():  # independent sub-networks become parallel graph branches
@@ -80,6 +81,8 @@ class Trainer(object):
                 from .. import streams
 
                 streams.reserve(torch.device(device))  # (created before any capture)
+                # one more stream: the discriminator's weight images are packed beside the generator's forward pass
+                self._bank_stream = torch.cuda.Stream(device=torch.device(device))
             # parameters of the sub-networks receive their gradients on the branch streams by design (the joins
             # are explicit events, streams.py); torch >= 2.9 warns about that once per process
             quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
@@ -491,11 +494,30 @@ class Trainer(object):
             if key in self._banks and y.is_cuda:
                 self._banks[key].ensure(with_bwd)
 
+        def prep_beside(key, with_bwd):
+            """``prep`` on a side stream while the caller's stream goes on (only inside a capture, where the fork is a
+            branch of the graph: the discriminator's images -- 70 M parameters, 0.5 ms of HBM-bound packing in the HiFi-GAN
+            V1 step -- are not needed before the generator's forward pass is over).  Returns the event to wait for, or None."""
+            from ..streams import fork_now
+
+            if not (key in self._banks and y.is_cuda and self._bank_stream is not None and fork_now()
+                    and os.environ.get("PWG_BANK_BESIDE", "1") == "1"):
+                prep(key, with_bwd)
+                return None
+            cur = torch.cuda.current_stream(y.device)
+            fork = torch.cuda.Event()
+            fork.record(cur)
+            self._bank_stream.wait_event(fork)
+            with torch.cuda.stream(self._bank_stream):
+                prep(key, with_bwd)
+                done = torch.cuda.Event()
+                done.record(self._bank_stream)
+            return done
+
         # ---------------- generator ----------------
         if self.steps > cfg.get("generator_train_start_steps", 0):
             prep("generator", True)
-            if disc_on:
-                prep("discriminator", True)
+            d_images = prep_beside("discriminator", True) if disc_on else None
             y_, y_mb_ = self._generator_forward(x)
             gen_loss = 0.0
             if cfg["use_stft_loss"]:
@@ -516,6 +538,8 @@ class Trainer(object):
                 self._log("train/mel_loss", mel_loss)
             gen_loss = gen_loss * cfg.get("lambda_aux", 1.0)
             if disc_on:
+                if d_images is not None:
+                    torch.cuda.current_stream(y.device).wait_event(d_images)
                 # D acts as a fixed critic for G(c): no D weight gradients (they would be discarded)
                 d_params = list(self._module("discriminator").parameters())
                 for p in d_params:
