@@ -4,7 +4,7 @@ that starts next (its launch / dependency latency) -- and (b) the kernels in fli
 workgroups (default 128: half a wave of workgroups on 256 CUs) -- attributed to the kernels in flight, pro rata.
 
     rocprofv3 --kernel-trace --output-format csv -d DIR -o p -- python tools/train_replay.py c3 14
-    python tools/graph_gaps.py DIR/p_kernel_trace.csv [fill=128] > profiles/r06_graph_gaps_c3.txt
+    python tools/graph_gaps.py DIR/p_kernel_trace.csv [fill=128] [launches per replay, for traces without an optimizer]
 """
 import collections
 import csv
@@ -39,6 +39,9 @@ def main():
     if len(opt) >= 6:
         lo, hi = opt[-5] + 1, opt[-3] + 1  # the step before the last one (complete)
         rows = rows[lo:hi]
+    elif len(sys.argv) > 3:  # no optimizer in the trace (inference replays): the last-but-one block of argv[3] launches
+        per = int(sys.argv[3])
+        rows = rows[-2 * per:-per]
     t0, t1 = rows[0][0], max(r[1] for r in rows)
     ev = []
     for i, (s, e, _, _) in enumerate(rows):
