@@ -94,3 +94,40 @@ def test_round5_traffic_summary_kernel_trace_and_bench_line_agree(tmp_path):
     trace_avg_us = float(fam[3])
     ev = json.load(open(os.path.join(ROOT, "profiles", "r05_infer_bench_detail.json")))["roofline"]["avg_launch_us"]
     assert int(fam[1]) == 470 and abs(trace_avg_us - ev) <= 0.02 * trace_avg_us, (trace_avg_us, ev)
+
+
+def test_round6_traffic_summary_kernel_trace_and_bench_line_agree(tmp_path):
+    """Round 6 (tools/evidence_round6.sh, tools/collect_round6.sh): (i) the traffic summary bench.py cites first is
+    reproducible from the committed raw counter sums and the detail record of the same profiling run; (ii) the conv family's
+    average launch duration in the rocprofv3 kernel trace agrees with the HIP-event figure of the same command and with the
+    committed stdout line of the round within 2 %; (iii) the line's roofline fraction is achieved / peak of those figures."""
+    import csv
+
+    out = tmp_path / "traffic.json"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_round5_summary.py"),
+                           os.path.join(ROOT, "profiles", "r06_pmc_hbm_raw.json"),
+                           os.path.join(ROOT, "profiles", "r06_infer_bench_detail.json"), str(out)],
+                          stdout=subprocess.DEVNULL)
+    new = json.load(open(out))
+    old = json.load(open(os.path.join(ROOT, "profiles", "r06_pmc_hbm_traffic.json")))
+    for fam in ("conv1d_mfma_dma_kernel", "resunit_kernel"):
+        for key in ("hbm_bytes_per_launch", "algorithmic_bytes_per_launch"):
+            assert abs(new["kernels"][fam][key] - old["kernels"][fam][key]) <= 1e-9 * old["kernels"][fam][key]
+    assert abs(old["calibration"]["fetch_factor_used"] - 2.0) < 1e-3 and abs(old["calibration"]["write_factor_used"] - 1.0) < 1e-3
+    assert old["kernel"] == "conv1d_mfma_dma_kernel" and old["launches_per_forward"] == 47.0
+    assert old["kernels"]["conv1d_mfma_dma_kernel"]["traffic_over_algorithmic"] < 1.3
+    trace_avg = None
+    with open(os.path.join(ROOT, "profiles", "r06_infer_kernel_stats.csv")) as f:
+        for row in csv.reader(r for r in f if not r.startswith("#")):
+            if row and row[0].startswith("FAMILY") and "conv1d_mfma_dma_kernel" in row[0]:
+                trace_avg = float(row[3])
+    assert trace_avg is not None
+    infer = json.loads(open(os.path.join(ROOT, "profiles", "r06_infer_bench_line.json")).read())
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r06_final_bench_line.json")).read())
+    for rec in (infer, line):
+        r = rec["roofline"]
+        assert r["kernel"] == "conv1d_mfma_dma_kernel" and r["bound"] == "mfma" and r["peak"] == 157.3
+        assert abs(r["avg_launch_us"] - trace_avg) <= 0.02 * trace_avg, (r["avg_launch_us"], trace_avg)
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-3
+        assert abs(r["achieved"] - r["flops_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e12) <= 0.01 * r["achieved"]
+    assert line["cpu_baseline"]["kind"] == "reference" and line["parity"]["ok"] and line["train_ok"]
