@@ -45,6 +45,23 @@ class WeightNormFn(torch.autograd.Function):
         return dv, dg
 
 
+class Unpack2Fn(torch.autograd.Function):
+    """(v[0], v[1]) of a 2-vector as two 0-dim tensors whose backward is ONE launch (``v[0], v[1]`` by indexing costs two
+    zero fills, two copies and an accumulation in the backward pass)."""
+
+    @staticmethod
+    def forward(ctx, v):
+        out = v.clone()
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        if g0 is None and g1 is None:
+            return None
+        z = (g0 if g0 is not None else g1).new_zeros(())
+        return torch.stack([g0 if g0 is not None else z, g1 if g1 is not None else z])
+
+
 class SpectralNormFn(torch.autograd.Function):
     """w = w_orig / sigma, sigma = u^T W v after (optionally) one power iteration that updates the
     ``u``/``v`` buffers in place, as torch.nn.utils.spectral_norm does in training mode."""
