@@ -626,7 +626,15 @@ __global__ __launch_bounds__(256) void reduce_slabs_wn_kernel(const float* __res
     const int c = ((int)blockIdx.x - n0) * 256 + threadIdx.x;
     if (c < nbias) {
       float s = 0.f;
-      for (int j = 0; j < nslabs; ++j) s += slabs[(long)j * slab_stride + slab_elems + c];
+      int j = 0;
+      for (; j + 8 <= nslabs; j += 8) {  // (loads first, additions in slab order)
+        float u[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) u[q] = slabs[(long)(j + q) * slab_stride + slab_elems + c];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += u[q];
+      }
+      for (; j < nslabs; ++j) s += slabs[(long)j * slab_stride + slab_elems + c];
       db[c] = s;
     }
     return;
@@ -642,7 +650,17 @@ __global__ __launch_bounds__(256) void reduce_slabs_wn_kernel(const float* __res
       const int tap = e / ci_g, i = e - tap * ci_g;
       const long src = seg0 + tap * seg_step + i;
       float s = 0.f;
-      for (int j = sl; j < nslabs; j += 8) s += slabs[(long)j * slab_stride + src];
+      // (round 6: eight loads in flight per lane, added in the same order -- the dependent load + add rounds made this
+      // finisher 62 - 121 us for MelGAN's short rows cut into 256 - 512 slabs, profiles/r06_wgrad_k1.txt)
+      int j = sl;
+      for (; j + 56 < nslabs; j += 64) {
+        float t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = slabs[(long)(j + 8 * q) * slab_stride + src];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += t[q];
+      }
+      for (; j < nslabs; j += 8) s += slabs[(long)j * slab_stride + src];
       part[sl * inner + e] = s;
     }
     __syncthreads();
@@ -658,7 +676,15 @@ __global__ __launch_bounds__(256) void reduce_slabs_wn_kernel(const float* __res
     } else {
       const long src = seg0 + tap * seg_step + i;
       t = 0.f;
-      for (int j = 0; j < nslabs; ++j) t += slabs[(long)j * slab_stride + src];
+      int j = 0;
+      for (; j + 8 <= nslabs; j += 8) {  // (loads first, additions in slab order)
+        float u[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) u[q] = slabs[(long)(j + q) * slab_stride + src];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += u[q];
+      }
+      for (; j < nslabs; ++j) t += slabs[(long)j * slab_stride + src];
     }
     row[i * k + tap] = t;
   }
@@ -999,9 +1025,11 @@ static int finish_wgrad_slabs(float* workspace, int splits, long slab_elems, lon
   // per 32 elements) followed by the row-wise weight-norm backward, into a spare slab of the workspace
   const long plane = (long)n0 * ci_g;  // elements per tap of a tap-major slab
   const int inner = ci_g * k;
-  // (round 6, measured and NOT kept: the fused finisher also for short rows cut into many slabs -- MelGAN's 48 / 96 / 192-channel
-  // stacks, one workgroup per row walking 128 - 512 slabs: 62 - 121 us per layer instead of 13 - 16 us for the two launches,
-  // C4 step 26.4 -> 27.9 ms, profiles/r06_wgrad_k1.txt)
+  // (round 6, measured twice and NOT kept: the fused finisher also for short rows cut into many slabs -- MelGAN's 48 / 96 / 192-
+  // channel stacks, one workgroup per row walking 128 - 512 slabs.  With dependent load + add rounds: 62 - 121 us per layer
+  // instead of 13 - 16 us for the two launches; with eight loads in flight (as the kernel has them now): 8.6 - 25 us, better at
+  // 128 / 192 rows, worse at 32 - 64, and the captured steps lose: C3 45.9 -> 46.4 ms, C5 41.9 -> 42.5 ms, C4 25.8 -> 25.9 ms,
+  // profiles/r06_wgrad_k1.txt)
   const bool wn_fused = wn != nullptr && (splits < 16 || n0 >= 512);
   if (wn != nullptr && !wn_fused) {
     float* dw_tmp = workspace + (size_t)splits * slab_stride;
