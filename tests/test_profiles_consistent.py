@@ -131,3 +131,6 @@ def test_round6_traffic_summary_kernel_trace_and_bench_line_agree(tmp_path):
         assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-3
         assert abs(r["achieved"] - r["flops_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e12) <= 0.01 * r["achieved"]
     assert line["cpu_baseline"]["kind"] == "reference" and line["parity"]["ok"] and line["train_ok"]
+    # the final line was taken AFTER the counter summary was committed: it cites exactly that file's number
+    assert line["roofline"]["traffic_source"] == "profiles/r06_pmc_hbm_traffic.json"
+    assert abs(line["roofline"]["traffic"] - old["hbm_bytes_per_launch"]) <= 0.01

@@ -14,7 +14,11 @@ for c in c2 c3 c4 c5; do grep -v amdgpu.ids $S/train_shapes_$c.txt > $D/r06_fina
 cp $P/infer_kernel_stats.csv $D/r06_infer_kernel_stats.csv
 cp $P/bench_kernel_stats.csv $D/r06_bench_kernel_stats.csv
 cp $P/infer_bench_line.json $D/r06_infer_bench_line.json
-cp $P/infer_bench.json $D/r06_infer_bench_detail.json
-cp $P/pmc_raw.json $D/r06_pmc_hbm_raw.json
-cp $P/pmc_hbm_traffic.json $D/r06_pmc_hbm_traffic.json
+# The counter summary (and the detail record of ITS run) is committed once: bench.py cites the committed file, so a line
+# taken afterwards carries exactly that number.  KEEP_PMC=0 replaces them with this run's.
+if [ "${KEEP_PMC:-1}" != "1" ] || [ ! -f $D/r06_pmc_hbm_traffic.json ]; then
+  cp $P/infer_bench.json $D/r06_infer_bench_detail.json
+  cp $P/pmc_raw.json $D/r06_pmc_hbm_raw.json
+  cp $P/pmc_hbm_traffic.json $D/r06_pmc_hbm_traffic.json
+fi
 ls -la $D | grep r06_ | wc -l
