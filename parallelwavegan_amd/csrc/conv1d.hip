@@ -1780,6 +1780,54 @@ extern "C" size_t pwg_conv1d_forward_workspace_floats(const pwg_conv1d_desc* d_i
   return p.ksplit > 1 ? (size_t)p.ksplit * flat.batch * flat.c_out * flat.t_out * flat.width : 0;
 }
 
+// Few output channels over a long sequence: the streaming VALU kernels (conv1d_small_cout_stream_kernel / conv1d_small_cout_kernel).
+// `d`: a plain (non-transposed) flattened descriptor for which small_cout_applicable holds; `g` its geometry.
+static int run_small_cout(const pwg_conv1d_desc* d, const Geometry& g, const float* x, const float* w_packed, const float* bias,
+                          float* y, void* stream) {
+  // few output channels over a long sequence: streaming VALU kernel (see conv1d_small_cout_kernel)
+  {
+    // round 6: the LDS-free stream for "same"-padded dilation-1 layers with 16-B aligned rows (PWG_SMALL_COUT_STREAM=0: off)
+    static const bool stream_on = !(getenv("PWG_SMALL_COUT_STREAM") && atoi(getenv("PWG_SMALL_COUT_STREAM")) == 0);
+    const int kk = d->kernel;
+    void (*sk)(const float*, const float*, const float*, float*, int, int, int, int, int, int, float, int, float, float) = nullptr;
+    if (stream_on && d->dilation == 1 && (kk & 1) && d->pad_left == (kk - 1) / 2 && d->t_out == d->t_in &&
+        (d->t_in & 3) == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && (d->c_out == 1 || d->c_out == 4)) {
+#define PWG_SCS(KV) (d->c_out == 1 ? conv1d_small_cout_stream_kernel<KV, (KV - 1) / 2, 1> : conv1d_small_cout_stream_kernel<KV, (KV - 1) / 2, 4>)
+      if (kk == 1) sk = PWG_SCS(1);
+      else if (kk == 3) sk = PWG_SCS(3);
+      else if (kk == 5) sk = PWG_SCS(5);
+      else if (kk == 7) sk = PWG_SCS(7);
+#undef PWG_SCS
+    }
+    if (sk) {
+      const double out_elems = (double)d->batch * d->c_out * d->t_out;
+      ProfScope prof((hipStream_t)stream, "conv1d_small_cout_stream_kernel", 2.0 * out_elems * d->c_in * d->kernel,
+                     4.0 * ((double)d->batch * d->c_in * d->t_in + out_elems));
+      hipLaunchKernelGGL(sk, dim3(ceil_div(d->t_out, 1024), d->batch), dim3(256),
+                         (size_t)d->c_out * d->c_in * d->kernel * sizeof(float), (hipStream_t)stream, x, w_packed, bias, y,
+                         d->c_in, g.cin_pad, g.m_pad, d->t_in, d->t_out, d->pre_act, d->pre_slope, d->post_act,
+                         d->post_slope, d->out_mul);
+      PWG_CHECK_LAUNCH("conv1d_small_cout_stream");
+      return PWG_OK;
+    }
+  }
+  int opt = 4;
+  while (opt > 1 && (long)ceil_div(d->t_out, 256 * opt) * d->batch < 1024) opt >>= 1;
+  const int tile = 256 * opt;
+  const size_t lds = ((size_t)d->c_out * d->c_in * d->kernel + tile + (d->kernel - 1) * d->dilation) * sizeof(float);
+  const double out_elems = (double)d->batch * d->c_out * d->t_out;
+  ProfScope prof((hipStream_t)stream, "conv1d_small_cout_kernel", 2.0 * out_elems * d->c_in * d->kernel,
+                 4.0 * ((double)d->batch * d->c_in * d->t_in + out_elems));
+  void (*sck)(const float*, const float*, const float*, float*, int, int, int, int, int, int, int, int, int, int, float, int,
+              float, float) = opt == 4 ? conv1d_small_cout_kernel<4> : (opt == 2 ? conv1d_small_cout_kernel<2> : conv1d_small_cout_kernel<1>);
+  hipLaunchKernelGGL(sck, dim3(ceil_div(d->t_out, tile), d->batch), dim3(256), lds,
+                     (hipStream_t)stream, x, w_packed, bias, y, d->c_in, g.cin_pad, g.m_pad, d->c_out, d->t_in, d->t_out,
+                     d->kernel, d->dilation, d->pad_left, d->pre_act, d->pre_slope, d->post_act, d->post_slope,
+                     d->out_mul);
+  PWG_CHECK_LAUNCH("conv1d_small_cout");
+  return PWG_OK;
+}
+
 extern "C" int pwg_conv1d_forward(const pwg_conv1d_desc* d_in, const float* x, const float* w_packed,
                                   const float* bias, const float* add1, const float* add2, float* y,
                                   float* workspace, size_t workspace_floats, void* stream) {
@@ -1819,48 +1867,7 @@ extern "C" int pwg_conv1d_forward(const pwg_conv1d_desc* d_in, const float* x, c
     ConvArgs chk;
     rc = fill_args(d, g, x, w_packed, bias, add1, add2, y, &chk);
     if (rc != PWG_OK) return rc;
-    // few output channels over a long sequence: streaming VALU kernel (see conv1d_small_cout_kernel)
-    {
-      // round 6: the LDS-free stream for "same"-padded dilation-1 layers with 16-B aligned rows (PWG_SMALL_COUT_STREAM=0: off)
-      static const bool stream_on = !(getenv("PWG_SMALL_COUT_STREAM") && atoi(getenv("PWG_SMALL_COUT_STREAM")) == 0);
-      const int kk = d->kernel;
-      void (*sk)(const float*, const float*, const float*, float*, int, int, int, int, int, int, float, int, float, float) = nullptr;
-      if (stream_on && d->dilation == 1 && (kk & 1) && d->pad_left == (kk - 1) / 2 && d->t_out == d->t_in &&
-          (d->t_in & 3) == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && (d->c_out == 1 || d->c_out == 4)) {
-#define PWG_SCS(KV) (d->c_out == 1 ? conv1d_small_cout_stream_kernel<KV, (KV - 1) / 2, 1> : conv1d_small_cout_stream_kernel<KV, (KV - 1) / 2, 4>)
-        if (kk == 1) sk = PWG_SCS(1);
-        else if (kk == 3) sk = PWG_SCS(3);
-        else if (kk == 5) sk = PWG_SCS(5);
-        else if (kk == 7) sk = PWG_SCS(7);
-#undef PWG_SCS
-      }
-      if (sk) {
-        const double out_elems = (double)d->batch * d->c_out * d->t_out;
-        ProfScope prof((hipStream_t)stream, "conv1d_small_cout_stream_kernel", 2.0 * out_elems * d->c_in * d->kernel,
-                       4.0 * ((double)d->batch * d->c_in * d->t_in + out_elems));
-        hipLaunchKernelGGL(sk, dim3(ceil_div(d->t_out, 1024), d->batch), dim3(256),
-                           (size_t)d->c_out * d->c_in * d->kernel * sizeof(float), (hipStream_t)stream, x, w_packed, bias, y,
-                           d->c_in, g.cin_pad, g.m_pad, d->t_in, d->t_out, d->pre_act, d->pre_slope, d->post_act,
-                           d->post_slope, d->out_mul);
-        PWG_CHECK_LAUNCH("conv1d_small_cout_stream");
-        return PWG_OK;
-      }
-    }
-    int opt = 4;
-    while (opt > 1 && (long)ceil_div(d->t_out, 256 * opt) * d->batch < 1024) opt >>= 1;
-    const int tile = 256 * opt;
-    const size_t lds = ((size_t)d->c_out * d->c_in * d->kernel + tile + (d->kernel - 1) * d->dilation) * sizeof(float);
-    const double out_elems = (double)d->batch * d->c_out * d->t_out;
-    ProfScope prof((hipStream_t)stream, "conv1d_small_cout_kernel", 2.0 * out_elems * d->c_in * d->kernel,
-                   4.0 * ((double)d->batch * d->c_in * d->t_in + out_elems));
-    void (*sck)(const float*, const float*, const float*, float*, int, int, int, int, int, int, int, int, int, int, float, int,
-                float, float) = opt == 4 ? conv1d_small_cout_kernel<4> : (opt == 2 ? conv1d_small_cout_kernel<2> : conv1d_small_cout_kernel<1>);
-    hipLaunchKernelGGL(sck, dim3(ceil_div(d->t_out, tile), d->batch), dim3(256), lds,
-                       (hipStream_t)stream, x, w_packed, bias, y, d->c_in, g.cin_pad, g.m_pad, d->c_out, d->t_in, d->t_out,
-                       d->kernel, d->dilation, d->pad_left, d->pre_act, d->pre_slope, d->post_act, d->post_slope,
-                       d->out_mul);
-    PWG_CHECK_LAUNCH("conv1d_small_cout");
-    return PWG_OK;
+    return run_small_cout(d, g, x, w_packed, bias, y, stream);
   }
   ConvArgs a;
   rc = fill_args(d, g, x, w_packed, bias, add1, add2, y, &a);
@@ -1921,6 +1928,31 @@ extern "C" int pwg_conv1d_backward_data(const pwg_conv1d_desc* d, const float* d
   Geometry g;
   int rc = make_geometry(&dd, &g);
   if (rc != PWG_OK) return rc;
+  // Round 6: the data gradient of a stride-1 layer with one (<= 4) input channel over a long sequence -- every discriminator's
+  // first layer, when the discriminator's input needs a gradient (generator phase) -- is a plain few-OUTPUT-channel convolution
+  // over the flipped taps (make_geometry: that is how the backward image is packed): on the MFMA tile one of 32 rows carries data
+  // (2.5 TFLOP/s, 0.2 ms for MelGAN's 16 -> 1 k = 15 layer at B64 x 16384, 0.15 ms for HiFi-GAN's 128 -> 1); the streaming
+  // kernels read dy once.  PWG_SMALL_COUT_DGRAD=0: the MFMA path.
+  static const bool dgrad_stream = !(getenv("PWG_SMALL_COUT_DGRAD") && atoi(getenv("PWG_SMALL_COUT_DGRAD")) == 0);
+  if (dgrad_stream && dd.stride == 1 && g.phases == 1 && g.out_off == 0 && accum == nullptr && d->pre_act == PWG_ACT_NONE) {
+    pwg_conv1d_desc pd = dd;
+    pd.transposed = 0;
+    pd.pad_left = g.pad;
+    // (the LDS kernel walks the input channels one by one, two barriers each: 0.29 ms for HiFi-GAN's 128 -> 1 k = 15 against 0.13 ms
+    // on the MFMA tile -- only few channels take it; the LDS-free stream (k <= 7, "same" padding) has no such walk)
+    const bool stream_form = pd.dilation == 1 && (pd.kernel & 1) && pd.kernel <= 7 && pd.pad_left == (pd.kernel - 1) / 2 &&
+                             pd.t_out == pd.t_in && (pd.t_in & 3) == 0 && ((((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0 &&
+                             (pd.c_out == 1 || pd.c_out == 4);
+    if (small_cout_applicable(&pd, false) && (pd.c_in <= 32 || stream_form)) {
+      PWG_REQUIRE(dy && w_packed_bwd && dx, PWG_ERR_NULL, "conv1d_backward_data: NULL pointer");
+      Geometry pg;
+      rc = make_geometry(&pd, &pg);
+      if (rc != PWG_OK) return rc;
+      PWG_REQUIRE(pg.cin_pad == g.cin_pad && pg.m_pad == g.m_pad && pg.k_phase == g.k_phase, PWG_ERR_UNSUPPORTED,
+                  "conv1d_backward_data: plain form of the dual descriptor has another image layout");
+      return run_small_cout(&pd, pg, dy, w_packed_bwd, nullptr, dx, stream);
+    }
+  }
   ConvArgs a;
   rc = fill_args(&dd, g, dy, w_packed_bwd, nullptr, accum, nullptr, dx, &a);
   if (rc != PWG_OK) return rc;

@@ -274,6 +274,8 @@ def test_small_cout_streaming_kernel(cin, cout, t, k, dil, pre, post, kernel, de
     (1, 128, 4100, 15, 1, 7, None, "leaky_relu", True),    # HiFi-GAN scale discriminator's first layer, ragged tiles
     (2, 64, 2500, 3, 2, 2, "leaky_relu", None, False),     # dilated, pre-activated (the operand activation of the wgrad)
     (2, 8, 2048, 16, 1, 8, None, None, True),              # maximal tap count, exactly two tiles
+    (3, 16, 4200, 15, 1, 0, None, "leaky_relu", False),    # long enough for the streaming DATA gradient too ("full" padding)
+    (2, 64, 8192, 3, 1, 1, None, "leaky_relu", True),      # PWG discriminator's first layer: the LDS-free stream (k = 3, "same")
 ])
 def test_single_input_channel_kernels(B, cout, t, k, dil, pad, pre, post, wn, device):
     """Cin = 1 over a long sequence (every discriminator's first layer) takes the streaming VALU kernels
@@ -308,6 +310,8 @@ def test_single_input_channel_kernels(B, cout, t, k, dil, pad, pre, post, wn, de
             dw_only, none = ops.conv1d_backward_weight(desc, xd, dyd, tuple(v.shape), need_db=False)
         dx = ops.conv1d_backward_data(desc, dyd, ops.pack_weight_bwd(desc, wd), xd)
     assert "conv1d_small_cin_kernel" in prof.results and "conv1d_small_cin_wgrad_kernel" in prof.results, list(prof.results)
+    if t >= 4096 and pre is None and (cout <= 32 or k <= 7):  # round 6: the data gradient (one output channel) streams as well
+        assert any(k.startswith("conv1d_small_cout") for k in prof.results), list(prof.results)
     _close(y, out_ref, "forward")
     _close(dv, v.grad, "weight gradient")
     _close(db, b.grad, "bias gradient")
