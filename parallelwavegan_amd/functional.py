@@ -244,20 +244,24 @@ class FusedConvFn(torch.autograd.Function):
         # data parallel: results go straight into the parameters' bucket slots where those are free (ops.claim_grad_slot)
         out_w = out_b = out_g = None
         acc_w = acc_b = acc_g = None  # slots that already hold this pass's first contribution: add into them
+        later_w = later_b = False     # (what claim_grad_slots said: True or the stream of the first contribution)
         if ctx.slot_keys is not None and ops.GRAD_SLOTS:
             kw, kb, kg = ctx.slot_keys
             if need_b and has_bias:
                 views, later = ops.claim_grad_slots([(kb, (desc.c_out,))])
                 if views is not None:
                     out_b, acc_b = (None, views[0]) if later else (views[0], None)
+                    later_b = later
             if ctx.has_g and need_w and need_g:
                 views, later = ops.claim_grad_slots([(kw, ctx.w_shape), (kg, tuple(g.reshape(-1).shape))])
                 if views is not None:
                     (out_w, out_g), (acc_w, acc_g) = ((None, None), views) if later else (views, (None, None))
+                    later_w = later
             elif not ctx.has_g and need_w:
                 views, later = ops.claim_grad_slots([(kw, ctx.w_shape)])
                 if views is not None:
                     out_w, acc_w = (None, views[0]) if later else (views[0], None)
+                    later_w = later
         if ctx.has_g and (need_w or need_g) and wn_row_bytes + 256 <= 64 * 1024:
             # weight-normalised layer: slabs -> (dv, dg) in one fused finishing kernel
             dv, dg, db = ops.conv1d_backward_weight_wn(desc, x3, gsum, v, g.reshape(-1),
@@ -282,13 +286,13 @@ class FusedConvFn(torch.autograd.Function):
         # later contributions of a backward pass (the discriminator phase differentiates D(y) and D(G(c)) together):
         # added into the bucket slot here; autograd gets None and has nothing to sum or copy
         if acc_w is not None and dw is not None:
-            acc_w.add_(dw.reshape(acc_w.shape))
+            ops.slot_add(acc_w, dw, later_w)
             dw = None
         if acc_g is not None and dg is not None:
-            acc_g.add_(dg.reshape(acc_g.shape))
+            ops.slot_add(acc_g, dg, later_w)
             dg = None
         if acc_b is not None and db is not None:
-            acc_b.add_(db.reshape(acc_b.shape))
+            ops.slot_add(acc_b, db, later_b)
             db = None
         gshape = dy.shape if desc.width == 1 else (desc.batch, desc.c_out, desc.t_out, desc.width)
         dadd1 = gsum.reshape(gshape) if has_add1 and ctx.needs_input_grad[3] else None

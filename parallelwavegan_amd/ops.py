@@ -74,9 +74,43 @@ def claim_grad_slots(keys_shapes):
     if len(states) != 1:  # (cannot happen while a layer's parameters live in one reducer; stay on the copying path)
         return None, False
     later = states.pop()
+    cur = torch.cuda.current_stream(entries[0][0][0].device) if entries[0][0][0].is_cuda else None
     for e, _, owner in entries:
         e[2] = owner.epoch
+        if not later:  # remember where this pass's first contribution is written (see slot_add)
+            if len(e) > 3:
+                e[3] = cur
+            else:
+                e.append(cur)
+    if later:
+        first = entries[0][0][3] if len(entries[0][0]) > 3 else None
+        later = first if first is not None else True
     return [e[0].view(shape) for e, shape, _ in entries], later
+
+
+def slot_add(slot_view, contribution, later):
+    """Add a LATER contribution of one backward pass into a gradient slot.  ``later`` is what :func:`claim_grad_slots`
+    returned: True, or the stream the pass's FIRST contribution was written on.  The two passes of a layer normally run
+    on one stream (program order).  They do not when one of them is the un-forked re-evaluation of a stateful
+    sub-discriminator (``only=[...]`` with a single branch: caller's stream) and the other one the forked full pass (side
+    stream): an ``add_`` on the caller's stream was then unordered against the first write -- and against the reducer
+    hook's event, which autograd places on the first write's stream (round 6: the bias gradients of HiFi-GAN's spectrally
+    normalised scale discriminator; found through the eager fork, profiles/r06_eager_nan_bisect.txt; the captured graph
+    had the same two unordered nodes).  The addition is issued on the FIRST stream, after this stream's producer."""
+    t = contribution.reshape(slot_view.shape)
+    if later is True or not t.is_cuda:
+        slot_view.add_(t)
+        return
+    cur = torch.cuda.current_stream(t.device)
+    if later == cur:
+        slot_view.add_(t)
+        return
+    done = torch.cuda.Event()
+    done.record(cur)
+    later.wait_event(done)
+    with torch.cuda.stream(later):
+        slot_view.add_(t)
+    t.record_stream(later)
 
 
 def _numel(shape):

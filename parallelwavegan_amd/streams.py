@@ -34,22 +34,15 @@ MAX_SIDE_STREAMS = int(os.environ.get("PWG_MAX_SIDE_STREAMS", "8"))
 # of a branch were always recorded; now the inputs are too (``inputs=`` below), which also pins them until the end of a
 # capture (the caching allocator defers the reuse of a block with recorded streams to the end of the capture), so the
 # captured graph cannot contain that write-after-read pair without an edge either.
+# A second finding of the same hunt, in the data-parallel path: a LATER contribution to a gradient slot was added on the
+# caller's stream when the stateful sub-discriminator was re-evaluated un-forked, unordered against the forked pass's first
+# write (ops.slot_add; the eager two-rank run differed from its segmented-graph twin in 3 of 12 runs before, 0 of 12 after).
 EAGER_FORK = os.environ.get("PWG_EAGER_BRANCH_STREAMS", "0") == "1"
 
 
 def fork_now(device=None):
     """Should independent branches be forked onto side streams right now?"""
-    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
-        return True
-    if not EAGER_FORK:
-        return False
-    # The eager fork is a debugging mode of the single-process path.  With a data-parallel reducer active (gradient slots
-    # registered, ops.GRAD_SLOTS) it is refused: the whole GPU suite under PWG_EAGER_BRANCH_STREAMS=1 passed 5 of 5 times
-    # except tests/test_ddp_graph_gpu.py::test_segmented_graph_ddp_matches_eager_ddp, whose EAGER two-rank run differed from
-    # the segmented-graph run in 2 of 5 (profiles/r06_eager_nan_bisect.txt); the product's data-parallel mode captures.
-    from . import ops
-
-    return not ops.GRAD_SLOTS
+    return EAGER_FORK or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())
 
 
 def reserve(device, n=None):

@@ -4,16 +4,19 @@ import torch
 from parallelwavegan_amd import ops, streams
 
 
-def test_eager_fork_is_refused_while_a_data_parallel_reducer_is_active(monkeypatch):
-    """Round 6: the eager fork (PWG_EAGER_BRANCH_STREAMS=1) is a single-process debugging mode; with gradient slots registered by a
-    data-parallel reducer it is refused (profiles/r06_eager_nan_bisect.txt).  Without the switch nothing forks outside a capture."""
+def test_fork_only_inside_a_capture_unless_the_debugging_switch_is_set(monkeypatch):
     monkeypatch.setattr(streams, "EAGER_FORK", False)
-    assert streams.fork_now() is False
+    assert streams.fork_now() is False  # (no GPU here: never capturing)
     monkeypatch.setattr(streams, "EAGER_FORK", True)
-    monkeypatch.setattr(ops, "GRAD_SLOTS", {})
     assert streams.fork_now() is True
-    monkeypatch.setattr(ops, "GRAD_SLOTS", {1234: ("slot", None, 0)})
-    assert streams.fork_now() is False
+
+
+def test_slot_add_without_a_device_is_a_plain_addition():
+    """ops.slot_add (round 6): CPU tensors / `later is True` take the plain in-place addition; the cross-stream form is
+    exercised by tests/test_ddp_graph_gpu.py."""
+    slot = torch.ones(2, 3)
+    ops.slot_add(slot, torch.full((6,), 2.0), True)
+    assert torch.equal(slot, torch.full((2, 3), 3.0))
 
 
 def test_run_branches_on_cpu_calls_the_branches_in_order():
